@@ -1,0 +1,270 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE ONLY — generate tests/golden/*.npz by running the reference itself.
+
+Runs ONLY in the build container (it needs /root/reference, which never travels to the GPU
+box); the fixtures it writes are plain data: seeded inputs + the outputs the reference's own
+functions produced on them with CPU PyTorch fp32.
+
+How each reference function is reached:
+  * modules that import as-is here: gcl.py, directau.py, selfcf.py, univariate/sept.py,
+    univariate/buir.py (directau.Interaction / LGCNEncoder are textually ncl.py's);
+  * ncl.py and ssl4rec.py stop at `from numba import jit` / `import faiss` (ordinary
+    ModuleNotFoundError; both packages stay absent).  Their loss functions do not use either
+    package, so the named FunctionDef nodes are taken out of the reference file with `ast` at
+    run time and executed unchanged against torch — no stand-in libraries, no source copied;
+  * lightgcn.py needs torch_geometric (absent): its loss block lightgcn.py:95-118 is a handful
+    of tensor expressions restated inline below; LGConv itself stays "parity unpinned".
+
+Usage:  python oracle/gen_golden.py   (writes tests/golden/)
+"""
+import ast
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(REF, "univariate"))
+
+
+def load_defs(path, names, methods=()):
+    """exec the named top-level functions (and `Class.method`s, as plain functions) of a reference file."""
+    tree = ast.parse(open(path).read())
+    wanted = []
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in names:
+            wanted.append(node)
+        if isinstance(node, ast.ClassDef):
+            for sub in node.body:
+                if isinstance(sub, ast.FunctionDef) and f"{node.name}.{sub.name}" in methods:
+                    wanted.append(sub)
+    ns = {"torch": torch, "F": F, "nn": torch.nn, "np": np, "device": torch.device("cpu")}
+    exec(compile(ast.Module(body=wanted, type_ignores=[]), path, "exec"), ns)
+    return ns
+
+
+def seeded_triples(rng, n_users, n_items, n_inter, n_dup):
+    raw_u = rng.choice(np.arange(1000, 1000 + 3 * n_users), n_users, replace=False)
+    raw_i = rng.choice(np.arange(5000, 5000 + 3 * n_items), n_items, replace=False)
+    u = raw_u[rng.integers(0, n_users, n_inter)]
+    i = raw_i[rng.integers(0, n_items, n_inter)]
+    # every user and every item at least once, plus explicit duplicate pairs
+    u = np.concatenate([raw_u, raw_u[rng.integers(0, n_users, n_items)], u, u[:n_dup]])
+    i = np.concatenate([raw_i[rng.integers(0, n_items, n_users)], raw_i, i, i[:n_dup]])
+    p = rng.permutation(u.size)
+    return [[str(a), str(b), 1.0] for a, b in zip(u[p], i[p])]
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    rng = np.random.default_rng(20250919)
+    import directau, selfcf, sept, gcl  # noqa: E401  (reference modules, imported as-is)
+
+    # ---------------------------------------------------------------- 1. graph build
+    train = seeded_triples(rng, 50, 30, 400, 12)
+    test = [[train[k][0], train[(k * 7) % len(train)][1], 1.0] for k in range(0, 60, 3)] + [["999999", "888888", 1.0]]
+    tr_u = np.array([t[0] for t in train])
+    tr_i = np.array([t[1] for t in train])
+
+    d_int = directau.Interaction({}, train, test)          # == ncl.py:46-88
+    coo = d_int.norm_adj
+    s_int = selfcf.Interaction({}, train, test)
+    s_adj = s_int.norm_adj.tocsr()
+    s_adj.sort_indices()
+
+    # gcl.load_data wants integer ids in space-separated files
+    int_u = rng.integers(0, 40, 300)
+    int_i = rng.integers(0, 25, 300)
+    tmp = tempfile.mkdtemp()
+    with open(os.path.join(tmp, "train.txt"), "w") as f:
+        f.writelines(f"{a} {b} 1\n" for a, b in zip(int_u, int_i))
+    with open(os.path.join(tmp, "test.txt"), "w") as f:
+        f.writelines(f"{a} {b} 1\n" for a, b in zip(int_u[:20] + 1, int_i[:20] + 2))
+    edge_index, _, _, g_nu, g_ni = gcl.load_data(os.path.join(tmp, "train.txt"), os.path.join(tmp, "test.txt"))
+
+    np.savez_compressed(
+        os.path.join(OUT, "graph_build.npz"),
+        train_user=tr_u, train_item=tr_i,
+        sorted_user_ids=np.array([d_int.id2user[k] for k in range(d_int.user_num)]),
+        sorted_item_ids=np.array([d_int.id2item[k] for k in range(d_int.item_num)]),
+        coo_row=coo.row.astype(np.int64), coo_col=coo.col.astype(np.int64), coo_data=coo.data.astype(np.float32),
+        seen_user_ids=np.array([s_int.id2user[k] for k in range(s_int.user_num)]),
+        seen_item_ids=np.array([s_int.id2item[k] for k in range(s_int.item_num)]),
+        norm_indptr=s_adj.indptr.astype(np.int64), norm_indices=s_adj.indices.astype(np.int64),
+        norm_data=s_adj.data.astype(np.float32),
+        gcl_user=int_u, gcl_item=int_i, gcl_test_user=int_u[:20] + 1, gcl_test_item=int_i[:20] + 2,
+        gcl_edge_index=edge_index.numpy(), gcl_num_users=g_nu, gcl_num_items=g_ni,
+    )
+
+    # ---------------------------------------------------------------- 2. propagation
+    n = d_int.user_num + d_int.item_num
+    d = 64
+    x0 = torch.empty(n, d)
+    torch.nn.init.xavier_uniform_(x0, generator=torch.Generator().manual_seed(0))
+    wgt = torch.randn(n, d, generator=torch.Generator().manual_seed(1))
+    out = {"x0": x0.numpy(), "w": wgt.numpy()}
+    for k_layers in (1, 2, 3):
+        enc = directau.LGCNEncoder(d_int, d, k_layers)
+        with torch.no_grad():
+            enc.embedding_dict["user_emb"].copy_(x0[: d_int.user_num])
+            enc.embedding_dict["item_emb"].copy_(x0[d_int.user_num:])
+        ue, ie, all_emb = enc()
+        final = torch.cat([ue, ie])
+        (final * wgt).sum().backward()
+        out[f"raw_mean_K{k_layers}"] = final.detach().numpy()
+        out[f"raw_last_K{k_layers}"] = all_emb[-1].detach().numpy()
+        out[f"raw_grad_K{k_layers}"] = torch.cat([enc.embedding_dict["user_emb"].grad, enc.embedding_dict["item_emb"].grad]).numpy()
+
+    ns = s_int.user_num + s_int.item_num
+    xs = torch.empty(ns, d)
+    torch.nn.init.xavier_uniform_(xs, generator=torch.Generator().manual_seed(2))
+    out["xs"] = xs.numpy()
+    for k_layers in (2, 3):
+        enc = selfcf.LGCN_Encoder(s_int, d, k_layers)
+        with torch.no_grad():
+            enc.embedding_dict["user_emb"].copy_(xs[: s_int.user_num])
+            enc.embedding_dict["item_emb"].copy_(xs[s_int.user_num:])
+        ue, ie = enc()
+        final = torch.cat([ue, ie])
+        (final * wgt[:ns]).sum().backward()
+        out[f"norm_mean_K{k_layers}"] = final.detach().numpy()
+        out[f"norm_grad_K{k_layers}"] = torch.cat([enc.embedding_dict["user_emb"].grad, enc.embedding_dict["item_emb"].grad]).numpy()
+
+    # sept.SEPT.encoder (sept.py:220-226) on the coalesced raw adjacency it builds (sept.py:42-50)
+    sp_int = sept.Interaction({}, train, test)
+    adj_t = sept.TFGraphInterface.convert_sparse_mat_to_tensor_inputs(sp_int.norm_adj)
+    fake = types.SimpleNamespace(n_layers=2)
+    xr = x0.clone().requires_grad_(True)
+    fin = sept.SEPT.encoder(fake, xr, adj_t)
+    (fin * wgt).sum().backward()
+    out["sept_mean_K2"] = fin.detach().numpy()
+    out["sept_grad_K2"] = xr.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "propagation.npz"), **out)
+
+    # ---------------------------------------------------------------- 3. contrast
+    ncl = load_defs(os.path.join(REF, "ncl.py"), {"InfoNCE", "bpr_loss", "l2_reg_loss"},
+                    {"NCLModel.ssl_layer_loss", "NCLModel.ProtoNCE_loss"})
+    s4r = load_defs(os.path.join(REF, "ssl4rec.py"), {"batch_softmax_loss", "InfoNCE", "l2_reg_loss"})
+    out = {}
+    g = torch.Generator().manual_seed(3)
+    for m in (1, 7, 257, 1000):
+        z1 = torch.randn(m, d, generator=g)
+        z2 = (z1 + 0.5 * torch.randn(m, d, generator=g))
+        out[f"z1_{m}"], out[f"z2_{m}"] = z1.numpy(), z2.numpy()
+        for temp in (0.1, 0.2, 0.5):
+            a, b = z1.clone().requires_grad_(True), z2.clone().requires_grad_(True)
+            loss = gcl.info_nce_loss(a, b, temp)
+            loss.backward()
+            out[f"gcl_loss_{m}_{temp}"] = loss.item()
+            if m in (7, 257) and temp == 0.2:
+                out[f"gcl_g1_{m}"], out[f"gcl_g2_{m}"] = a.grad.numpy(), b.grad.numpy()
+        for b_cos in (True, False):
+            a, b = (0.3 * z1).clone().requires_grad_(True), (0.3 * z2).clone().requires_grad_(True)
+            loss = ncl["InfoNCE"](a, b, 0.2, b_cos)
+            loss.backward()
+            out[f"ncl_infonce_{m}_{int(b_cos)}"] = loss.item()
+            if m == 257:
+                out[f"ncl_infonce_g1_{m}_{int(b_cos)}"] = a.grad.numpy()
+                out[f"ncl_infonce_g2_{m}_{int(b_cos)}"] = b.grad.numpy()
+            out[f"s4r_infonce_{m}_{int(b_cos)}"] = s4r["InfoNCE"](0.3 * z1, 0.3 * z2, 0.2, b_cos).item()
+        out[f"s4r_bsl_{m}"] = s4r["batch_softmax_loss"](z1, z2, 0.2).item()
+
+    # NCL structure / prototype losses on the toy graph (centroids + assignments injected)
+    nu, ni = d_int.user_num, d_int.item_num
+    ctx = torch.randn(n, d, generator=g) * 0.1 + x0
+    bsz = 32
+    uidx = torch.randint(0, nu, (bsz,), generator=g).tolist()
+    iidx = torch.randint(0, ni, (bsz,), generator=g).tolist()
+    kc = 5
+    self_ = types.SimpleNamespace(
+        data=types.SimpleNamespace(user_num=nu, item_num=ni), ssl_temp=0.1, ssl_reg=1e-6, alpha=1.5,
+        proto_reg=8e-8, batch_size=bsz,
+        user_centroids=torch.randn(kc, d, generator=g), item_centroids=torch.randn(kc, d, generator=g),
+        user_2cluster=torch.randint(0, kc, (nu,), generator=g), item_2cluster=torch.randint(0, kc, (ni,), generator=g))
+    ctx_r, x0_r = ctx.clone().requires_grad_(True), x0.clone().requires_grad_(True)
+    ssl = ncl["ssl_layer_loss"](self_, ctx_r, x0_r, uidx, iidx)
+    ssl.backward()
+    x0_p = x0.clone().requires_grad_(True)
+    # ProtoNCE_loss calls the module-level InfoNCE: it is in the same exec namespace
+    proto = ncl["ProtoNCE_loss"](self_, x0_p, uidx, iidx)
+    proto.backward()
+    out.update(ncl_ctx=ctx.numpy(), ncl_x0=x0.numpy(), ncl_uidx=np.array(uidx), ncl_iidx=np.array(iidx),
+               ncl_num_users=nu, ncl_ssl_temp=0.1, ncl_ssl_reg=1e-6, ncl_alpha=1.5, ncl_proto_reg=8e-8, ncl_bsz=bsz,
+               ncl_ucent=self_.user_centroids.numpy(), ncl_icent=self_.item_centroids.numpy(),
+               ncl_u2c=self_.user_2cluster.numpy(), ncl_i2c=self_.item_2cluster.numpy(),
+               ncl_ssl=ssl.item(), ncl_ssl_gctx=ctx_r.grad.numpy(), ncl_ssl_gx0=x0_r.grad.numpy(),
+               ncl_proto=proto.item(), ncl_proto_gx0=x0_p.grad.numpy())
+    np.savez_compressed(os.path.join(OUT, "contrast.npz"), **out)
+
+    # ---------------------------------------------------------------- 4. BPR / regularisers
+    out = {}
+    ut = torch.randn(40, d, generator=g) * 0.3
+    it = torch.randn(25, d, generator=g) * 0.3
+    bq = 300
+    ui = torch.randint(0, 40, (bq,), generator=g)
+    pi = torch.randint(0, 25, (bq,), generator=g)
+    ni1 = torch.randint(0, 25, (bq,), generator=g)
+    ni3 = torch.randint(0, 25, (bq, 3), generator=g)
+    out.update(user_tab=ut.numpy(), item_tab=it.numpy(), u_idx=ui.numpy(), i_idx=pi.numpy(), j_idx=ni1.numpy(), j_idx3=ni3.numpy())
+
+    def run(fn_loss, name, neg_idx):
+        a, b = ut.clone().requires_grad_(True), it.clone().requires_grad_(True)
+        loss = fn_loss(a, b, neg_idx)
+        loss.backward()
+        out[f"{name}_loss"], out[f"{name}_gu"], out[f"{name}_gi"] = loss.item(), a.grad.numpy(), b.grad.numpy()
+
+    run(lambda a, b, nj: ncl["bpr_loss"](a[ui], b[pi], b[nj]), "ncl_bpr", ni1)          # ncl.py:116-120
+    run(lambda a, b, nj: sept.bpr_loss(a[ui], b[pi], b[nj]), "sept_bpr", ni1)             # sept.py:34-38
+    run(lambda a, b, nj: ncl["l2_reg_loss"](1e-4, a[ui], b[pi], b[nj]), "ncl_l2reg", ni1)  # ncl.py:122-123
+    out["directau_l2reg_loss"] = directau.l2_reg_loss(1e-4, ut[ui], it[pi], it[ni1]).item()
+
+    def lightgcn_block(a, b, nj, reg_weight=1e-4):
+        # lightgcn.py:95-108,118 restated inline (module needs torch_geometric): bpr + reg
+        uv, pv = a[ui], b[pi]
+        nv = b[nj]
+        if nj.dim() == 1:
+            ns_ = (uv * nv).sum(dim=-1)
+        else:
+            ns_ = (uv.unsqueeze(1) * nv).sum(dim=-1).mean(dim=1)
+        ps_ = (uv * pv).sum(dim=-1)
+        loss = -torch.log(torch.sigmoid(ps_ - ns_)).mean()
+        return loss + reg_weight * (uv.norm(2).pow(2) + pv.norm(2).pow(2))
+
+    run(lightgcn_block, "lgcn_block_n1", ni1)
+    run(lightgcn_block, "lgcn_block_n3", ni3)
+
+    def gcl_block(a, b, nj, reg_weight=1e-4):
+        # gcl.py:216-223 (bpr + reg part) restated inline: it lives inside the tuner loop body
+        u_e, p_e, n_e = a[ui], b[pi], b[nj]
+        bpr = -F.logsigmoid((u_e * p_e).sum(1) - (u_e * n_e).sum(1)).mean()
+        reg = (u_e.norm(2).pow(2) + p_e.norm(2).pow(2) + n_e.norm(2).pow(2)) / len(ui)
+        return bpr + reg_weight * reg
+
+    run(gcl_block, "gcl_block", ni1)
+    np.savez_compressed(os.path.join(OUT, "bpr.npz"), **out)
+
+    # ---------------------------------------------------------------- 5. augmentation properties
+    torch.manual_seed(5)
+    np.random.seed(5)
+    ei = edge_index
+    kept = gcl.EdgeRemoving(0.3)(ei)
+    dropped = sept.GraphAugmentor.edge_dropout(sp_int.norm_adj.tocsr(), 0.25)
+    nnz_unique = len(sp_int.norm_adj.tocsr().nonzero()[0])
+    np.savez_compressed(os.path.join(OUT, "augment.npz"),
+                        gcl_pe=0.3, gcl_nnz=ei.shape[1], gcl_kept=kept.shape[1],
+                        sept_rate=0.25, sept_nnz=nnz_unique, sept_kept=dropped.nnz,
+                        sept_vals_all_one=bool((dropped.data == 1.0).all()))
+    print("golden fixtures written to", os.path.abspath(OUT))
+    for fn in sorted(os.listdir(OUT)):
+        print("  ", fn, os.path.getsize(os.path.join(OUT, fn)), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""Headline benchmark: edges propagated/sec (+ InfoNCE pairs/sec) of the LightGCN d=64 hot path.
+
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the
+driver launches it under torch.distributed.run, one rank per GPU.  W untimed warm-up steps, then
+exactly K timed steps between barrier + synchronize, MAX over ranks, rank 0 prints ONE JSON line.
+
+A "step" is one pass of the hot path over one batch of synthetic input: the K_layers-layer
+LightGCN message pass (normalised bipartite adjacency SpMM x embedding table, layer combine
+fused) over the whole graph — forward only for the headline `value`; fwd+bwd, InfoNCE and BPR
+rates are measured separately and reported under "extra".
+
+Workloads:
+  cfg2  U=1M  I=100K E=10M  (N=1.1M,  nnz=20M)   K=3 d=64   <- N=1 default (BASELINE configs[1])
+  cfg4  U=10M I=1M   E=100M (N=11M,   nnz=200M)  K=3 d=64
+  cfg1  U=943 I=1682 E=80K                        K=2 d=64   (plumbing size)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    "cfg1": dict(users=943, items=1682, edges=80_000, layers=2),
+    "cfg2": dict(users=1_000_000, items=100_000, edges=10_000_000, layers=3),
+    "cfg4": dict(users=10_000_000, items=1_000_000, edges=100_000_000, layers=3),
+}
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+SEED = 20250919
+
+
+def synth_interactions_device(n_users, n_items, n_edges, seed, device):
+    """Same recipe as oracle_np.synthetic_interactions (users uniform, items Zipf(1) capped at
+    0.5 % each, unique pairs, every user >= 1 edge), generated with torch on the GPU."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    p = 1.0 / torch.arange(1, n_items + 1, device=device, dtype=torch.float64)
+    p /= p.sum()
+    cap = 0.005
+    for _ in range(50):
+        over = p > cap
+        if not bool(over.any()):
+            break
+        excess = (p[over] - cap).sum()
+        p[over] = cap
+        p[~over] += excess * p[~over] / p[~over].sum()
+    cdf = torch.cumsum(p, 0)
+    cdf[-1] = 1.0
+    perm = torch.randperm(n_items, generator=g, device=device)
+
+    def draw_items(n):
+        r = torch.rand(n, generator=g, device=device, dtype=torch.float64)
+        return perm[torch.searchsorted(cdf, r, right=True).clamp_(max=n_items - 1)]
+
+    keys = torch.arange(n_users, device=device, dtype=torch.int64) * n_items + draw_items(n_users)
+    need = n_edges - n_users
+    while need > 0:
+        n = int(need * 1.15) + 16
+        k = torch.randint(0, n_users, (n,), generator=g, device=device) * n_items + draw_items(n)
+        k = torch.unique(k)
+        k = k[~torch.isin(k, keys)]
+        if k.numel() > need:
+            k = k[torch.randperm(k.numel(), generator=g, device=device)[:need]]
+        keys = torch.cat([keys, k])
+        need = n_edges - keys.numel()
+    keys = keys[torch.randperm(keys.numel(), generator=g, device=device)]
+    return keys // n_items, keys % n_items
+
+
+def sym_norm_csr_device(users, items, n_users, n_items):
+    """D^-1/2 (R + R^T) D^-1/2 as CSR, built with torch ops on the device (bench plumbing; the
+    pairs are unique so no duplicate merge is needed; rows sorted by (row, col) like selfcf.py:297)."""
+    n = n_users + n_items
+    row = torch.cat([users, items + n_users])
+    col = torch.cat([items + n_users, users])
+    order = torch.argsort(row * n + col)
+    row, col = row[order], col[order]
+    deg = torch.bincount(row, minlength=n)
+    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=row.device)
+    rowptr[1:] = torch.cumsum(deg, 0)
+    dinv = deg.to(torch.float32).pow(-0.5)
+    dinv[torch.isinf(dinv)] = 0.0
+    val = dinv[row] * dinv[col]
+    return rowptr, col.to(torch.int32), val
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
+    ap.add_argument("--dim", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import recommendation_amd as ra
+    from recommendation_amd import functional as Fn
+
+    if world > 1:
+        from recommendation_amd import distributed as gdist
+        return gdist.bench_main(args, rank, world, dev)
+
+    name = args.workload or "cfg2"
+    wl = WORKLOADS[name]
+    n_u, n_i, n_e, k_layers, d = wl["users"], wl["items"], wl["edges"], wl["layers"], args.dim
+    n = n_u + n_i
+    t_build = time.time()
+    users, items = synth_interactions_device(n_u, n_i, n_e, SEED, dev)
+    rowptr, col, val = sym_norm_csr_device(users, items, n_u, n_i)
+    graph = ra.CsrGraph(rowptr, col, val, n, n, dev, symmetric=True)
+    nnz = graph.nnz
+    x0 = torch.empty(n, d, device=dev)
+    torch.nn.init.xavier_uniform_(x0, generator=torch.Generator(device=dev).manual_seed(0))
+    torch.cuda.synchronize()
+    t_build = time.time() - t_build
+
+    events = []
+    Fn.EVENT_SINK = None
+
+    def step():
+        with torch.no_grad():
+            return Fn.lightgcn_propagate(graph, x0, k_layers, combine="sum")
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    Fn.EVENT_SINK = events          # HIP events around every gcr_spmm_csr_f32 launch (same stream)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    Fn.EVENT_SINK = None
+    elapsed = t1 - t0
+    ms_per_step = 1e3 * elapsed / args.steps
+    edges_per_s = nnz * k_layers * args.steps / elapsed
+
+    launch_ms = [a.elapsed_time(b) for a, b in events]
+    avg_launch_ms = sum(launch_ms) / len(launch_ms)
+    bytes_alg = nnz * (4 + 4 + 4 * d) + n * (4 * d + 4)      # BASELINE.md §4 / SURVEY §8d, per layer
+    achieved = bytes_alg / (avg_launch_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": "spmm_parts (gcr_spmm_csr_f32)", "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "bytes_alg_per_launch": bytes_alg, "avg_launch_ms": round(avg_launch_ms, 4),
+                "compulsory_bytes_per_launch": nnz * 8 + (n + 1) * 4 + 2 * n * 4 * d}
+
+    extra = {"graph_build_s": round(t_build, 2), "nnz": nnz, "n_nodes": n,
+             "spmm_parts": graph.plan.n_parts, "spmm_split_rows": graph.plan.n_long}
+    if not args.no_extra:
+        extra.update(bench_extra(ra, Fn, graph, x0, k_layers, nnz, dev))
+
+    cpu = None
+    if not args.no_cpu_baseline:
+        cpu = cpu_baseline(graph, x0, k_layers, nnz)
+
+    line = {
+        "metric": "edges propagated/sec (LightGCN d=%d, %d-layer fwd message pass)" % (d, k_layers),
+        "value": edges_per_s, "unit": "edges/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{name}: LightGCN {k_layers}-layer d={d}, {n_u} users x {n_i} items / {n_e} "
+                               f"interactions (nnz={nnz}), sym-normalised CSR, forward propagation + fused layer sum",
+                   "users": n_u, "items": n_i, "interactions": n_e, "layers": k_layers, "dim": d},
+        "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
+    }
+    print(json.dumps(line))
+
+
+def bench_extra(ra, Fn, graph, x0, k_layers, nnz, dev):
+    """Secondary rates, each timed on its own (not part of `value`)."""
+    out = {}
+
+    def timeit(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / reps
+
+    xg = x0.clone().requires_grad_(True)
+
+    def fwd_bwd():
+        xg.grad = None
+        Fn.lightgcn_propagate(graph, xg, k_layers, combine="mean").sum().backward()
+
+    t = timeit(fwd_bwd, 5)
+    out["fwd_bwd_edges_per_s"] = nnz * 2 * k_layers / t
+    out["fwd_bwd_ms"] = 1e3 * t
+    return out
+
+
+def cpu_baseline(graph, x0, k_layers, nnz):
+    """The C restatement of the reference path (oracle/oracle.c, OpenMP) on this box's host cores,
+    bounded to ~10-30 s: the same graph, the same K-layer propagation."""
+    from oracle import oracle_c
+    rowptr = graph.rowptr_host
+    col = graph.col.cpu().numpy()
+    val = graph.val.cpu().numpy()
+    xh = x0.cpu().numpy()
+    threads = oracle_c.num_threads()
+    oracle_c.lightgcn_propagate(rowptr, col, val, xh, 1, "sum")      # warm-up (page-in, threads)
+    reps, spent = 0, 0.0
+    while spent < 10.0 and reps < 5:
+        t = time.perf_counter()
+        oracle_c.lightgcn_propagate(rowptr, col, val, xh, k_layers, "sum")
+        spent += time.perf_counter() - t
+        reps += 1
+    return {"value": nnz * k_layers * reps / spent, "unit": "edges/s", "cores": threads, "kind": "port",
+            "sample": f"{reps} x full {k_layers}-layer CSR propagation of the same graph (oracle/oracle.c, "
+                      f"OpenMP {threads} threads, fp32)"}
+
+
+if __name__ == "__main__":
+    main()

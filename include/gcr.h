@@ -1,0 +1,82 @@
+/*
+ * gcr.h — C ABI of libgcr (graph-contrastive recommender hot path, MI355X / gfx950).
+ *
+ * The reference (Cmint22/Recommendation) has no FFI of its own: its op boundary is the stock
+ * PyTorch call inside each model class.  Each entry point below names the
+ * reference call site(s) it replaces.  A maintainer binds them with ctypes;
+ * recommendation_amd/_lib.py is that binding.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless the name ends in _host; buffers are caller-owned
+ *     and only borrowed for the call; no hidden allocations, workspaces are passed in;
+ *   - `stream` is a hipStream_t passed as void*; launches are asynchronous on it; no global
+ *     mutable state, re-entrant across streams;
+ *   - dense matrices are row-major contiguous fp32 with row stride d; column ids int32,
+ *     row pointers int64;
+ *   - return value: 0 = ok, GCR_EINVAL.. = argument error (nothing launched),
+ *     -(1000 + hipError_t) = runtime error.
+ */
+#ifndef GCR_H
+#define GCR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GCR_OK 0
+#define GCR_EINVAL (-1)      /* null pointer / negative size / unsupported d */
+#define GCR_EUNSUPPORTED (-2)
+#define GCR_HIP_ERROR_BASE (-1000)
+
+/* library / build identification: returns e.g. 100 for 0.1.0; arch string is "gfx950". */
+int32_t gcr_version(void);
+const char* gcr_arch(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * SpMM work plan (host, one-off per graph — the reference also builds its adjacency once:
+ * ncl.py:74-85, selfcf.py:291-306).  Rows are packed into partitions of <= nnz_per_part
+ * non-zeros (<= 64 whole rows each); rows longer than nnz_per_part are split into equal chunks
+ * whose partial sums are combined in a fixed order (deterministic, no atomics).
+ * desc is [n_parts][4] int64: {nnz_begin, nnz_end, row0 | (nrows << 32), slot (or -1)}.
+ * --------------------------------------------------------------------------------------------- */
+int32_t gcr_spmm_plan_size_host(const int64_t* rowptr_host, int64_t n_rows, int32_t nnz_per_part,
+                                int64_t* n_parts, int64_t* n_long_rows, int64_t* n_slots);
+int32_t gcr_spmm_plan_fill_host(const int64_t* rowptr_host, int64_t n_rows, int32_t nnz_per_part,
+                                int64_t* desc_host, int32_t* long_row_host, int32_t* long_slot0_host);
+
+/* flags for gcr_spmm_csr_f32 */
+#define GCR_SPMM_ROW_L2NORM 1u /* y <- y / max(||y||_2, 1e-12) per row (sept.py:224, mhcn.py:441-457) */
+
+/*
+ * y = epilogue( val_scale * A[keep] x )            A: CSR [n_rows, n_cols], x: [n_cols, d]
+ * replaces  torch.sparse.mm(self.sparse_norm_adj, emb)   ncl.py:419, directau.py:290,
+ *           selfcf.py:479, buir.py:317,334, sept.py:223, sept_social.py:373,382,
+ *           mhcn.py:440-456,494 and LGConv()(x, edge_index) lightgcn.py:25 (after gcn_norm).
+ * Fused layer combine (lightgcn.py:26 `x += out`, ncl.py:421 mean over layers):
+ *           acc_out[r] = (acc_in[r] + y[r]) * acc_scale     when acc_out != NULL
+ * val == NULL means all-ones values (the raw 0/1 adjacency of ncl.py:74-85).
+ * keep_bits == NULL means no edge mask; otherwise bit e of the little-endian uint32 bitmap keeps
+ * non-zero e (gcl.py:22-25 / sept.py:55-61 / buir.py:300-309 edge dropout consumed as a predicate).
+ * inv_norm_out (optional, [n_rows]) receives 1/max(||.||,1e-12) under GCR_SPMM_ROW_L2NORM.
+ * y may be NULL when only acc_out is wanted.  partials: fp32 workspace [n_slots, d].
+ */
+int32_t gcr_spmm_csr_f32(const int64_t* desc, int64_t n_parts,
+                         const int32_t* long_row, const int32_t* long_slot0, int64_t n_long_rows,
+                         const int64_t* rowptr, const int32_t* col, const float* val,
+                         const uint32_t* keep_bits, float val_scale,
+                         const float* x, int32_t d,
+                         float* y, const float* acc_in, float* acc_out, float acc_scale,
+                         uint32_t flags, float* inv_norm_out, float* partials,
+                         int64_t n_rows, int64_t n_cols, void* stream);
+
+/* Counts structural errors of a CSR on the device (rowptr not monotone / not ending at nnz,
+ * col outside [0, n_cols)); *n_errors_dev is a device int64 the caller zeroes and reads back. */
+int32_t gcr_csr_validate(const int64_t* rowptr, const int32_t* col, int64_t n_rows, int64_t n_cols,
+                         int64_t nnz, int64_t* n_errors_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GCR_H */

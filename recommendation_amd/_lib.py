@@ -1,0 +1,76 @@
+"""ctypes binding of libgcr.so — the C ABI declared in include/gcr.h.
+
+This is the binding a maintainer of the reference would add.  There is no
+CPU fallback: if the HIP library is missing or a call fails, the op raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int32, c_int64, c_uint32, c_void_p
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libgcr.so")
+
+_P = c_void_p  # every device / host buffer crosses the ABI as a plain pointer
+
+# name -> (restype, argtypes); mirrors include/gcr.h one to one
+SIGNATURES = {
+    "gcr_version": (c_int32, []),
+    "gcr_arch": (c_char_p, []),
+    "gcr_spmm_plan_size_host": (c_int32, [_P, c_int64, c_int32, _P, _P, _P]),
+    "gcr_spmm_plan_fill_host": (c_int32, [_P, c_int64, c_int32, _P, _P, _P]),
+    "gcr_spmm_csr_f32": (c_int32, [_P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, c_float, _P, c_int32,
+                                   _P, _P, _P, c_float, c_uint32, _P, _P, c_int64, c_int64, _P]),
+    "gcr_csr_validate": (c_int32, [_P, _P, c_int64, c_int64, c_int64, _P, _P]),
+}
+
+_lib = None
+
+
+class GcrError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads libgcr.so once; raises loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GcrError(
+                f"{LIB_PATH} is missing: the HIP extension is not built "
+                "(run `python -c 'import __graft_entry__ as g; g.build()'`); there is no CPU fallback")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        if rc <= -1000:
+            raise GcrError(f"{what}: HIP runtime error {-(rc + 1000)}")
+        raise GcrError(f"{what}: invalid or unsupported arguments (code {rc})")
+
+
+def dptr(t):
+    """Device (or host) pointer of a contiguous tensor, None -> NULL."""
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise GcrError("libgcr needs contiguous tensors")
+    return c_void_p(t.data_ptr())
+
+
+def cur_stream(device=None):
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise GcrError("libgcr operates on HIP device tensors only (no CPU fallback)")

@@ -1,0 +1,180 @@
+"""Differentiable ops over libgcr (HIP kernels behind the C ABI of include/gcr.h).
+
+Each op names the reference expression it stands in for.  Tensors must live on the GPU; a
+missing/failed HIP library raises (there is deliberately no eager PyTorch fallback here).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from .graph import CsrGraph
+
+SPMM_ROW_L2NORM = 1
+
+# bench.py sets this to a list to receive a (start, end) HIP event pair per gcr_spmm_csr_f32
+# launch, recorded on the stream the kernel is launched on
+EVENT_SINK = None
+
+
+def _check_dense(x, n_rows, name):
+    if x.dtype != torch.float32 or x.dim() != 2 or x.shape[0] != n_rows:
+        raise ValueError(f"{name} must be float32 [{n_rows}, d], got {tuple(x.shape)} {x.dtype}")
+    if not (1 <= x.shape[1] <= 256):
+        raise ValueError("embedding dim must be in [1, 256]")
+
+
+def spmm_into(graph: CsrGraph, x, *, y=None, acc_in=None, acc_out=None, acc_scale=1.0, val_scale=1.0,
+              keep_bits=None, l2norm=False, inv_norm_out=None):
+    """Raw launch of gcr_spmm_csr_f32: y = epilogue(val_scale * A[keep] x); optional fused layer
+    combine acc_out = (acc_in + y) * acc_scale (lightgcn.py:26, ncl.py:421) and row L2
+    normalise (sept.py:224).  Outputs are caller-allocated; nothing is recorded for autograd."""
+    _lib.require_cuda(x, y, acc_in, acc_out, keep_bits, inv_norm_out)
+    x = x.contiguous()
+    _check_dense(x, graph.n_cols, "x")
+    d = x.shape[1]
+    for t, nm in ((y, "y"), (acc_in, "acc_in"), (acc_out, "acc_out")):
+        if t is not None:
+            _check_dense(t, graph.n_rows, nm)
+            if t.shape[1] != d or not t.is_contiguous():
+                raise ValueError(f"{nm} must be contiguous [{graph.n_rows}, {d}]")
+    if y is None and acc_out is None:
+        raise ValueError("need y and/or acc_out")
+    if keep_bits is not None and (keep_bits.dtype != torch.int32 or keep_bits.numel() * 32 < graph.nnz):
+        raise ValueError("keep_bits must be an int32 bitmap with >= nnz bits")
+    if inv_norm_out is not None and (inv_norm_out.dtype != torch.float32 or inv_norm_out.numel() != graph.n_rows):
+        raise ValueError("inv_norm_out must be float32 [n_rows]")
+    p = graph.plan
+    ws = graph.workspace(d)
+    sink = EVENT_SINK
+    if sink is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    rc = _lib.lib().gcr_spmm_csr_f32(
+        _lib.dptr(p.desc), p.n_parts, _lib.dptr(p.long_row), _lib.dptr(p.long_slot0), p.n_long,
+        _lib.dptr(graph.rowptr), _lib.dptr(graph.col), _lib.dptr(graph.val), _lib.dptr(keep_bits), float(val_scale),
+        _lib.dptr(x), d, _lib.dptr(y), _lib.dptr(acc_in), _lib.dptr(acc_out), float(acc_scale),
+        SPMM_ROW_L2NORM if l2norm else 0, _lib.dptr(inv_norm_out), _lib.dptr(ws),
+        graph.n_rows, graph.n_cols, _lib.cur_stream(x.device))
+    _lib.check(rc, "gcr_spmm_csr_f32")
+    if sink is not None:
+        ev1.record()
+        sink.append((ev0, ev1))
+    return y if y is not None else acc_out
+
+
+class _SpMM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, graph, keep_bits, keep_bits_t, val_scale):
+        ctx.graph, ctx.keep_bits_t, ctx.val_scale = graph, keep_bits_t, val_scale
+        y = torch.empty(graph.n_rows, x.shape[1], dtype=torch.float32, device=x.device)
+        return spmm_into(graph, x, y=y, keep_bits=keep_bits, val_scale=val_scale)
+
+    @staticmethod
+    def backward(ctx, dy):
+        gt = ctx.graph.t
+        dx = torch.empty(gt.n_rows, dy.shape[1], dtype=torch.float32, device=dy.device)
+        spmm_into(gt, dy.contiguous(), y=dx, keep_bits=ctx.keep_bits_t, val_scale=ctx.val_scale)
+        return dx, None, None, None, None
+
+
+def spmm(graph: CsrGraph, x, keep_bits=None, keep_bits_t=None, val_scale=1.0):
+    """Drop-in for `torch.sparse.mm(A, x)` (ncl.py:419 and the 13 other call sites of SURVEY §2.3
+    S1), differentiable w.r.t. x: backward is the same kernel on A^T.  `keep_bits` is an edge-
+    dropout bitmap in A's non-zero order, `keep_bits_t` the same mask in A^T's order (only
+    needed for backward through an asymmetric graph / mask)."""
+    if keep_bits is not None and keep_bits_t is None and graph.symmetric is False and x.requires_grad:
+        raise ValueError("backward through a masked asymmetric graph needs keep_bits_t")
+    if keep_bits is not None and keep_bits_t is None:
+        keep_bits_t = keep_bits
+    return _SpMM.apply(x, graph, keep_bits, keep_bits_t, float(val_scale))
+
+
+class _Propagate(torch.autograd.Function):
+    """final = c * sum_{k=0..K} A^k x0 (c = 1 or 1/(K+1)), optionally also every layer output.
+    Linear in x0, so backward is the same recurrence on A^T (Horner form):
+        h_K = g_K + c g_final ; h_k = g_k + c g_final + A^T h_{k+1} ; dx0 = h_0."""
+
+    @staticmethod
+    def forward(ctx, x0, graph, n_layers, scale, want_layers):
+        ctx.graph, ctx.n_layers, ctx.scale, ctx.want_layers = graph, n_layers, scale, want_layers
+        x0 = x0.contiguous()
+        cur, acc = x0, x0
+        layers = []
+        for k in range(n_layers):
+            last = k == n_layers - 1
+            need_y = want_layers or not last
+            y = torch.empty_like(x0) if need_y else None
+            acc_out = torch.empty_like(x0) if k == 0 else acc  # in place after the first layer
+            spmm_into(graph, cur, y=y, acc_in=acc, acc_out=acc_out, acc_scale=scale if last else 1.0)
+            acc = acc_out
+            if need_y:
+                cur = y
+                layers.append(y)
+        if n_layers == 0:
+            acc = x0 * scale
+        return (acc, *layers) if want_layers else acc
+
+    @staticmethod
+    def backward(ctx, g_final, *g_layers):
+        gt, K, c = ctx.graph.t, ctx.n_layers, ctx.scale
+        base = g_final.contiguous() * c
+        if K == 0:
+            return base, None, None, None, None
+        gl = [g.contiguous() if g is not None else None for g in g_layers] if ctx.want_layers else [None] * K
+        h = base if gl[K - 1] is None else base + gl[K - 1]
+        for k in range(K - 1, 0, -1):
+            acc_in = base if gl[k - 1] is None else base + gl[k - 1]
+            out = torch.empty_like(base)
+            spmm_into(gt, h, acc_in=acc_in, acc_out=out)
+            h = out
+        dx0 = torch.empty_like(base)
+        spmm_into(gt, h, acc_in=base, acc_out=dx0)
+        return dx0, None, None, None, None
+
+
+def lightgcn_propagate(graph: CsrGraph, x0, n_layers: int, combine: str = "mean", return_layers: bool = False):
+    """K-layer LightGCN message pass with the layer combine fused into the SpMM epilogue.
+    combine='mean' -> ncl.py:415-422 / selfcf.py:475-485 (mean of the K+1 layer outputs);
+    combine='sum'  -> lightgcn.py:21-27 (x += out, no division, Q3).
+    Returns final [N, d] (and the list [x0, A x0, ..., A^K x0] when return_layers)."""
+    if combine not in ("mean", "sum"):
+        raise ValueError("combine must be 'mean' or 'sum'")
+    _lib.require_cuda(x0)
+    _check_dense(x0, graph.n_cols, "x0")
+    if graph.n_rows != graph.n_cols:
+        raise ValueError("propagation needs a square operator")
+    scale = 1.0 / (n_layers + 1) if combine == "mean" else 1.0
+    out = _Propagate.apply(x0, graph, int(n_layers), scale, bool(return_layers))
+    if return_layers:
+        return out[0], [x0, *out[1:]]
+    return out
+
+
+class _NormProp(torch.autograd.Function):
+    """One SEPT/MHCN layer: y = normalize(A x) row-wise (sept.py:223-224); saves y and 1/||Ax||."""
+
+    @staticmethod
+    def forward(ctx, x, graph):
+        y = torch.empty(graph.n_rows, x.shape[1], dtype=torch.float32, device=x.device)
+        inv = torch.empty(graph.n_rows, dtype=torch.float32, device=x.device)
+        spmm_into(graph, x.contiguous(), y=y, l2norm=True, inv_norm_out=inv)
+        ctx.graph = graph
+        ctx.save_for_backward(y, inv)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, inv = ctx.saved_tensors
+        # d(Ax) = (dy - y <y, dy>) / max(||Ax||, eps); rows clamped by eps have inv = 1e12 and y = 0
+        dz = (dy - y * (y * dy).sum(1, keepdim=True)) * inv.unsqueeze(1)
+        gt = ctx.graph.t
+        dx = torch.empty(gt.n_rows, dy.shape[1], dtype=torch.float32, device=dy.device)
+        spmm_into(gt, dz.contiguous(), y=dx)
+        return dx, None
+
+
+def spmm_l2norm(graph: CsrGraph, x):
+    """`F.normalize(torch.sparse.mm(adj, emb), dim=1)` (sept.py:223-224, mhcn.py:440-457) in one kernel."""
+    _lib.require_cuda(x)
+    return _NormProp.apply(x, graph)

@@ -1,0 +1,188 @@
+"""Prepared sparse operators for the LightGCN message pass (device-resident CSR + work plan).
+
+Mirrors what the reference builds once per model and then reuses every step:
+  * raw 0/1 bipartite adjacency, duplicates kept       ncl.py:74-85 (= directau.py:130-141,
+                                                        sept.py:134-145, mhcn.py:245-256)   [Q1]
+  * D^-1/2 (R + R^T) D^-1/2, duplicates summed          selfcf.py:291-306 + 240-255, ssl4rec.py:79-88
+  * gcn_norm(add_self_loops=False) edge weights         lightgcn.py:17,25 (torch_geometric LGConv)
+Layout in HBM: rowptr int64[N+1], col int32[nnz], val fp32[nnz] (absent for the all-ones raw
+adjacency), plus the SpMM plan (32-byte partition descriptors) and, for split rows, an fp32
+partial-sum workspace [n_slots, d].
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+DEFAULT_NNZ_PER_PART = 256
+
+
+def _np_i64(a):
+    if isinstance(a, torch.Tensor):
+        a = a.detach().cpu().numpy()
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+class SpmmPlan:
+    """Host-built partition list for gcr_spmm_csr_f32 (include/gcr.h)."""
+
+    def __init__(self, rowptr_host: np.ndarray, device, nnz_per_part=DEFAULT_NNZ_PER_PART):
+        L = _lib.lib()
+        rowptr_host = np.ascontiguousarray(rowptr_host, dtype=np.int64)
+        n_rows = rowptr_host.size - 1
+        sizes = (ctypes.c_int64 * 3)()
+        p = ctypes.addressof(sizes)
+        _lib.check(L.gcr_spmm_plan_size_host(rowptr_host.ctypes.data, n_rows, nnz_per_part, p, p + 8, p + 16),
+                   "gcr_spmm_plan_size_host")
+        self.n_parts, self.n_long, self.n_slots = int(sizes[0]), int(sizes[1]), int(sizes[2])
+        desc = np.empty((max(self.n_parts, 1), 4), dtype=np.int64)
+        long_row = np.zeros(max(self.n_long, 1), dtype=np.int32)
+        long_slot0 = np.zeros(self.n_long + 1, dtype=np.int32)
+        _lib.check(L.gcr_spmm_plan_fill_host(rowptr_host.ctypes.data, n_rows, nnz_per_part, desc.ctypes.data,
+                                             long_row.ctypes.data, long_slot0.ctypes.data), "gcr_spmm_plan_fill_host")
+        self.nnz_per_part = nnz_per_part
+        self.desc_host = desc[: self.n_parts]
+        self.desc = torch.from_numpy(desc).to(device)
+        self.long_row = torch.from_numpy(long_row).to(device)
+        self.long_slot0 = torch.from_numpy(long_slot0).to(device)
+
+
+class CsrGraph:
+    """A sparse operator A [n_rows, n_cols] resident on one GPU, ready for `functional.spmm`."""
+
+    def __init__(self, rowptr, col, val, n_rows, n_cols, device, symmetric=False,
+                 nnz_per_part=DEFAULT_NNZ_PER_PART, validate=True, transpose=None):
+        rowptr_host = _np_i64(rowptr)
+        if rowptr_host.size != n_rows + 1:
+            raise ValueError("rowptr must have n_rows + 1 entries")
+        self.n_rows, self.n_cols = int(n_rows), int(n_cols)
+        self.nnz = int(rowptr_host[-1])
+        self.device = torch.device(device)
+        self.symmetric = bool(symmetric)
+        self.rowptr_host = rowptr_host
+        self.rowptr = torch.from_numpy(rowptr_host).to(self.device)
+        self.col = torch.as_tensor(col).to(device=self.device, dtype=torch.int32).contiguous()
+        self.val = None if val is None else torch.as_tensor(val).to(device=self.device, dtype=torch.float32).contiguous()
+        if self.col.numel() != self.nnz or (self.val is not None and self.val.numel() != self.nnz):
+            raise ValueError("col / val length must equal rowptr[-1]")
+        self.plan = SpmmPlan(rowptr_host, self.device, nnz_per_part)
+        self._t = self if symmetric else transpose
+        self._workspaces = {}
+        if validate and self.device.type == "cuda":
+            self.validate()
+
+    # -- checks ---------------------------------------------------------------------------
+    def validate(self):
+        """Device-side structural check before any kernel trusts the indices."""
+        errs = torch.zeros(1, dtype=torch.int64, device=self.device)
+        _lib.check(_lib.lib().gcr_csr_validate(_lib.dptr(self.rowptr), _lib.dptr(self.col), self.n_rows, self.n_cols,
+                                               self.nnz, _lib.dptr(errs), _lib.cur_stream(self.device)), "gcr_csr_validate")
+        n = int(errs.item())
+        if n:
+            raise ValueError(f"CSR graph is malformed: {n} structural errors (rowptr order / column range)")
+
+    # -- helpers --------------------------------------------------------------------------
+    def workspace(self, d: int):
+        """fp32 [n_slots, d] partial-sum buffer for split rows, one per (d, stream)."""
+        if self.plan.n_slots == 0:
+            return None
+        key = (d, torch.cuda.current_stream(self.device).cuda_stream)
+        ws = self._workspaces.get(key)
+        if ws is None:
+            ws = torch.empty(self.plan.n_slots, d, dtype=torch.float32, device=self.device)
+            self._workspaces[key] = ws
+        return ws
+
+    @property
+    def t(self) -> "CsrGraph":
+        """Transposed operator (for the backward pass dX = A^T dY); `self` when symmetric."""
+        if self._t is None:
+            col_host = self.col.cpu().numpy().astype(np.int64)
+            rows = np.repeat(np.arange(self.n_rows, dtype=np.int64), np.diff(self.rowptr_host))
+            val_host = None if self.val is None else self.val.cpu().numpy()
+            rp, c, v, _ = _coo_to_csr_host(col_host, rows, val_host, self.n_cols)
+            self._t = CsrGraph(rp, c, v, self.n_cols, self.n_rows, self.device, symmetric=False,
+                               nnz_per_part=self.plan.nnz_per_part, validate=False, transpose=self)
+        return self._t
+
+    # -- constructors ---------------------------------------------------------------------
+    @classmethod
+    def from_coo(cls, row, col, val, n_rows, n_cols, device, coalesce=False, symmetric=False, **kw):
+        """Stable sort by row (COO order kept inside a row, duplicates kept — torch.sparse.mm on the
+        uncoalesced COO of ncl.py:203-209 sums them), or (row, col)-sorted with duplicates summed
+        when `coalesce` (scipy `tmp + tmp.T`, selfcf.py:297; `.coalesce()`, sept.py:50)."""
+        row, col = _np_i64(row), _np_i64(col)
+        if val is not None and isinstance(val, torch.Tensor):
+            val = val.detach().cpu().numpy()
+        if coalesce:
+            rp, c, v = _coalesce_host(row, col, val, n_rows, n_cols)
+        else:
+            rp, c, v, _ = _coo_to_csr_host(row, col, val, n_rows)
+        return cls(rp, c, v, n_rows, n_cols, device, symmetric=symmetric, **kw)
+
+    @classmethod
+    def bipartite_raw(cls, uid, iid, num_users, num_items, device, **kw):
+        """ncl.py:74-85: rows/cols [(u, i+U), (i+U, u)] per interaction, value 1, duplicates kept (Q1)."""
+        uid, iid = _np_i64(uid), _np_i64(iid) + num_users
+        n = num_users + num_items
+        row = np.empty(2 * uid.size, dtype=np.int64)
+        col = np.empty_like(row)
+        row[0::2], row[1::2] = uid, iid
+        col[0::2], col[1::2] = iid, uid
+        return cls.from_coo(row, col, None, n, n, device, symmetric=True, **kw)
+
+    @classmethod
+    def bipartite_sym_norm(cls, uid, iid, num_users, num_items, device, **kw):
+        """selfcf.py:291-306 + 240-255 (ssl4rec.py:79-88): A = R~ + R~^T with duplicate interactions
+        summed, then D^-1/2 A D^-1/2 with 1/sqrt(0) -> 0, float32."""
+        uid, iid = _np_i64(uid), _np_i64(iid) + num_users
+        n = num_users + num_items
+        rp, c, v = _coalesce_host(np.concatenate([uid, iid]), np.concatenate([iid, uid]), None, n, n)
+        rows = np.repeat(np.arange(n), np.diff(rp))
+        rowsum = np.zeros(n, dtype=np.float32)
+        np.add.at(rowsum, rows, v)
+        with np.errstate(divide="ignore"):
+            dinv = np.power(rowsum, np.float32(-0.5), dtype=np.float32)
+        dinv[np.isinf(dinv)] = 0.0
+        return cls(rp, c, (dinv[rows] * v * dinv[c]).astype(np.float32), n, n, device, symmetric=True, **kw)
+
+    @classmethod
+    def from_edge_index_gcn_norm(cls, edge_index, num_nodes, device, symmetric=False, **kw):
+        """lightgcn.py:25 `LGConv()(x, edge_index)`: deg[v] = #edges with target v; w_e =
+        deg^-1/2[src] deg^-1/2[dst] (inf -> 0); out[dst] += w_e x[src]  => CSR over rows = dst."""
+        ei = _np_i64(edge_index)
+        src, dst = ei[0], ei[1]
+        deg = np.bincount(dst, minlength=num_nodes).astype(np.float32)
+        with np.errstate(divide="ignore"):
+            dis = np.power(deg, np.float32(-0.5), dtype=np.float32)
+        dis[np.isinf(dis)] = 0.0
+        return cls.from_coo(dst, src, (dis[src] * dis[dst]).astype(np.float32), num_nodes, num_nodes, device,
+                            symmetric=symmetric, **kw)
+
+
+def _coo_to_csr_host(row, col, val, n_rows):
+    order = np.argsort(row, kind="stable")
+    rowptr = np.zeros(n_rows + 1, dtype=np.int64)
+    np.cumsum(np.bincount(row, minlength=n_rows), out=rowptr[1:])
+    v = None if val is None else np.asarray(val, dtype=np.float32)[order]
+    return rowptr, col[order].astype(np.int32), v, order
+
+
+def _coalesce_host(row, col, val, n_rows, n_cols):
+    key = row * np.int64(n_cols) + col
+    order = np.argsort(key, kind="stable")
+    key_s = key[order]
+    first = np.ones(key_s.size, dtype=bool)
+    first[1:] = key_s[1:] != key_s[:-1]
+    seg = np.cumsum(first) - 1
+    v_in = np.ones(row.size, dtype=np.float32) if val is None else np.asarray(val, dtype=np.float32)
+    v = np.zeros(int(first.sum()), dtype=np.float32)
+    np.add.at(v, seg, v_in[order])
+    r, c = row[order][first], col[order][first]
+    rowptr = np.zeros(n_rows + 1, dtype=np.int64)
+    np.cumsum(np.bincount(r, minlength=n_rows), out=rowptr[1:])
+    return rowptr, c.astype(np.int32), v

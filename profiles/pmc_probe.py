@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Workload for the rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE in separate runs, as
+MI355X_MICROARCH.md §HBM prescribes).  Dispatch order of spmm_parts:
+  1..3   calibration: diagonal graph, N = 4M rows, d = 64 -> every byte is known
+         (read x once = N*256 B + col/val/rowptr/desc, write y once = N*256 B)
+  4..9   cfg2 LightGCN layers (2 forward passes x 3 layers)   [--workload cfg4 for the big graph]
+Run e.g.:
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/prof/pmc_fetch -- python3 profiles/pmc_probe.py
+"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+import recommendation_amd as ra  # noqa: E402
+from recommendation_amd import functional as Fn  # noqa: E402
+
+dev = torch.device("cuda", 0)
+name = sys.argv[sys.argv.index("--workload") + 1] if "--workload" in sys.argv else "cfg2"
+
+n_cal = 4_000_000
+rowptr = torch.arange(n_cal + 1, dtype=torch.int64)
+col = torch.arange(n_cal, dtype=torch.int32)
+val = torch.ones(n_cal)
+gcal = ra.CsrGraph(rowptr, col, val, n_cal, n_cal, dev, symmetric=True)
+xc = torch.randn(n_cal, 64, device=dev)
+yc = torch.empty_like(xc)
+for _ in range(3):
+    Fn.spmm_into(gcal, xc, y=yc)
+torch.cuda.synchronize()
+del xc, yc, gcal
+
+wl = bench.WORKLOADS[name]
+users, items = bench.synth_interactions_device(wl["users"], wl["items"], wl["edges"], bench.SEED, dev)
+rp, c, v = bench.sym_norm_csr_device(users, items, wl["users"], wl["items"])
+n = wl["users"] + wl["items"]
+graph = ra.CsrGraph(rp, c, v, n, n, dev, symmetric=True)
+x0 = torch.empty(n, 64, device=dev)
+torch.nn.init.xavier_uniform_(x0, generator=torch.Generator(device=dev).manual_seed(0))
+with torch.no_grad():
+    for _ in range(2):
+        Fn.lightgcn_propagate(graph, x0, wl["layers"], combine="sum")
+torch.cuda.synchronize()
+print("probe done", name, "nnz", graph.nnz, "n", n, "cal_rows", n_cal)

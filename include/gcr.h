@@ -76,6 +76,66 @@ int32_t gcr_spmm_csr_f32(const int64_t* desc, int64_t n_parts,
 int32_t gcr_csr_validate(const int64_t* rowptr, const int32_t* col, int64_t n_rows, int64_t n_cols,
                          int64_t nnz, int64_t* n_errors_dev, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * BPR pairwise loss over gathered rows, fused with the squared norms the regularisers need.
+ * --------------------------------------------------------------------------------------------- */
+#define GCR_BPR_NCL 0         /* -log(1e-5 + sigmoid(x))  ncl.py:116-120 (literal 10e-6), mhcn.py:35-39 */
+#define GCR_BPR_LOGSIGMOID 1  /* -logsigmoid(x)           gcl.py:221, sept.py:34-38 */
+#define GCR_BPR_LOG_SIGMOID 2 /* -log(sigmoid(x))         lightgcn.py:108 */
+
+/* floats of workspace gcr_bpr_fwd_f32 needs for `batch` samples */
+int64_t gcr_bpr_workspace_floats(int64_t batch);
+
+/*
+ * x_b = <U[u_b], I[i_b]> - mean_k <U[u_b], I[j_{b,k}]>          (n_neg negatives per sample)
+ * replaces  rec_user_emb[user_idx] / rec_item_emb[pos_idx] / [neg_idx] + bpr_loss  ncl.py:314-317,
+ *           lightgcn.py:95-108, gcl.py:216-221, sept.py:236-240, mhcn.py:527-530.
+ * Outputs: dloss_dx[b] = d loss_b / d x_b (saved for backward); sums[5] =
+ *   { sum_b loss_b, sum_b |U[u_b]|^2, sum_b |I[i_b]|^2, sum_{b,k} |I[j_bk]|^2, #samples skipped
+ *     because an id was out of range } — the caller forms mean / regulariser variants
+ *   (lightgcn.py:118, gcl.py:222, ncl.py:122-123, sept.py:241) from these.
+ * Deterministic (fixed-order block reduction).  j_idx is [batch * n_neg] row-major.
+ */
+int32_t gcr_bpr_fwd_f32(const float* user_tab, const float* item_tab, int32_t d,
+                        const int64_t* u_idx, const int64_t* i_idx, const int64_t* j_idx,
+                        int64_t batch, int32_t n_neg, int32_t variant, int64_t n_users, int64_t n_items,
+                        float* dloss_dx, float* sums, float* workspace, void* stream);
+
+/*
+ * Backward: grad_sums (device, 4 floats) is dL/d sums[0..3] of the forward; the row gradients are
+ * accumulated (float atomics, duplicate ids add up) into the dense tables grad_user [n_users, d] /
+ * grad_item [n_items, d], which the caller zeroes or already holds other gradient terms in.
+ */
+int32_t gcr_bpr_bwd_f32(const float* user_tab, const float* item_tab, int32_t d,
+                        const int64_t* u_idx, const int64_t* i_idx, const int64_t* j_idx,
+                        int64_t batch, int32_t n_neg, int64_t n_users, int64_t n_items,
+                        const float* dloss_dx, const float* grad_sums,
+                        float* grad_user, float* grad_item, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Counter-based RNG (Philox-4x32-10): negative sampler and edge-dropout bitmaps.
+ * --------------------------------------------------------------------------------------------- */
+/*
+ * out[b * n_negs + k] = first of the draws  mulhi(philox(ctr = (slot, trial/4, 'NEGS'), key = seed)
+ * [trial % 4], num_items),  slot = offset + b * n_negs + k,  that is not in the user's sorted
+ * training row user_items_sorted[user_rowptr[u] .. user_rowptr[u+1]);  max_trials == 0 disables
+ * rejection (lightgcn.py:91-94); no acceptable draw within max_trials -> -1 (ncl.py:110-112).
+ * replaces  next_batch_pairwise  ncl.py:91-114, gcl.py:111-125, ssl4rec.py:33-50, sept.py:12-30.
+ */
+int32_t gcr_neg_sample(const int64_t* user_rowptr, const int32_t* user_items_sorted, const int64_t* u_idx,
+                       int64_t batch, int32_t n_negs, int64_t n_users, int64_t num_items,
+                       uint64_t seed, uint64_t offset, int32_t max_trials, int64_t* out, void* stream);
+
+/*
+ * Bernoulli keep bitmap over nnz edges: bit e = (u_e >= pe), u_e the 24-bit uniform of word id%4 of
+ * philox(ctr = (id/4, 0, 'EDGE'), key = seed), id = edge_id[e] (or e when edge_id == NULL).
+ * Passing the canonical id of every non-zero lets A and A^T carry the same mask without a gather.
+ * replaces  EdgeRemoving.__call__  gcl.py:22-25 (`rand >= pe`), buir.py:300-309 (mask part).
+ * bits: uint32[(nnz + 31) / 32], unused high bits cleared.
+ */
+int32_t gcr_edge_mask_bits(int64_t nnz, float pe, uint64_t seed, const int64_t* edge_id, uint32_t* bits,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

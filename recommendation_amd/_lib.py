@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int32, c_int64, c_uint32, c_void_p
+from ctypes import c_char_p, c_float, c_int32, c_int64, c_uint32, c_uint64, c_void_p
 
 import torch
 
@@ -25,6 +25,13 @@ SIGNATURES = {
     "gcr_spmm_csr_f32": (c_int32, [_P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, c_float, _P, c_int32,
                                    _P, _P, _P, c_float, c_uint32, _P, _P, c_int64, c_int64, _P]),
     "gcr_csr_validate": (c_int32, [_P, _P, c_int64, c_int64, c_int64, _P, _P]),
+    "gcr_bpr_workspace_floats": (c_int64, [c_int64]),
+    "gcr_bpr_fwd_f32": (c_int32, [_P, _P, c_int32, _P, _P, _P, c_int64, c_int32, c_int32, c_int64, c_int64,
+                                  _P, _P, _P, _P]),
+    "gcr_bpr_bwd_f32": (c_int32, [_P, _P, c_int32, _P, _P, _P, c_int64, c_int32, c_int64, c_int64,
+                                  _P, _P, _P, _P, _P]),
+    "gcr_neg_sample": (c_int32, [_P, _P, _P, c_int64, c_int32, c_int64, c_int64, c_uint64, c_uint64, c_int32, _P, _P]),
+    "gcr_edge_mask_bits": (c_int32, [c_int64, c_float, c_uint64, _P, _P, _P]),
 }
 
 _lib = None

@@ -1,0 +1,243 @@
+// Fused BPR pairwise loss over gathered embedding rows (gfx950).
+//
+// Replaces the gather x3 + dot x2 + log-sigmoid + mean chain of ncl.py:314-317,116-120,
+// lightgcn.py:95-108 (n_neg negatives averaged), gcl.py:216-221, sept.py:34-38, mhcn.py:35-39,
+// and accumulates the squared norms every regulariser variant needs (lightgcn.py:118,
+// gcl.py:222, ncl.py:122-123, sept.py:241) in the same pass.
+//
+// Forward: a 16-lane group per sample (4 samples per wavefront), float4 per lane when d % 4 == 0
+// (d = 64: exactly one 16-B load per lane and row); dots reduced with 4 in-row DPP/LDS-crossbar
+// steps; per-block partial sums are written to a workspace and added in block order by a second
+// tiny kernel, so the scalar loss is bitwise reproducible.
+// Backward: one wavefront per sample, lane l owns columns l, l+64, ...: each row gradient is one
+// 256-B no-return global_atomic_add_f32 wave instruction (the shape that runs at the chip-wide
+// atomic rate, MI355X_MICROARCH.md §Global float atomics); duplicates in the index vectors
+// accumulate like torch's index_put(accumulate=True) backward.
+#include "gcr_common.h"
+
+namespace {
+
+constexpr int kFwdThreads = 256;
+constexpr int kGroups = kFwdThreads / 16;
+
+__device__ __forceinline__ float group16_sum(float v) {
+  v += __shfl_xor(v, 8, 16);
+  v += __shfl_xor(v, 4, 16);
+  v += __shfl_xor(v, 2, 16);
+  v += __shfl_xor(v, 1, 16);
+  return v;
+}
+
+// d(loss)/dx and loss for x = pos - neg
+__device__ __forceinline__ void bpr_point(int variant, float x, float& loss, float& dl) {
+  const float s = 1.0f / (1.0f + __expf(-x));
+  if (variant == GCR_BPR_NCL) {            // -log(1e-5 + sigmoid(x))   ncl.py:119 (literal 10e-6)
+    loss = -__logf(10e-6f + s);
+    dl = -(s * (1.0f - s)) / (10e-6f + s);
+  } else if (variant == GCR_BPR_LOGSIGMOID) {  // -logsigmoid(x)          gcl.py:221, sept.py:37
+    loss = (x > 0.f) ? log1pf(__expf(-x)) : (-x + log1pf(__expf(x)));
+    dl = -(1.0f - s);
+  } else {                                  // -log(sigmoid(x))          lightgcn.py:108
+    loss = -__logf(s);
+    dl = -(1.0f - s);
+  }
+}
+
+template <bool VEC4>
+__global__ __launch_bounds__(kFwdThreads) void bpr_fwd_kernel(const float* __restrict__ user_tab,
+                                                              const float* __restrict__ item_tab, int d,
+                                                              const int64_t* __restrict__ u_idx,
+                                                              const int64_t* __restrict__ i_idx,
+                                                              const int64_t* __restrict__ j_idx, int64_t batch,
+                                                              int n_neg, int variant, int64_t n_users, int64_t n_items,
+                                                              float* __restrict__ dloss_dx,
+                                                              float* __restrict__ block_partials) {
+  __shared__ float red[kGroups][5];
+  const int l16 = threadIdx.x & 15;
+  const int grp = threadIdx.x >> 4;
+  float t_loss = 0.f, t_su = 0.f, t_sp = 0.f, t_sn = 0.f, t_err = 0.f;
+  for (int64_t b = (int64_t)blockIdx.x * kGroups + grp; b < batch; b += (int64_t)gridDim.x * kGroups) {
+    const int64_t u = u_idx[b], i = i_idx[b];
+    bool ok = u >= 0 && u < n_users && i >= 0 && i < n_items;
+    for (int k = 0; k < n_neg; ++k) {
+      const int64_t j = j_idx[b * n_neg + k];
+      ok = ok && j >= 0 && j < n_items;
+    }
+    if (!ok) {  // never dereference a bad id; reported through sums[4]
+      t_err += 1.f;
+      if (l16 == 0) dloss_dx[b] = 0.f;
+      continue;
+    }
+    const float* ur = user_tab + u * d;
+    const float* pr = item_tab + i * d;
+    float pos = 0.f, neg = 0.f, su = 0.f, sp = 0.f, sn = 0.f;
+    if (VEC4) {
+      for (int c = l16 * 4; c < d; c += 64) {
+        const float4 uu = *reinterpret_cast<const float4*>(ur + c);
+        const float4 pp = *reinterpret_cast<const float4*>(pr + c);
+        pos += uu.x * pp.x + uu.y * pp.y + uu.z * pp.z + uu.w * pp.w;
+        su += uu.x * uu.x + uu.y * uu.y + uu.z * uu.z + uu.w * uu.w;
+        sp += pp.x * pp.x + pp.y * pp.y + pp.z * pp.z + pp.w * pp.w;
+        for (int k = 0; k < n_neg; ++k) {
+          const float4 nn = *reinterpret_cast<const float4*>(item_tab + j_idx[b * n_neg + k] * d + c);
+          neg += uu.x * nn.x + uu.y * nn.y + uu.z * nn.z + uu.w * nn.w;
+          sn += nn.x * nn.x + nn.y * nn.y + nn.z * nn.z + nn.w * nn.w;
+        }
+      }
+    } else {
+      for (int c = l16; c < d; c += 16) {
+        const float uu = ur[c], pp = pr[c];
+        pos += uu * pp;
+        su += uu * uu;
+        sp += pp * pp;
+        for (int k = 0; k < n_neg; ++k) {
+          const float nn = item_tab[j_idx[b * n_neg + k] * d + c];
+          neg += uu * nn;
+          sn += nn * nn;
+        }
+      }
+    }
+    pos = group16_sum(pos);
+    neg = group16_sum(neg);
+    su = group16_sum(su);
+    sp = group16_sum(sp);
+    sn = group16_sum(sn);
+    float loss, dl;
+    bpr_point(variant, pos - neg / (float)n_neg, loss, dl);
+    if (l16 == 0) dloss_dx[b] = dl;
+    t_loss += loss;
+    t_su += su;
+    t_sp += sp;
+    t_sn += sn;
+  }
+  if (l16 == 0) {
+    red[grp][0] = t_loss;
+    red[grp][1] = t_su;
+    red[grp][2] = t_sp;
+    red[grp][3] = t_sn;
+    red[grp][4] = t_err;
+  }
+  __syncthreads();
+  if (threadIdx.x < 5) {
+    float s = 0.f;
+    for (int g = 0; g < kGroups; ++g) s += red[g][threadIdx.x];  // fixed order
+    block_partials[(int64_t)blockIdx.x * 5 + threadIdx.x] = s;
+  }
+}
+
+// sums[0..4] = {sum loss, sum |u|^2, sum |p|^2, sum |n|^2, #samples skipped for bad ids}
+__global__ void bpr_reduce_kernel(const float* __restrict__ block_partials, int n_blocks, float* __restrict__ sums) {
+  const int k = threadIdx.x >> 6;  // 5 waves, one per scalar
+  const int lane = threadIdx.x & 63;
+  double s = 0.0;
+  for (int b = lane; b < n_blocks; b += 64) s += (double)block_partials[(int64_t)b * 5 + k];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (lane == 0) sums[k] = (float)s;
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void bpr_bwd_kernel(const float* __restrict__ user_tab,
+                                                      const float* __restrict__ item_tab, int d,
+                                                      const int64_t* __restrict__ u_idx,
+                                                      const int64_t* __restrict__ i_idx,
+                                                      const int64_t* __restrict__ j_idx, int64_t batch, int n_neg,
+                                                      int64_t n_users, int64_t n_items,
+                                                      const float* __restrict__ dloss_dx,
+                                                      const float* __restrict__ grad_sums,
+                                                      float* __restrict__ grad_user,
+                                                      float* __restrict__ grad_item) {
+  const int lane = threadIdx.x & 63;
+  // upstream gradient of the four forward sums; d(sum |x|^2)/dx = 2x
+  const float g_loss = grad_sums[0], c_u = 2.f * grad_sums[1], c_p = 2.f * grad_sums[2], c_n = 2.f * grad_sums[3];
+  const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  for (int64_t b = wave0; b < batch; b += (int64_t)gridDim.x * 4) {
+    const int64_t u = u_idx[b], i = i_idx[b];
+    bool ok = u >= 0 && u < n_users && i >= 0 && i < n_items;
+    for (int k = 0; k < n_neg; ++k) {
+      const int64_t j = j_idx[b * n_neg + k];
+      ok = ok && j >= 0 && j < n_items;
+    }
+    if (!ok) continue;
+    const float g = g_loss * dloss_dx[b];
+    const float gn = -g / (float)n_neg;
+    float uu[NV], du[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int c = lane + 64 * v;
+      uu[v] = c < d ? user_tab[u * d + c] : 0.f;
+      const float pp = c < d ? item_tab[i * d + c] : 0.f;
+      du[v] = g * pp + c_u * uu[v];
+      if (c < d) atomicAdd(grad_item + i * d + c, g * uu[v] + c_p * pp);
+    }
+    for (int k = 0; k < n_neg; ++k) {
+      const int64_t j = j_idx[b * n_neg + k];
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int c = lane + 64 * v;
+        if (c < d) {
+          const float nn = item_tab[j * d + c];
+          du[v] += gn * nn;
+          atomicAdd(grad_item + j * d + c, gn * uu[v] + c_n * nn);
+        }
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int c = lane + 64 * v;
+      if (c < d) atomicAdd(grad_user + u * d + c, du[v]);
+    }
+  }
+}
+
+int fwd_blocks(int64_t batch) {
+  const int64_t want = (batch + kGroups - 1) / kGroups;
+  return (int)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
+}
+
+}  // namespace
+
+extern "C" int64_t gcr_bpr_workspace_floats(int64_t batch) { return (int64_t)fwd_blocks(batch) * 5; }
+
+extern "C" int32_t gcr_bpr_fwd_f32(const float* user_tab, const float* item_tab, int32_t d, const int64_t* u_idx,
+                                   const int64_t* i_idx, const int64_t* j_idx, int64_t batch, int32_t n_neg,
+                                   int32_t variant, int64_t n_users, int64_t n_items, float* dloss_dx, float* sums,
+                                   float* workspace, void* stream) {
+  GCR_CHECK_ARG(batch >= 0 && n_neg >= 1 && d >= 1 && d <= 256 && n_users >= 0 && n_items >= 0);
+  GCR_CHECK_ARG(variant >= GCR_BPR_NCL && variant <= GCR_BPR_LOG_SIGMOID);
+  GCR_CHECK_ARG(sums != nullptr && workspace != nullptr);
+  GCR_CHECK_ARG(batch == 0 || (user_tab && item_tab && u_idx && i_idx && j_idx && dloss_dx));
+  hipStream_t s = (hipStream_t)stream;
+  const int blocks = fwd_blocks(batch);
+  if (d % 4 == 0)
+    hipLaunchKernelGGL((bpr_fwd_kernel<true>), dim3(blocks), dim3(kFwdThreads), 0, s, user_tab, item_tab, d, u_idx,
+                       i_idx, j_idx, batch, n_neg, variant, n_users, n_items, dloss_dx, workspace);
+  else
+    hipLaunchKernelGGL((bpr_fwd_kernel<false>), dim3(blocks), dim3(kFwdThreads), 0, s, user_tab, item_tab, d, u_idx,
+                       i_idx, j_idx, batch, n_neg, variant, n_users, n_items, dloss_dx, workspace);
+  int32_t st = GCR_LAUNCH_STATUS();
+  if (st != GCR_OK) return st;
+  hipLaunchKernelGGL(bpr_reduce_kernel, dim3(1), dim3(320), 0, s, workspace, blocks, sums);
+  return GCR_LAUNCH_STATUS();
+}
+
+extern "C" int32_t gcr_bpr_bwd_f32(const float* user_tab, const float* item_tab, int32_t d, const int64_t* u_idx,
+                                   const int64_t* i_idx, const int64_t* j_idx, int64_t batch, int32_t n_neg,
+                                   int64_t n_users, int64_t n_items, const float* dloss_dx, const float* grad_sums,
+                                   float* grad_user, float* grad_item, void* stream) {
+  GCR_CHECK_ARG(batch >= 0 && n_neg >= 1 && d >= 1 && d <= 256 && n_users >= 0 && n_items >= 0);
+  if (batch == 0) return GCR_OK;
+  GCR_CHECK_ARG(user_tab && item_tab && u_idx && i_idx && j_idx && dloss_dx && grad_sums && grad_user && grad_item);
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t want = (batch + 3) / 4;
+  const int blocks = (int)(want > 8192 ? 8192 : want);
+#define GCR_BWD(NV)                                                                                              \
+  hipLaunchKernelGGL((bpr_bwd_kernel<NV>), dim3(blocks), dim3(256), 0, s, user_tab, item_tab, d, u_idx, i_idx, \
+                     j_idx, batch, n_neg, n_users, n_items, dloss_dx, grad_sums, grad_user, grad_item)
+  if (d <= 64) GCR_BWD(1);
+  else if (d <= 128) GCR_BWD(2);
+  else if (d <= 192) GCR_BWD(3);
+  else GCR_BWD(4);
+#undef GCR_BWD
+  return GCR_LAUNCH_STATUS();
+}

@@ -178,3 +178,95 @@ def spmm_l2norm(graph: CsrGraph, x):
     """`F.normalize(torch.sparse.mm(adj, emb), dim=1)` (sept.py:223-224, mhcn.py:440-457) in one kernel."""
     _lib.require_cuda(x)
     return _NormProp.apply(x, graph)
+
+
+# ---------------------------------------------------------------------------------------------
+# BPR pairwise loss (P1/P2)
+# ---------------------------------------------------------------------------------------------
+BPR_NCL, BPR_LOGSIGMOID, BPR_LOG_SIGMOID = 0, 1, 2
+
+
+def _as_index(t, device):
+    t = torch.as_tensor(t, device=device)
+    if t.dtype != torch.int64:
+        t = t.to(torch.int64)
+    return t.contiguous()
+
+
+class _BprSums(torch.autograd.Function):
+    """sums = [sum_b loss_b, sum|U[u]|^2, sum|I[i]|^2, sum|I[j]|^2] through gcr_bpr_fwd/bwd_f32."""
+
+    @staticmethod
+    def forward(ctx, user_tab, item_tab, u_idx, i_idx, j_idx, variant):
+        L = _lib.lib()
+        user_tab, item_tab = user_tab.contiguous(), item_tab.contiguous()
+        batch = u_idx.numel()
+        n_neg = 1 if j_idx.dim() == 1 else j_idx.shape[1]
+        d = user_tab.shape[1]
+        dev = user_tab.device
+        dldx = torch.empty(max(batch, 1), dtype=torch.float32, device=dev)
+        sums = torch.zeros(5, dtype=torch.float32, device=dev)
+        ws = torch.empty(int(L.gcr_bpr_workspace_floats(batch)), dtype=torch.float32, device=dev)
+        _lib.check(L.gcr_bpr_fwd_f32(_lib.dptr(user_tab), _lib.dptr(item_tab), d, _lib.dptr(u_idx), _lib.dptr(i_idx),
+                                     _lib.dptr(j_idx), batch, n_neg, variant, user_tab.shape[0], item_tab.shape[0],
+                                     _lib.dptr(dldx), _lib.dptr(sums), _lib.dptr(ws), _lib.cur_stream(dev)),
+                   "gcr_bpr_fwd_f32")
+        ctx.save_for_backward(user_tab, item_tab, u_idx, i_idx, j_idx, dldx)
+        ctx.n_neg = n_neg
+        ctx.mark_non_differentiable(u_idx, i_idx, j_idx)
+        return sums
+
+    @staticmethod
+    def backward(ctx, g_sums):
+        user_tab, item_tab, u_idx, i_idx, j_idx, dldx = ctx.saved_tensors
+        gs = g_sums.contiguous().to(torch.float32)
+        gu = torch.zeros_like(user_tab)
+        gi = torch.zeros_like(item_tab)
+        _lib.check(_lib.lib().gcr_bpr_bwd_f32(
+            _lib.dptr(user_tab), _lib.dptr(item_tab), user_tab.shape[1], _lib.dptr(u_idx), _lib.dptr(i_idx),
+            _lib.dptr(j_idx), u_idx.numel(), ctx.n_neg, user_tab.shape[0], item_tab.shape[0], _lib.dptr(dldx),
+            _lib.dptr(gs), _lib.dptr(gu), _lib.dptr(gi), _lib.cur_stream(user_tab.device)), "gcr_bpr_bwd_f32")
+        return gu, gi, None, None, None, None
+
+
+def bpr_sums(user_tab, item_tab, u_idx, i_idx, j_idx, variant=BPR_NCL):
+    """Fused gather + BPR + squared norms.  Returns a differentiable float32[5]:
+    [sum_b loss_b, sum_b |U[u_b]|^2, sum_b |I[i_b]|^2, sum_bk |I[j_bk]|^2, #samples with a bad id].
+    j_idx may be [B] or [B, n_neg] (lightgcn.py:93: negatives' scores are averaged)."""
+    _lib.require_cuda(user_tab, item_tab)
+    if user_tab.dtype != torch.float32 or item_tab.dtype != torch.float32 or user_tab.shape[1] != item_tab.shape[1]:
+        raise ValueError("user_tab / item_tab must be float32 [*, d] with the same d")
+    dev = user_tab.device
+    u_idx, i_idx, j_idx = _as_index(u_idx, dev), _as_index(i_idx, dev), _as_index(j_idx, dev)
+    if u_idx.dim() != 1 or i_idx.shape != u_idx.shape or j_idx.shape[0] != u_idx.shape[0] or j_idx.dim() > 2:
+        raise ValueError("u_idx, i_idx: [B]; j_idx: [B] or [B, n_neg]")
+    return _BprSums.apply(user_tab, item_tab, u_idx, i_idx, j_idx, int(variant))
+
+
+# ---------------------------------------------------------------------------------------------
+# negative sampler (N1) and edge-dropout bitmaps (A1)
+# ---------------------------------------------------------------------------------------------
+def neg_sample(user_rowptr, user_items_sorted, u_idx, n_negs, num_items, seed, offset=0, max_trials=101):
+    """Uniform negatives with rejection against the user's sorted training row (device Philox).
+    max_trials=0: no rejection (lightgcn.py:92); slots that exhaust max_trials come back as -1
+    (ncl.py:110-112).  Returns int64 [B * n_negs]."""
+    _lib.require_cuda(user_rowptr, u_idx)
+    dev = u_idx.device
+    u_idx = _as_index(u_idx, dev)
+    out = torch.empty(u_idx.numel() * n_negs, dtype=torch.int64, device=dev)
+    _lib.check(_lib.lib().gcr_neg_sample(_lib.dptr(user_rowptr), _lib.dptr(user_items_sorted), _lib.dptr(u_idx),
+                                         u_idx.numel(), int(n_negs), user_rowptr.numel() - 1, int(num_items),
+                                         int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), int(max_trials),
+                                         _lib.dptr(out), _lib.cur_stream(dev)), "gcr_neg_sample")
+    return out
+
+
+def edge_mask_bits(nnz, pe, seed, device, edge_id=None):
+    """Bernoulli keep bitmap (`rand >= pe`, gcl.py:22-25) as int32 words, bit e <-> non-zero e.
+    edge_id (int64 [nnz]) gives every non-zero a canonical id so that A and A^T share one mask."""
+    bits = torch.zeros((nnz + 31) // 32, dtype=torch.int32, device=device)
+    if edge_id is not None:
+        edge_id = _as_index(edge_id, device)
+    _lib.check(_lib.lib().gcr_edge_mask_bits(int(nnz), float(pe), int(seed) & (2 ** 64 - 1), _lib.dptr(edge_id),
+                                             _lib.dptr(bits), _lib.cur_stream(device)), "gcr_edge_mask_bits")
+    return bits

@@ -136,6 +136,70 @@ int32_t gcr_neg_sample(const int64_t* user_rowptr, const int32_t* user_items_sor
 int32_t gcr_edge_mask_bits(int64_t nnz, float pe, uint64_t seed, const int64_t* edge_id, uint32_t* bits,
                            void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * InfoNCE / prototype contrast: all-pairs logits on the fp32 MFMA, fused 1/tau scale + row
+ * logsumexp; the M x N score matrix is never materialised.  d must be 32, 64, 128 or 256
+ * (GCR_EUNSUPPORTED otherwise; the host wrapper zero-pads other widths).
+ * --------------------------------------------------------------------------------------------- */
+/* out[r] = 1 / max(||x_r||_2, eps): the denominator of F.normalize (ncl.py:127, gcl.py:29-30). */
+int32_t gcr_row_inv_norm_f32(const float* x, int64_t n, int32_t d, float eps, float* out, void* stream);
+
+/* bytes of workspace gcr_infonce_fwd_f32 needs */
+int64_t gcr_infonce_fwd_workspace_bytes(int64_t m, int64_t n, int32_t d);
+
+/*
+ * lse[i] = log sum_j exp( inv_tau * a_scale[i] * b_scale[j] * <a_i, b_j> ),  i < m, j < n.
+ * a_scale / b_scale are optional per-row multipliers (the inverse norms when b_cos / normalize).
+ * replaces  F.log_softmax(view1 @ view2.T / t, dim=1)           ncl.py:128-129, ssl4rec.py:22-23
+ *           F.cross_entropy(sim, labels) / (sim.T, labels)       gcl.py:31-34
+ *           torch.exp(torch.matmul(norm_cu, F.normalize(iu).T) / t).sum(1)   ncl.py:363-366
+ *           torch.exp(user_emb @ item_emb.T / t).sum(dim=1)      ssl4rec.py:29
+ */
+int32_t gcr_infonce_fwd_f32(const float* a, const float* a_scale, int64_t m,
+                            const float* b, const float* b_scale, int64_t n, int32_t d,
+                            float inv_tau, float* lse, void* workspace, void* stream);
+
+/*
+ * out[i] = scale * a_scale[i] * b_scale[p] * <a_i, b_p>, p = pos[i] (pos == NULL: p = i) — the
+ * positive logit (the diagonal of ncl.py:129 / gcl.py:32-34, `(norm_cu * norm_iu).sum(1) / t`
+ * ncl.py:363).  An out-of-range pos yields NaN for that row.  Any d.
+ */
+int32_t gcr_pos_logit_f32(const float* a, const float* a_scale, const float* b, const float* b_scale,
+                          const int64_t* pos, int64_t m, int64_t n, int32_t d, float scale, float* out,
+                          void* stream);
+
+/* bytes of workspace gcr_infonce_bwd_f32 needs (0 when no column split is used) */
+int64_t gcr_infonce_bwd_workspace_bytes(int64_t mx, int64_t ny, int32_t d);
+
+/*
+ * Flash-style backward of the softmax part (autograd of the expressions listed at
+ * gcr_infonce_fwd_f32).  With s_ij = inv_tau * <xhat_i, yhat_j>, xhat = x * x_scale, yhat = y * y_scale:
+ *   P_ij   = w_x[i] * exp(s_ij - lse_x[i]) + w_y[j] * exp(s_ij - lse_y[j])
+ *   g[i,:] = inv_tau * sum_j P_ij * yhat_j          (gradient w.r.t. xhat_i; the positive-logit
+ *                                                    term is gcr_infonce_pos_bwd_f32)
+ * (w_x, lse_x) is the row-softmax side (upstream dL/dlse of the rows of x, their forward lse);
+ * (w_y, lse_y) the column side (dL/dlse of the rows of y).  Either pair may be NULL.  Call twice
+ * with x and y swapped for both input gradients.  Scores are recomputed, never stored.
+ */
+int32_t gcr_infonce_bwd_f32(const float* x, const float* x_scale, int64_t mx,
+                            const float* y, const float* y_scale, int64_t ny, int32_t d, float inv_tau,
+                            const float* lse_x, const float* w_x, const float* lse_y, const float* w_y,
+                            float* g, void* workspace, void* stream);
+
+/*
+ * Positive-logit term: gx[i,:] += coef[i] * inv_tau * yhat[p_i,:]  (plain add, row i is exclusive)
+ *                      gy[p_i,:] += coef[i] * inv_tau * xhat[i,:]  (float atomics, p_i may repeat)
+ * p_i = pos[i] (pos == NULL: p_i = i); gx or gy may be NULL.  Any d.
+ */
+int32_t gcr_infonce_pos_bwd_f32(const float* x, const float* x_scale, const float* y, const float* y_scale,
+                                const int64_t* pos, const float* coef, int64_t mx, int64_t ny, int32_t d,
+                                float inv_tau, float* gx, float* gy, void* stream);
+
+/* Backward through F.normalize: out = inv_norm * (ghat - xhat <xhat, ghat>), xhat = x * inv_norm;
+ * out may alias ghat.  Any d. */
+int32_t gcr_normalize_bwd_f32(const float* x, const float* inv_norm, const float* ghat, int64_t n, int32_t d,
+                              float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,636 @@
+// InfoNCE / prototype-contrast logits with fused temperature scale and row logsumexp on the
+// fp32 MFMA of gfx950 (v_mfma_f32_32x32x2_f32: exact f32, 64 FLOP/clk/SIMD, ~155 TF dense).
+//
+// Replaces the materialised score matrices of
+//   InfoNCE            ncl.py:125-130, ssl4rec.py:19-23   (view1 @ view2.T / t -> log_softmax diag)
+//   info_nce_loss      gcl.py:28-35                       (sim, sim.T cross-entropies)
+//   ssl_layer_loss     ncl.py:358-367                     (B anchors x ALL layer-0 rows, exp-sum)
+//   ProtoNCE_loss      ncl.py:369-375, batch_softmax_loss ssl4rec.py:25-30
+// The M x N logits never leave the register file.
+//
+// Mapping.  The score tile is computed TRANSPOSED: MFMA "A" = 32 streamed table rows j, MFMA "B" =
+// 32 stationary anchors i, so in the 32x32 accumulator a lane owns ONE anchor (column i = lane&31)
+// and its 16 registers are 16 different table rows: the online max / exp2-sum over j is in-lane
+// work, no cross-lane traffic until one final lane<->lane+32 merge.  The K (= d) dimension is
+// split between the two lane halves (half h covers features [h*d/2, (h+1)*d/2)), so each lane's
+// operand slice is contiguous in memory: 16-byte global loads for the stationary anchors, and
+// conflict-free ds_read_b128 (row stride padded by 16 B) for the streamed tile.
+// A wave keeps NT x 32 anchors (pre-multiplied by 1/||a|| * 1/tau * log2(e)) in registers and walks
+// a column range of the table; table tiles of 32 rows are staged global -> registers -> LDS
+// (normalised on the way) one tile ahead of the MFMAs (double buffer, one barrier per tile).
+// Grid = anchor blocks x column splits; split partials (max, sum) are merged by a second kernel.
+#include "gcr_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kTileJ = 32;
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+constexpr float kNegBig = -1.0e30f;
+
+template <int D>
+struct Shape {
+  static constexpr int KH = D / 2;                       // k-steps per 32x32 tile (2 k per MFMA)
+  static constexpr int STRIDE = D + 4;                   // floats; +16 B pad -> conflict-free b128
+  static constexpr int NT = D <= 128 ? 2 : 1;            // anchor tiles of 32 per wave
+  static constexpr int NLD = (kTileJ * D / 4) / 256;     // float4 staged per thread and tile
+  static constexpr int ANCHORS_PER_BLOCK = 4 * 32 * NT;
+};
+
+// C/D layout of the 32x32 accumulator: register r of lane (col = lane&31, h = lane>>5) is row
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+template <int D>
+__device__ __forceinline__ void stage_load(const float* __restrict__ b, const float* __restrict__ b_scale,
+                                           int64_t n_rows, int64_t j0, int tid, float4 (&regs)[Shape<D>::NLD]) {
+#pragma unroll
+  for (int u = 0; u < Shape<D>::NLD; ++u) {
+    const int idx = tid + 256 * u;
+    const int row = idx / (D / 4), c4 = idx % (D / 4);
+    const int64_t j = j0 + row;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j < n_rows) {
+      v = *reinterpret_cast<const float4*>(b + j * D + 4 * c4);
+      if (b_scale != nullptr) {
+        const float s = b_scale[j];
+        v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+      }
+    }
+    regs[u] = v;
+  }
+}
+
+template <int D>
+__device__ __forceinline__ void stage_store(float* __restrict__ tile, int tid, const float4 (&regs)[Shape<D>::NLD]) {
+#pragma unroll
+  for (int u = 0; u < Shape<D>::NLD; ++u) {
+    const int idx = tid + 256 * u;
+    const int row = idx / (D / 4), c4 = idx % (D / 4);
+    *reinterpret_cast<float4*>(tile + row * Shape<D>::STRIDE + 4 * c4) = regs[u];
+  }
+}
+
+// stationary operand: lane (i = lane&31, h) holds features [h*KH, (h+1)*KH) of its row, pre-scaled
+template <int D>
+__device__ __forceinline__ void load_stationary(const float* __restrict__ a, const float* __restrict__ a_scale,
+                                                int64_t m_rows, int64_t row, int h, float mult,
+                                                float (&frag)[Shape<D>::KH]) {
+  const bool valid = row < m_rows;
+  const float s = valid ? (a_scale != nullptr ? a_scale[row] : 1.0f) * mult : 0.f;
+  const float* p = a + (valid ? row : 0) * D + h * Shape<D>::KH;
+#pragma unroll
+  for (int q = 0; q < Shape<D>::KH / 4; ++q) {
+    float4 v = valid ? *reinterpret_cast<const float4*>(p + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    frag[4 * q + 0] = v.x * s;
+    frag[4 * q + 1] = v.y * s;
+    frag[4 * q + 2] = v.z * s;
+    frag[4 * q + 3] = v.w * s;
+  }
+}
+
+// S^T tile: acc[t][r] = log2-domain logit of (table row acc_row(r,h), anchor tile t / lane&31)
+template <int D>
+__device__ __forceinline__ void score_tile(const float* __restrict__ tile, int i32, int h,
+                                           const float (&bfrag)[Shape<D>::NT][Shape<D>::KH],
+                                           f32x16 (&acc)[Shape<D>::NT]) {
+#pragma unroll
+  for (int t = 0; t < Shape<D>::NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const float* base = tile + i32 * Shape<D>::STRIDE + h * Shape<D>::KH;
+#pragma unroll
+  for (int q = 0; q < Shape<D>::KH / 4; ++q) {
+    const float4 av = *reinterpret_cast<const float4*>(base + 4 * q);
+    const float ae[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int t = 0; t < Shape<D>::NT; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae[e], bfrag[t][4 * q + e], acc[t], 0, 0, 0);
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void infonce_fwd_kernel(const float* __restrict__ a,
+                                                             const float* __restrict__ a_scale, int64_t m_rows,
+                                                             const float* __restrict__ b,
+                                                             const float* __restrict__ b_scale, int64_t n_rows,
+                                                             float scale2, int nsplit, int64_t tiles_per_split,
+                                                             float2* __restrict__ part) {
+  using S = Shape<D>;
+  __shared__ __align__(16) float lds[2][kTileJ * S::STRIDE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i32 = lane & 31, h = lane >> 5;
+  const int64_t mblk = blockIdx.x / nsplit;
+  const int split = blockIdx.x % nsplit;
+  const int64_t i0 = (mblk * 4 + wave) * (32 * S::NT);
+
+  float bfrag[S::NT][S::KH];
+#pragma unroll
+  for (int t = 0; t < S::NT; ++t) load_stationary<D>(a, a_scale, m_rows, i0 + 32 * t + i32, h, scale2, bfrag[t]);
+
+  float m_run[S::NT], l_run[S::NT];
+#pragma unroll
+  for (int t = 0; t < S::NT; ++t) {
+    m_run[t] = kNegBig;
+    l_run[t] = 0.f;
+  }
+
+  const int64_t total_tiles = (n_rows + kTileJ - 1) / kTileJ;
+  const int64_t tile0 = (int64_t)split * tiles_per_split;
+  const int64_t tile1 = min(total_tiles, tile0 + tiles_per_split);
+  float4 regs[S::NLD];
+  if (tile0 < tile1) {
+    stage_load<D>(b, b_scale, n_rows, tile0 * kTileJ, tid, regs);
+    stage_store<D>(lds[0], tid, regs);
+  }
+  __syncthreads();
+  for (int64_t tt = tile0; tt < tile1; ++tt) {
+    const int cur = (int)((tt - tile0) & 1);
+    const bool more = tt + 1 < tile1;
+    if (more) stage_load<D>(b, b_scale, n_rows, (tt + 1) * kTileJ, tid, regs);
+
+    f32x16 acc[S::NT];
+    score_tile<D>(lds[cur], i32, h, bfrag, acc);
+    const int64_t j0 = tt * kTileJ;
+    if (j0 + kTileJ > n_rows) {  // ragged last tile: rows past the table never contribute
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (j0 + acc_row(r, h) >= n_rows) {
+#pragma unroll
+          for (int t = 0; t < S::NT; ++t) acc[t][r] = -INFINITY;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < S::NT; ++t) {
+      float tmax = acc[t][0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, acc[t][r]);
+      const float m_new = fmaxf(m_run[t], tmax);
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sum += __builtin_amdgcn_exp2f(acc[t][r] - m_new);
+      l_run[t] = l_run[t] * __builtin_amdgcn_exp2f(m_run[t] - m_new) + sum;
+      m_run[t] = m_new;
+    }
+    if (more) stage_store<D>(lds[cur ^ 1], tid, regs);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int t = 0; t < S::NT; ++t) {
+    const float m_o = __shfl_xor(m_run[t], 32, 64), l_o = __shfl_xor(l_run[t], 32, 64);
+    const float m = fmaxf(m_run[t], m_o);
+    const float l = l_run[t] * __builtin_amdgcn_exp2f(m_run[t] - m) + l_o * __builtin_amdgcn_exp2f(m_o - m);
+    const int64_t row = i0 + 32 * t + i32;
+    if (h == 0 && row < m_rows) part[(int64_t)split * m_rows + row] = make_float2(m, l);
+  }
+}
+
+// natural-log LSE of the scaled logits from the per-split (max2, sum2) partials
+__global__ void infonce_merge_kernel(const float2* __restrict__ part, int nsplit, int64_t m_rows,
+                                     float* __restrict__ lse) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m_rows) return;
+  float m = kNegBig;
+  for (int s = 0; s < nsplit; ++s) m = fmaxf(m, part[(int64_t)s * m_rows + i].x);
+  float l = 0.f;
+  for (int s = 0; s < nsplit; ++s) {
+    const float2 p = part[(int64_t)s * m_rows + i];
+    l += p.y * __builtin_amdgcn_exp2f(p.x - m);
+  }
+  lse[i] = (m + __log2f(l)) * kLn2;
+}
+
+__device__ __forceinline__ float group16_sum(float v) {
+  v += __shfl_xor(v, 8, 16);
+  v += __shfl_xor(v, 4, 16);
+  v += __shfl_xor(v, 2, 16);
+  v += __shfl_xor(v, 1, 16);
+  return v;
+}
+
+// out[r] = 1 / max(||x_r||_2, eps)   (F.normalize's denominator, ncl.py:127, gcl.py:29-30)
+__global__ __launch_bounds__(256) void row_inv_norm_kernel(const float* __restrict__ x, int64_t n, int d, float eps,
+                                                           float* __restrict__ out) {
+  const int l16 = threadIdx.x & 15;
+  for (int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); r < n; r += (int64_t)gridDim.x * 16) {
+    float ss = 0.f;
+    if ((d & 3) == 0) {
+      for (int c = l16 * 4; c < d; c += 64) {
+        const float4 v = *reinterpret_cast<const float4*>(x + r * d + c);
+        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+      }
+    } else {
+      for (int c = l16; c < d; c += 16) ss += x[r * d + c] * x[r * d + c];
+    }
+    ss = group16_sum(ss);
+    if (l16 == 0) out[r] = 1.0f / fmaxf(sqrtf(ss), eps);
+  }
+}
+
+// out[i] = scale * a_scale[i] * b_scale[p] * <a_i, b_p>,  p = pos[i] (or i): the positive logit
+__global__ __launch_bounds__(256) void pos_logit_kernel(const float* __restrict__ a, const float* __restrict__ a_scale,
+                                                        const float* __restrict__ b, const float* __restrict__ b_scale,
+                                                        const int64_t* __restrict__ pos, int64_t m, int64_t n, int d,
+                                                        float scale, float* __restrict__ out) {
+  const int l16 = threadIdx.x & 15;
+  for (int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); i < m; i += (int64_t)gridDim.x * 16) {
+    const int64_t p = pos != nullptr ? pos[i] : i;
+    float dot = 0.f;
+    const bool ok = p >= 0 && p < n;
+    if (ok) {
+      if ((d & 3) == 0) {
+        for (int c = l16 * 4; c < d; c += 64) {
+          const float4 u = *reinterpret_cast<const float4*>(a + i * d + c);
+          const float4 v = *reinterpret_cast<const float4*>(b + p * d + c);
+          dot += u.x * v.x + u.y * v.y + u.z * v.z + u.w * v.w;
+        }
+      } else {
+        for (int c = l16; c < d; c += 16) dot += a[i * d + c] * b[p * d + c];
+      }
+    }
+    dot = group16_sum(dot);
+    if (l16 == 0) {
+      const float sa = a_scale != nullptr ? a_scale[i] : 1.0f;
+      const float sb = (ok && b_scale != nullptr) ? b_scale[p] : 1.0f;
+      out[i] = ok ? scale * sa * sb * dot : __builtin_nanf("");
+    }
+  }
+}
+
+
+struct FwdPlan {
+  int nsplit;
+  int64_t tiles_per_split;
+  int64_t m_blocks;
+};
+
+FwdPlan plan_fwd(int64_t m, int64_t n, int anchors_per_block) {
+  FwdPlan p;
+  p.m_blocks = (m + anchors_per_block - 1) / anchors_per_block;
+  const int64_t total_tiles = (n + kTileJ - 1) / kTileJ;
+  int64_t want = (512 + p.m_blocks - 1) / p.m_blocks;  // ~2 blocks per CU over 256 CUs
+  if (want > total_tiles) want = total_tiles;
+  if (want < 1) want = 1;
+  p.tiles_per_split = (total_tiles + want - 1) / want;
+  if (p.tiles_per_split < 1) p.tiles_per_split = 1;
+  p.nsplit = (int)((total_tiles + p.tiles_per_split - 1) / p.tiles_per_split);
+  if (p.nsplit < 1) p.nsplit = 1;
+  return p;
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward (flash-style recompute).  For stationary rows x_i and streamed rows y_j:
+//   P_ij = w_x[i] * exp(s_ij - lse_x[i]) + w_y[j] * exp(s_ij - lse_y[j]),  s = logits (1/tau scaled)
+//   G[i, :] = inv_tau * sum_j P_ij * yhat_j                  (gradient w.r.t. the scaled row xhat_i)
+// The score tile is recomputed exactly as in the forward; because its accumulator already has the
+// stationary row on the lane and the streamed rows in the registers, register r IS the MFMA
+// B-operand of k-step r of the second product G^T[c][i] += yhat[j_r][c] * P[j_r][i] (no LDS round
+// trip for P); the A operand yhat[j_r(h)][c] is a conflict-free ds_read_b32 from the same tile.
+// w_x/lse_x are the "lane side" statistics (row-softmax of the stationary rows), w_y/lse_y the
+// "register side" ones (softmax over the stationary index for every streamed row): calling the
+// kernel twice with the roles swapped yields both input gradients of the symmetric loss.
+// ------------------------------------------------------------------------------------------
+template <int D>
+struct BwdShape {
+  static constexpr int NT = D <= 64 ? 2 : 1;
+  static constexpr int CT = D / 32 > 4 ? 4 : D / 32;     // column tiles of 32 handled per launch
+  static constexpr int PASSES = (D / 32) / CT;
+  static constexpr int ROWS_PER_BLOCK = 4 * 32 * NT;
+};
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void infonce_bwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ x_scale, int64_t mx, const float* __restrict__ y,
+    const float* __restrict__ y_scale, int64_t ny, float scale2, float out_scale, const float* __restrict__ lse_x,
+    const float* __restrict__ w_x, const float* __restrict__ lse_y, const float* __restrict__ w_y, int ct0, int nsplit,
+    int64_t tiles_per_split, float* __restrict__ gpart) {
+  using S = Shape<D>;
+  using B = BwdShape<D>;
+  __shared__ __align__(16) float lds[2][kTileJ * S::STRIDE];
+  __shared__ __align__(16) float st_lse[2][kTileJ];
+  __shared__ __align__(16) float st_w[2][kTileJ];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i32 = lane & 31, h = lane >> 5;
+  const int64_t mblk = blockIdx.x / nsplit;
+  const int split = blockIdx.x % nsplit;
+  const int64_t i0 = (mblk * 4 + wave) * (32 * B::NT);
+
+  float bfrag[B::NT][S::KH];
+  float lse2l[B::NT], wl[B::NT];
+#pragma unroll
+  for (int t = 0; t < B::NT; ++t) {
+    const int64_t row = i0 + 32 * t + i32;
+    load_stationary<D>(x, x_scale, mx, row, h, scale2, bfrag[t]);
+    const bool on = row < mx && w_x != nullptr;
+    wl[t] = on ? w_x[row] : 0.f;
+    lse2l[t] = on ? lse_x[row] * kLog2e : 1.0e30f;  // disabled term: exp2(-huge) = 0, never 0 * inf
+  }
+  f32x16 gacc[B::NT][B::CT];
+#pragma unroll
+  for (int t = 0; t < B::NT; ++t)
+#pragma unroll
+    for (int c = 0; c < B::CT; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gacc[t][c][r] = 0.f;
+
+  const int64_t total_tiles = (ny + kTileJ - 1) / kTileJ;
+  const int64_t tile0 = (int64_t)split * tiles_per_split;
+  const int64_t tile1 = min(total_tiles, tile0 + tiles_per_split);
+  float4 regs[S::NLD];
+  float s_lse = 0.f, s_w = 0.f;
+  auto load_stats = [&](int64_t j0) {
+    if (tid < kTileJ) {
+      const int64_t j = j0 + tid;
+      const bool on = j < ny && w_y != nullptr;
+      s_w = on ? w_y[j] : 0.f;
+      s_lse = on ? lse_y[j] * kLog2e : 1.0e30f;
+    }
+  };
+  auto store_stats = [&](int buf) {
+    if (tid < kTileJ) {
+      st_lse[buf][tid] = s_lse;
+      st_w[buf][tid] = s_w;
+    }
+  };
+  if (tile0 < tile1) {
+    stage_load<D>(y, y_scale, ny, tile0 * kTileJ, tid, regs);
+    load_stats(tile0 * kTileJ);
+    stage_store<D>(lds[0], tid, regs);
+    store_stats(0);
+  }
+  __syncthreads();
+  for (int64_t tt = tile0; tt < tile1; ++tt) {
+    const int cur = (int)((tt - tile0) & 1);
+    const bool more = tt + 1 < tile1;
+    if (more) {
+      stage_load<D>(y, y_scale, ny, (tt + 1) * kTileJ, tid, regs);
+      load_stats((tt + 1) * kTileJ);
+    }
+    f32x16 acc[B::NT];
+    {
+#pragma unroll
+      for (int t = 0; t < B::NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+      const float* base = lds[cur] + i32 * S::STRIDE + h * S::KH;
+#pragma unroll
+      for (int q = 0; q < S::KH / 4; ++q) {
+        const float4 av = *reinterpret_cast<const float4*>(base + 4 * q);
+        const float ae[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int t = 0; t < B::NT; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae[e], bfrag[t][4 * q + e], acc[t], 0, 0, 0);
+      }
+    }
+    const int64_t j0 = tt * kTileJ;
+    const bool ragged = j0 + kTileJ > ny;
+    // P in place of the scores
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 lr = *reinterpret_cast<const float4*>(&st_lse[cur][8 * g + 4 * h]);
+      const float4 wr = *reinterpret_cast<const float4*>(&st_w[cur][8 * g + 4 * h]);
+      const float lre[4] = {lr.x, lr.y, lr.z, lr.w};
+      const float wre[4] = {wr.x, wr.y, wr.z, wr.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g + e;
+        const bool dead = ragged && (j0 + acc_row(r, h) >= ny);
+#pragma unroll
+        for (int t = 0; t < B::NT; ++t) {
+          const float sc = dead ? -INFINITY : acc[t][r];
+          acc[t][r] = wl[t] * __builtin_amdgcn_exp2f(sc - lse2l[t]) + wre[e] * __builtin_amdgcn_exp2f(sc - lre[e]);
+        }
+      }
+    }
+    // G^T[c][i] += yhat[j_r][c] * P[j_r][i]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float* yrow = lds[cur] + acc_row(r, h) * S::STRIDE + 32 * ct0 + i32;
+#pragma unroll
+      for (int c = 0; c < B::CT; ++c) {
+        const float yv = yrow[32 * c];
+#pragma unroll
+        for (int t = 0; t < B::NT; ++t)
+          gacc[t][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(yv, acc[t][r], gacc[t][c], 0, 0, 0);
+      }
+    }
+    if (more) {
+      stage_store<D>(lds[cur ^ 1], tid, regs);
+      store_stats(cur ^ 1);
+    }
+    __syncthreads();
+  }
+
+  // gacc[t][c] register rr of lane (i, h) is column 32*(ct0+c) + acc_row(rr, h) of row i
+  float* gout = gpart + (int64_t)split * mx * D;
+#pragma unroll
+  for (int t = 0; t < B::NT; ++t) {
+    const int64_t row = i0 + 32 * t + i32;
+    if (row < mx) {
+#pragma unroll
+      for (int c = 0; c < B::CT; ++c)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float4 v = make_float4(gacc[t][c][4 * g + 0] * out_scale, gacc[t][c][4 * g + 1] * out_scale,
+                                 gacc[t][c][4 * g + 2] * out_scale, gacc[t][c][4 * g + 3] * out_scale);
+          *reinterpret_cast<float4*>(gout + row * D + 32 * (ct0 + c) + 8 * g + 4 * h) = v;
+        }
+    }
+  }
+}
+
+// g[i, :] = sum over splits (fixed order) of the partial gradients
+__global__ __launch_bounds__(256) void bwd_reduce_kernel(const float* __restrict__ gpart, int nsplit, int64_t n4,
+                                                         float* __restrict__ g) {
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n4; k += (int64_t)gridDim.x * blockDim.x) {
+    float4 s = reinterpret_cast<const float4*>(gpart)[k];
+    for (int p = 1; p < nsplit; ++p) {
+      const float4 v = reinterpret_cast<const float4*>(gpart)[(int64_t)p * n4 + k];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    reinterpret_cast<float4*>(g)[k] = s;
+  }
+}
+
+// positive-logit term: gx[i] += c_i * inv_tau * yhat[p_i] (row-exclusive), gy[p_i] += c_i * inv_tau * xhat[i] (atomic)
+__global__ __launch_bounds__(256) void pos_bwd_kernel(const float* __restrict__ x, const float* __restrict__ x_scale,
+                                                      const float* __restrict__ y, const float* __restrict__ y_scale,
+                                                      const int64_t* __restrict__ pos, const float* __restrict__ coef,
+                                                      int64_t mx, int64_t ny, int d, float inv_tau, float* gx,
+                                                      float* gy) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < mx; i += (int64_t)gridDim.x * 4) {
+    const int64_t p = pos != nullptr ? pos[i] : i;
+    if (p < 0 || p >= ny) continue;
+    const float c = coef[i] * inv_tau;
+    const float sx = x_scale != nullptr ? x_scale[i] : 1.0f;
+    const float sy = y_scale != nullptr ? y_scale[p] : 1.0f;
+    for (int col = lane; col < d; col += 64) {
+      if (gx != nullptr) gx[i * d + col] += c * sy * y[p * d + col];
+      if (gy != nullptr) atomicAdd(gy + p * d + col, c * sx * x[i * d + col]);
+    }
+  }
+}
+
+// through F.normalize: out = inv * (ghat - xhat <xhat, ghat>), xhat = x * inv  (out may alias ghat)
+__global__ __launch_bounds__(256) void normalize_bwd_kernel(const float* __restrict__ x, const float* __restrict__ inv,
+                                                            const float* ghat, int64_t n, int d, float* out) {
+  const int l16 = threadIdx.x & 15;
+  for (int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); r < n; r += (int64_t)gridDim.x * 16) {
+    const float s = inv[r];
+    float dot = 0.f;
+    for (int c = l16; c < d; c += 16) dot += x[r * d + c] * s * ghat[r * d + c];
+    dot = group16_sum(dot);
+    for (int c = l16; c < d; c += 16) out[r * d + c] = s * (ghat[r * d + c] - x[r * d + c] * s * dot);
+  }
+}
+
+template <int D>
+FwdPlan plan_bwd(int64_t mx, int64_t ny) { return plan_fwd(mx, ny, BwdShape<D>::ROWS_PER_BLOCK); }
+
+template <int D>
+int32_t launch_bwd(const float* x, const float* x_scale, int64_t mx, const float* y, const float* y_scale, int64_t ny,
+                   float inv_tau, const float* lse_x, const float* w_x, const float* lse_y, const float* w_y, float* g,
+                   void* workspace, hipStream_t s) {
+  const FwdPlan p = plan_bwd<D>(mx, ny);
+  float* gpart = p.nsplit == 1 ? g : reinterpret_cast<float*>(workspace);
+  for (int pass = 0; pass < BwdShape<D>::PASSES; ++pass) {
+    hipLaunchKernelGGL((infonce_bwd_kernel<D>), dim3((unsigned)(p.m_blocks * p.nsplit)), dim3(256), 0, s, x, x_scale,
+                       mx, y, y_scale, ny, inv_tau * kLog2e, inv_tau, lse_x, w_x, lse_y, w_y, pass * BwdShape<D>::CT,
+                       p.nsplit, p.tiles_per_split, gpart);
+    int32_t st = GCR_LAUNCH_STATUS();
+    if (st != GCR_OK) return st;
+  }
+  if (p.nsplit > 1) {
+    const int64_t n4 = mx * D / 4;
+    const int64_t want = (n4 + 255) / 256;
+    hipLaunchKernelGGL(bwd_reduce_kernel, dim3((unsigned)(want > 4096 ? 4096 : want)), dim3(256), 0, s, gpart,
+                       p.nsplit, n4, g);
+    return GCR_LAUNCH_STATUS();
+  }
+  return GCR_OK;
+}
+
+int anchors_per_block_for(int d) { return d <= 128 ? 256 : 128; }
+
+template <int D>
+int32_t launch_fwd(const float* a, const float* a_scale, int64_t m, const float* b, const float* b_scale, int64_t n,
+                   float inv_tau, float* lse, void* workspace, hipStream_t s) {
+  const FwdPlan p = plan_fwd(m, n, Shape<D>::ANCHORS_PER_BLOCK);
+  float2* part = reinterpret_cast<float2*>(workspace);
+  hipLaunchKernelGGL((infonce_fwd_kernel<D>), dim3((unsigned)(p.m_blocks * p.nsplit)), dim3(256), 0, s, a, a_scale, m,
+                     b, b_scale, n, inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part);
+  int32_t st = GCR_LAUNCH_STATUS();
+  if (st != GCR_OK) return st;
+  hipLaunchKernelGGL(infonce_merge_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, part, p.nsplit, m, lse);
+  return GCR_LAUNCH_STATUS();
+}
+
+bool dim_supported(int d) { return d == 32 || d == 64 || d == 128 || d == 256; }
+
+}  // namespace
+
+extern "C" int64_t gcr_infonce_fwd_workspace_bytes(int64_t m, int64_t n, int32_t d) {
+  if (m <= 0 || n <= 0 || !dim_supported(d)) return 0;
+  const FwdPlan p = plan_fwd(m, n, anchors_per_block_for(d));
+  return (int64_t)p.nsplit * m * (int64_t)sizeof(float2);
+}
+
+extern "C" int32_t gcr_infonce_fwd_f32(const float* a, const float* a_scale, int64_t m, const float* b,
+                                       const float* b_scale, int64_t n, int32_t d, float inv_tau, float* lse,
+                                       void* workspace, void* stream) {
+  GCR_CHECK_ARG(m >= 0 && n >= 1);
+  if (!dim_supported(d)) return GCR_EUNSUPPORTED;
+  if (m == 0) return GCR_OK;
+  GCR_CHECK_ARG(a != nullptr && b != nullptr && lse != nullptr && workspace != nullptr);
+  GCR_CHECK_ARG(m < (1ll << 40) && n < (1ll << 40));
+  hipStream_t s = (hipStream_t)stream;
+  switch (d) {
+    case 32: return launch_fwd<32>(a, a_scale, m, b, b_scale, n, inv_tau, lse, workspace, s);
+    case 64: return launch_fwd<64>(a, a_scale, m, b, b_scale, n, inv_tau, lse, workspace, s);
+    case 128: return launch_fwd<128>(a, a_scale, m, b, b_scale, n, inv_tau, lse, workspace, s);
+    default: return launch_fwd<256>(a, a_scale, m, b, b_scale, n, inv_tau, lse, workspace, s);
+  }
+}
+
+extern "C" int32_t gcr_row_inv_norm_f32(const float* x, int64_t n, int32_t d, float eps, float* out, void* stream) {
+  GCR_CHECK_ARG(n >= 0 && d >= 1);
+  if (n == 0) return GCR_OK;
+  GCR_CHECK_ARG(x != nullptr && out != nullptr);
+  const int64_t want = (n + 15) / 16;
+  hipLaunchKernelGGL(row_inv_norm_kernel, dim3((unsigned)(want > 8192 ? 8192 : want)), dim3(256), 0,
+                     (hipStream_t)stream, x, n, d, eps, out);
+  return GCR_LAUNCH_STATUS();
+}
+
+extern "C" int32_t gcr_pos_logit_f32(const float* a, const float* a_scale, const float* b, const float* b_scale,
+                                     const int64_t* pos, int64_t m, int64_t n, int32_t d, float scale, float* out,
+                                     void* stream) {
+  GCR_CHECK_ARG(m >= 0 && n >= 0 && d >= 1);
+  if (m == 0) return GCR_OK;
+  GCR_CHECK_ARG(a != nullptr && b != nullptr && out != nullptr);
+  const int64_t want = (m + 15) / 16;
+  hipLaunchKernelGGL(pos_logit_kernel, dim3((unsigned)(want > 8192 ? 8192 : want)), dim3(256), 0, (hipStream_t)stream,
+                     a, a_scale, b, b_scale, pos, m, n, d, scale, out);
+  return GCR_LAUNCH_STATUS();
+}
+
+extern "C" int64_t gcr_infonce_bwd_workspace_bytes(int64_t mx, int64_t ny, int32_t d) {
+  if (mx <= 0 || ny <= 0 || !dim_supported(d)) return 0;
+  FwdPlan p;
+  switch (d) {
+    case 32: p = plan_bwd<32>(mx, ny); break;
+    case 64: p = plan_bwd<64>(mx, ny); break;
+    case 128: p = plan_bwd<128>(mx, ny); break;
+    default: p = plan_bwd<256>(mx, ny); break;
+  }
+  return p.nsplit > 1 ? (int64_t)p.nsplit * mx * d * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int32_t gcr_infonce_bwd_f32(const float* x, const float* x_scale, int64_t mx, const float* y,
+                                       const float* y_scale, int64_t ny, int32_t d, float inv_tau, const float* lse_x,
+                                       const float* w_x, const float* lse_y, const float* w_y, float* g,
+                                       void* workspace, void* stream) {
+  GCR_CHECK_ARG(mx >= 0 && ny >= 1);
+  if (!dim_supported(d)) return GCR_EUNSUPPORTED;
+  if (mx == 0) return GCR_OK;
+  GCR_CHECK_ARG(x != nullptr && y != nullptr && g != nullptr);
+  GCR_CHECK_ARG((w_x == nullptr) == (lse_x == nullptr) && (w_y == nullptr) == (lse_y == nullptr));
+  GCR_CHECK_ARG(workspace != nullptr || gcr_infonce_bwd_workspace_bytes(mx, ny, d) == 0);
+  hipStream_t s = (hipStream_t)stream;
+  switch (d) {
+    case 32: return launch_bwd<32>(x, x_scale, mx, y, y_scale, ny, inv_tau, lse_x, w_x, lse_y, w_y, g, workspace, s);
+    case 64: return launch_bwd<64>(x, x_scale, mx, y, y_scale, ny, inv_tau, lse_x, w_x, lse_y, w_y, g, workspace, s);
+    case 128: return launch_bwd<128>(x, x_scale, mx, y, y_scale, ny, inv_tau, lse_x, w_x, lse_y, w_y, g, workspace, s);
+    default: return launch_bwd<256>(x, x_scale, mx, y, y_scale, ny, inv_tau, lse_x, w_x, lse_y, w_y, g, workspace, s);
+  }
+}
+
+extern "C" int32_t gcr_infonce_pos_bwd_f32(const float* x, const float* x_scale, const float* y, const float* y_scale,
+                                           const int64_t* pos, const float* coef, int64_t mx, int64_t ny, int32_t d,
+                                           float inv_tau, float* gx, float* gy, void* stream) {
+  GCR_CHECK_ARG(mx >= 0 && ny >= 0 && d >= 1);
+  if (mx == 0) return GCR_OK;
+  GCR_CHECK_ARG(x != nullptr && y != nullptr && coef != nullptr && (gx != nullptr || gy != nullptr));
+  const int64_t want = (mx + 3) / 4;
+  hipLaunchKernelGGL(pos_bwd_kernel, dim3((unsigned)(want > 8192 ? 8192 : want)), dim3(256), 0, (hipStream_t)stream, x,
+                     x_scale, y, y_scale, pos, coef, mx, ny, d, inv_tau, gx, gy);
+  return GCR_LAUNCH_STATUS();
+}
+
+extern "C" int32_t gcr_normalize_bwd_f32(const float* x, const float* inv_norm, const float* ghat, int64_t n,
+                                         int32_t d, float* out, void* stream) {
+  GCR_CHECK_ARG(n >= 0 && d >= 1);
+  if (n == 0) return GCR_OK;
+  GCR_CHECK_ARG(x != nullptr && inv_norm != nullptr && ghat != nullptr && out != nullptr);
+  const int64_t want = (n + 15) / 16;
+  hipLaunchKernelGGL(normalize_bwd_kernel, dim3((unsigned)(want > 8192 ? 8192 : want)), dim3(256), 0,
+                     (hipStream_t)stream, x, inv_norm, ghat, n, d, out);
+  return GCR_LAUNCH_STATUS();
+}

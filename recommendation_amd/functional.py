@@ -270,3 +270,140 @@ def edge_mask_bits(nnz, pe, seed, device, edge_id=None):
     _lib.check(_lib.lib().gcr_edge_mask_bits(int(nnz), float(pe), int(seed) & (2 ** 64 - 1), _lib.dptr(edge_id),
                                              _lib.dptr(bits), _lib.cur_stream(device)), "gcr_edge_mask_bits")
     return bits
+
+
+# ---------------------------------------------------------------------------------------------
+# InfoNCE family (C1-C4): row logsumexp of the all-pairs logits on the fp32 MFMA
+# ---------------------------------------------------------------------------------------------
+_MFMA_DIMS = (32, 64, 128, 256)
+
+
+def _pad_dim(x):
+    """Zero-pad the feature dim to the next width the MFMA kernels are built for (dot products
+    and norms are unchanged by zero columns)."""
+    d = x.shape[1]
+    for w in _MFMA_DIMS:
+        if d == w:
+            return x
+        if d < w:
+            return torch.nn.functional.pad(x, (0, w - d))
+    raise ValueError("embedding dim must be <= 256")
+
+
+def row_inv_norm(x, eps=1e-12):
+    """1 / max(||x_r||, eps) per row — F.normalize's denominator (ncl.py:127, gcl.py:29-30)."""
+    _lib.require_cuda(x)
+    x = x.contiguous()
+    out = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().gcr_row_inv_norm_f32(_lib.dptr(x), x.shape[0], x.shape[1], float(eps), _lib.dptr(out),
+                                               _lib.cur_stream(x.device)), "gcr_row_inv_norm_f32")
+    return out
+
+
+def infonce_lse_raw(a, a_scale, b, b_scale, inv_tau):
+    """lse[i] = log sum_j exp(inv_tau * a_scale[i] b_scale[j] <a_i, b_j>) (no autograd)."""
+    L = _lib.lib()
+    m, d = a.shape
+    n = b.shape[0]
+    lse = torch.empty(m, dtype=torch.float32, device=a.device)
+    ws = torch.empty(max(int(L.gcr_infonce_fwd_workspace_bytes(m, n, d)), 8) // 4, dtype=torch.float32, device=a.device)
+    _lib.check(L.gcr_infonce_fwd_f32(_lib.dptr(a), _lib.dptr(a_scale), m, _lib.dptr(b), _lib.dptr(b_scale), n, d,
+                                     float(inv_tau), _lib.dptr(lse), _lib.dptr(ws), _lib.cur_stream(a.device)),
+               "gcr_infonce_fwd_f32")
+    return lse
+
+
+def pos_logit_raw(a, a_scale, b, b_scale, pos, scale):
+    m, d = a.shape
+    out = torch.empty(m, dtype=torch.float32, device=a.device)
+    _lib.check(_lib.lib().gcr_pos_logit_f32(_lib.dptr(a), _lib.dptr(a_scale), _lib.dptr(b), _lib.dptr(b_scale),
+                                            _lib.dptr(pos), m, b.shape[0], d, float(scale), _lib.dptr(out),
+                                            _lib.cur_stream(a.device)), "gcr_pos_logit_f32")
+    return out
+
+
+def _infonce_bwd_raw(x, x_scale, y, y_scale, inv_tau, lse_x, w_x, lse_y, w_y):
+    """g = inv_tau * sum_j P_ij yhat_j (see gcr_infonce_bwd_f32): gradient w.r.t. the scaled rows of x."""
+    L = _lib.lib()
+    mx, d = x.shape
+    g = torch.empty_like(x)
+    nbytes = int(L.gcr_infonce_bwd_workspace_bytes(mx, y.shape[0], d))
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device) if nbytes else None
+    _lib.check(L.gcr_infonce_bwd_f32(_lib.dptr(x), _lib.dptr(x_scale), mx, _lib.dptr(y), _lib.dptr(y_scale), y.shape[0],
+                                     d, float(inv_tau), _lib.dptr(lse_x), _lib.dptr(w_x), _lib.dptr(lse_y),
+                                     _lib.dptr(w_y), _lib.dptr(g), _lib.dptr(ws), _lib.cur_stream(x.device)),
+               "gcr_infonce_bwd_f32")
+    return g
+
+
+class _InfoNCEStats(torch.autograd.Function):
+    """(a, b) -> row_lse [M], pos_logit [M] (and col_lse [N]) of S = inv_tau * ahat bhat^T, with the
+    flash-style HIP backward.  Every loss of the InfoNCE family is a few [M]-vector ops on top."""
+
+    @staticmethod
+    def forward(ctx, a, b, pos, inv_tau, normalize, want_col):
+        a_p, b_p = _pad_dim(a).contiguous(), _pad_dim(b).contiguous()
+        sa = row_inv_norm(a_p) if normalize else None
+        sb = row_inv_norm(b_p) if normalize else None
+        lse = infonce_lse_raw(a_p, sa, b_p, sb, inv_tau)
+        pl = pos_logit_raw(a_p, sa, b_p, sb, pos, inv_tau)
+        col = infonce_lse_raw(b_p, sb, a_p, sa, inv_tau) if want_col else None
+        ctx.save_for_backward(a_p, b_p, pos, sa, sb, lse, col)
+        ctx.inv_tau, ctx.d = inv_tau, a.shape[1]
+        if want_col:
+            return lse, pl, col
+        return lse, pl
+
+    @staticmethod
+    def backward(ctx, g_lse, g_pos, g_col=None):
+        a, b, pos, sa, sb, lse, col = ctx.saved_tensors
+        L = _lib.lib()
+        inv_tau = ctx.inv_tau
+        need_a, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        g_lse = g_lse.contiguous().float() if g_lse is not None else None
+        g_col = g_col.contiguous().float() if (g_col is not None and col is not None) else None
+        lse_r = lse if g_lse is not None else None
+        col_r = col if g_col is not None else None
+        ga = gb = None
+        stream = _lib.cur_stream(a.device)
+        if need_a:
+            ga = _infonce_bwd_raw(a, sa, b, sb, inv_tau, lse_r, g_lse, col_r, g_col)
+        if need_b:
+            gb = _infonce_bwd_raw(b, sb, a, sa, inv_tau, col_r, g_col, lse_r, g_lse)
+        if g_pos is not None and (need_a or need_b):
+            _lib.check(L.gcr_infonce_pos_bwd_f32(_lib.dptr(a), _lib.dptr(sa), _lib.dptr(b), _lib.dptr(sb), _lib.dptr(pos),
+                                                 _lib.dptr(g_pos.contiguous().float()), a.shape[0], b.shape[0], a.shape[1],
+                                                 float(inv_tau), _lib.dptr(ga), _lib.dptr(gb), stream),
+                       "gcr_infonce_pos_bwd_f32")
+        if sa is not None:
+            for x, s, g in ((a, sa, ga), (b, sb, gb)):
+                if g is not None:
+                    _lib.check(L.gcr_normalize_bwd_f32(_lib.dptr(x), _lib.dptr(s), _lib.dptr(g), x.shape[0], x.shape[1],
+                                                       _lib.dptr(g), stream), "gcr_normalize_bwd_f32")
+        d = ctx.d
+        if ga is not None and ga.shape[1] != d:
+            ga = ga[:, :d].contiguous()
+        if gb is not None and gb.shape[1] != d:
+            gb = gb[:, :d].contiguous()
+        return ga, gb, None, None, None, None
+
+
+def infonce_stats(a, b, pos=None, temperature=0.2, normalize=True, want_col=False):
+    """Row logsumexp and positive logit of S = (ahat @ bhat.T) / temperature without materialising S.
+    a: [M, d] anchors, b: [N, d] candidates, pos: int64 [M] index of each anchor's positive row in b
+    (None: the diagonal, requires N >= M).  Returns (lse [M], pos_logit [M]) and, with want_col,
+    also the column logsumexp [N] (gcl.py:34 `cross_entropy(sim.T, labels)`).  Differentiable
+    w.r.t. a and b."""
+    _lib.require_cuda(a, b)
+    if a.dim() != 2 or b.dim() != 2 or a.shape[1] != b.shape[1] or a.dtype != torch.float32 or b.dtype != torch.float32:
+        raise ValueError("a [M, d] and b [N, d] must be float32 with the same d")
+    if b.shape[0] == 0:
+        raise ValueError("empty candidate table")
+    if pos is None:
+        if b.shape[0] < a.shape[0]:
+            raise ValueError("diagonal positives need N >= M")
+    else:
+        pos = _as_index(pos, a.device)
+        if pos.shape != (a.shape[0],):
+            raise ValueError("pos must be [M]")
+    return _InfoNCEStats.apply(a, b, pos, 1.0 / float(temperature), bool(normalize), bool(want_col))

@@ -1,0 +1,91 @@
+"""Loss functions with the reference's names, argument order and return values, computed by the
+HIP kernels of libgcr (no M x N score matrix is ever materialised).
+
+  InfoNCE, bpr_loss, l2_reg_loss          ncl.py:116-130 (= ssl4rec.py:16-23)
+  info_nce_loss                           gcl.py:28-35 (= univariate/gcl_univariate.py:28-35)
+  batch_softmax_loss                      ssl4rec.py:25-30
+  ssl_layer_loss, ProtoNCE_loss           ncl.py:358-375 (NCLModel methods; here plain functions
+                                          taking what the methods read from `self`)
+"""
+from __future__ import annotations
+
+import torch
+
+from . import functional as Fn
+
+
+def InfoNCE(view1, view2, temperature: float, b_cos: bool = True):
+    """ncl.py:125-130: -mean(diag(log_softmax(view1n @ view2n.T / temperature, dim=1)))."""
+    lse, pos = Fn.infonce_stats(view1, view2, None, temperature, normalize=b_cos)
+    return (lse - pos).mean()
+
+
+def info_nce_loss(z1, z2, temp=0.2):
+    """gcl.py:28-35: (CE(sim, arange) + CE(sim.T, arange)) / 2, sim = z1n @ z2n.T / temp."""
+    if z1.shape[0] != z2.shape[0]:
+        raise ValueError("info_nce_loss needs as many rows in z2 as in z1 (labels = arange)")
+    lse, pos, col = Fn.infonce_stats(z1, z2, None, temp, normalize=True, want_col=True)
+    return ((lse - pos).mean() + (col - pos).mean()) / 2
+
+
+def batch_softmax_loss(user_emb, item_emb, temperature):
+    """ssl4rec.py:25-30: mean(-log(exp(pos/t) / sum_j exp(<u, i_j>/t) + 1e-6)) on normalised rows."""
+    lse, pos = Fn.infonce_stats(user_emb, item_emb, None, temperature, normalize=True)
+    return (-torch.log(torch.exp(pos - lse) + 1e-6)).mean()
+
+
+def ssl_layer_loss(context, initial, user, item, user_num, ssl_temp, ssl_reg, alpha):
+    """ncl.py:358-367 (NCLModel.ssl_layer_loss): structure contrast of the batch's context-layer rows
+    against ALL layer-0 rows of the same side; positives = the row's own layer-0 embedding; summed."""
+    cu, ci = context[:user_num], context[user_num:]
+    iu, ii = initial[:user_num], initial[user_num:]
+    dev = context.device
+    user = torch.as_tensor(user, device=dev, dtype=torch.int64)
+    item = torch.as_tensor(item, device=dev, dtype=torch.int64)
+    lse_u, pos_u = Fn.infonce_stats(cu[user], iu, user, ssl_temp, normalize=True)
+    lse_i, pos_i = Fn.infonce_stats(ci[item], ii, item, ssl_temp, normalize=True)
+    return ssl_reg * ((lse_u - pos_u).sum() + alpha * (lse_i - pos_i).sum())
+
+
+def ProtoNCE_loss(initial_emb, user_idx, item_idx, user_num, user_centroids, user_2cluster, item_centroids,
+                  item_2cluster, ssl_temp, proto_reg, batch_size):
+    """ncl.py:369-375 (NCLModel.ProtoNCE_loss): InfoNCE(e0[idx], centroids[assign[idx]]) * batch_size."""
+    dev = initial_emb.device
+    user_idx = torch.as_tensor(user_idx, device=dev, dtype=torch.int64)
+    item_idx = torch.as_tensor(item_idx, device=dev, dtype=torch.int64)
+    user_emb, item_emb = initial_emb[:user_num], initial_emb[user_num:]
+    u2c = user_centroids.to(dev)[user_2cluster.to(dev)[user_idx]]
+    i2c = item_centroids.to(dev)[item_2cluster.to(dev)[item_idx]]
+    loss_user = InfoNCE(user_emb[user_idx], u2c, ssl_temp) * batch_size
+    loss_item = InfoNCE(item_emb[item_idx], i2c, ssl_temp) * batch_size
+    return proto_reg * (loss_user + loss_item)
+
+
+def _rows(x):
+    return torch.arange(x.shape[0], device=x.device)
+
+
+def bpr_loss(user_emb, pos_item_emb, neg_item_emb):
+    """ncl.py:116-120: mean(-log(10e-6 + sigmoid(<u,p> - <u,n>))) on already-gathered rows."""
+    r = _rows(user_emb)
+    return Fn.bpr_sums(user_emb, torch.cat([pos_item_emb, neg_item_emb]), r, r, r + user_emb.shape[0], Fn.BPR_NCL)[0] \
+        / user_emb.shape[0]
+
+
+def bpr_loss_logsigmoid(user_emb, pos_emb, neg_emb):
+    """sept.py:34-38 / gcl.py:219-221: -mean(logsigmoid(pos - neg))."""
+    r = _rows(user_emb)
+    return Fn.bpr_sums(user_emb, torch.cat([pos_emb, neg_emb]), r, r, r + user_emb.shape[0], Fn.BPR_LOGSIGMOID)[0] \
+        / user_emb.shape[0]
+
+
+def l2_reg_loss(reg, *args):
+    """ncl.py:122-123: reg * sum_x ||x||_F / rows(x) (tiny reductions; stays in torch)."""
+    return reg * sum(torch.norm(x, p=2) / x.shape[0] for x in args)
+
+
+def bpr_gather_loss(user_tab, item_tab, u_idx, i_idx, j_idx, variant=Fn.BPR_NCL):
+    """Fused form used by the model classes: gathers + BPR in one kernel, gradients scattered
+    straight into the tables.  Returns (mean bpr loss, sum|u|^2, sum|p|^2, sum|n|^2)."""
+    sums = Fn.bpr_sums(user_tab, item_tab, u_idx, i_idx, j_idx, variant)
+    return sums[0] / max(len(u_idx), 1), sums[1], sums[2], sums[3]

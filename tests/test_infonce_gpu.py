@@ -1,0 +1,196 @@
+"""GPU parity of the MFMA InfoNCE kernels (through the C ABI) against the CPU oracle and the
+reference-generated goldens.  Tolerance 1e-5 relative fp32 on the loss values (north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle_c as C
+from oracle import oracle_np as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def Fn():
+    from recommendation_amd import functional
+    return functional
+
+
+def _lse(Fn, a, b, inv_tau, normalize):
+    at, bt = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    sa = Fn.row_inv_norm(at) if normalize else None
+    sb = Fn.row_inv_norm(bt) if normalize else None
+    return Fn.infonce_lse_raw(Fn._pad_dim(at).contiguous(), sa, Fn._pad_dim(bt).contiguous(), sb, inv_tau).cpu().numpy()
+
+
+@pytest.mark.parametrize("m,n,d", [(1, 1, 64), (7, 7, 64), (257, 257, 64), (64, 1000, 64), (300, 33, 64),
+                                   (130, 4097, 32), (100, 777, 128), (70, 500, 256), (50, 300, 48), (40, 90, 100)])
+@pytest.mark.parametrize("normalize", [True, False])
+def test_row_lse_matches_oracle(Fn, m, n, d, normalize):
+    rng = np.random.default_rng(m * 1000 + n + d)
+    a = (rng.standard_normal((m, d)) * 0.4).astype(np.float32)
+    b = (rng.standard_normal((n, d)) * 0.4).astype(np.float32)
+    ref, _ = O.row_lse_scores(a, b, 5.0, normalize)
+    got = _lse(Fn, a, b, 5.0, normalize)
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5)
+
+
+def test_lse_extreme_logits_and_inv_norm(Fn):
+    rng = np.random.default_rng(0)
+    a = rng.standard_normal((33, 64)).astype(np.float32) * 3
+    b = rng.standard_normal((2000, 64)).astype(np.float32) * 3
+    b[17] = a[5] * 4             # a huge positive logit (~ +2000) in the middle of the stream
+    a[9] = 0                     # an all-zero anchor: every logit 0 -> lse = log n
+    ref, _ = O.row_lse_scores(a, b, 1.0, False)
+    got = _lse(Fn, a, b, 1.0, False)
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5)
+    assert got[9] == pytest.approx(np.log(2000), rel=1e-6)
+    inv = Fn.row_inv_norm(torch.from_numpy(a).cuda()).cpu().numpy()
+    nrm = np.sqrt((a.astype(np.float64) ** 2).sum(1))
+    np.testing.assert_allclose(inv, 1 / np.maximum(nrm, 1e-12), rtol=1e-6)
+
+
+def test_pos_logit(Fn):
+    rng = np.random.default_rng(1)
+    a = rng.standard_normal((100, 64)).astype(np.float32)
+    b = rng.standard_normal((50, 64)).astype(np.float32)
+    pos = rng.integers(0, 50, 100)
+    at, bt = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    sa, sb = Fn.row_inv_norm(at), Fn.row_inv_norm(bt)
+    got = Fn.pos_logit_raw(at, sa, bt, sb, torch.from_numpy(pos).cuda(), 5.0).cpu().numpy()
+    _, s = O.row_lse_scores(a, b, 5.0, True)
+    np.testing.assert_allclose(got, s[np.arange(100), pos], rtol=1e-5, atol=1e-5)
+
+
+def test_large_rectangular_against_c_oracle(Fn):
+    """ncl.py:363-366 shape: B anchors against ALL rows of a table (2048 x 100K, d = 64)."""
+    rng = np.random.default_rng(2)
+    a = (rng.standard_normal((2048, 64)) * 0.3).astype(np.float32)
+    b = (rng.standard_normal((100_000, 64)) * 0.3).astype(np.float32)
+    ref, _ = C.row_lse(a, b, None, 10.0, True)
+    got = _lse(Fn, a, b, 10.0, True)
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------ reference-named losses
+@pytest.fixture(scope="module")
+def Ls():
+    from recommendation_amd import losses
+    return losses
+
+
+def _t(x, grad=False):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda().requires_grad_(grad)
+
+
+def _gclose(t, ref, rel=1e-4, floor=1e-8):
+    got = t.detach().cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(got, ref, rtol=rel, atol=max(1e-5 * np.abs(ref).max(), floor))
+
+
+@pytest.mark.parametrize("m", [1, 7, 257, 1000])
+def test_golden_loss_values(Ls, golden, m):
+    """gcl.info_nce_loss, ncl.InfoNCE (= ssl4rec.InfoNCE), ssl4rec.batch_softmax_loss outputs."""
+    c = golden("contrast.npz")
+    z1, z2 = _t(c[f"z1_{m}"]), _t(c[f"z2_{m}"])
+    for temp in (0.1, 0.2, 0.5):
+        assert float(Ls.info_nce_loss(z1, z2, temp)) == pytest.approx(float(c[f"gcl_loss_{m}_{temp}"]), rel=1e-5, abs=2e-6)
+    for b_cos in (True, False):
+        got = float(Ls.InfoNCE(0.3 * z1, 0.3 * z2, 0.2, b_cos))
+        assert got == pytest.approx(float(c[f"ncl_infonce_{m}_{int(b_cos)}"]), rel=1e-5, abs=2e-6)
+    assert float(Ls.batch_softmax_loss(z1, z2, 0.2)) == pytest.approx(float(c[f"s4r_bsl_{m}"]), rel=1e-5, abs=2e-6)
+
+
+@pytest.mark.parametrize("m", [7, 257])
+def test_golden_info_nce_loss_grads(Ls, golden, m):
+    c = golden("contrast.npz")
+    z1, z2 = _t(c[f"z1_{m}"], True), _t(c[f"z2_{m}"], True)
+    Ls.info_nce_loss(z1, z2, 0.2).backward()
+    _gclose(z1.grad, c[f"gcl_g1_{m}"])
+    _gclose(z2.grad, c[f"gcl_g2_{m}"])
+
+
+@pytest.mark.parametrize("b_cos", [1, 0])
+def test_golden_ncl_infonce_grads(Ls, golden, b_cos):
+    c = golden("contrast.npz")
+    z1, z2 = _t(0.3 * c["z1_257"], True), _t(0.3 * c["z2_257"], True)
+    Ls.InfoNCE(z1, z2, 0.2, bool(b_cos)).backward()
+    # b_cos=False saturates the softmax (logits ~29, p_ii = 1 - 1e-11): the true gradient (~1e-13) is
+    # below fp32 cancellation noise in the reference itself (it is (softmax - onehot) @ z / (m t)),
+    # so the bound is 1e-5 of the un-cancelled term scale |z| / (m * temperature)
+    floor = 1e-8 if b_cos else 1e-5 * float(np.abs(0.3 * c["z2_257"]).max()) / (257 * 0.2)
+    _gclose(z1.grad, c[f"ncl_infonce_g1_257_{b_cos}"], floor=floor)
+    _gclose(z2.grad, c[f"ncl_infonce_g2_257_{b_cos}"], floor=floor)
+
+
+def test_golden_ncl_structure_and_prototype(Ls, golden):
+    """NCLModel.ssl_layer_loss / ProtoNCE_loss (ncl.py:358-375) values and gradients."""
+    c = golden("contrast.npz")
+    nu = int(c["ncl_num_users"])
+    ctx, x0 = _t(c["ncl_ctx"], True), _t(c["ncl_x0"], True)
+    ssl = Ls.ssl_layer_loss(ctx, x0, c["ncl_uidx"], c["ncl_iidx"], nu, float(c["ncl_ssl_temp"]),
+                            float(c["ncl_ssl_reg"]), float(c["ncl_alpha"]))
+    assert float(ssl) == pytest.approx(float(c["ncl_ssl"]), rel=1e-5)
+    ssl.backward()
+    _gclose(ctx.grad, c["ncl_ssl_gctx"], floor=1e-12)
+    _gclose(x0.grad, c["ncl_ssl_gx0"], floor=1e-12)
+    x0p = _t(c["ncl_x0"], True)
+    proto = Ls.ProtoNCE_loss(x0p, c["ncl_uidx"], c["ncl_iidx"], nu, _t(c["ncl_ucent"]), _t(c["ncl_u2c"]),
+                             _t(c["ncl_icent"]), _t(c["ncl_i2c"]), float(c["ncl_ssl_temp"]), float(c["ncl_proto_reg"]),
+                             int(c["ncl_bsz"]))
+    assert float(proto) == pytest.approx(float(c["ncl_proto"]), rel=1e-5)
+    proto.backward()
+    _gclose(x0p.grad, c["ncl_proto_gx0"], floor=1e-13)
+
+
+@pytest.mark.parametrize("m,n,d,normalize,sym", [(64, 333, 64, True, False), (300, 300, 64, True, True),
+                                                 (130, 1000, 128, False, False), (90, 90, 32, True, True),
+                                                 (33, 70, 256, True, False), (50, 120, 48, True, False)])
+def test_stats_grads_match_oracle(Fn, m, n, d, normalize, sym):
+    """Random upstream weights on lse / pos / col: exercises every term of the backward kernels."""
+    rng = np.random.default_rng(m + n + d)
+    sc = 0.4 if normalize else 0.15
+    a = (rng.standard_normal((m, d)) * sc).astype(np.float32)
+    b = (rng.standard_normal((n, d)) * sc).astype(np.float32)
+    pos = np.arange(m) if sym else rng.integers(0, n, m)
+    w_l, w_p = rng.standard_normal(m), rng.standard_normal(m)
+    at, bt = _t(a, True), _t(b, True)
+    out = Fn.infonce_stats(at, bt, None if sym else pos, 0.2, normalize, want_col=sym)
+    loss = (out[0] * _t(w_l.astype(np.float32))).sum() + (out[1] * _t(w_p.astype(np.float32))).sum()
+    w_c = None
+    if sym:
+        w_c = rng.standard_normal(n)
+        loss = loss + (out[2] * _t(w_c.astype(np.float32))).sum()
+    loss.backward()
+    # oracle: L = sum w_l lse + sum w_p pos (+ sum w_c col)  ==  infonce_grads with row_w = w_l and the
+    # positive coefficient -w_l replaced by +w_p: add the difference analytically
+    g1, g2 = O.infonce_grads(a, b, pos, 5.0, normalize, w_l, w_c)
+    an, bn = (O.row_l2_normalize(a), O.row_l2_normalize(b)) if normalize else (a.astype(np.float64), b.astype(np.float64))
+    extra = w_l + w_p + (w_c[:m] if sym else 0.0)       # infonce_grads subtracted w_l (+ w_c) at the positive
+    d_an = extra[:, None] * bn[pos] * 5.0
+    d_bn = np.zeros_like(bn)
+    np.add.at(d_bn, pos, extra[:, None] * an * 5.0)
+    if normalize:
+        def thr(x, xn, g):
+            nrm = np.maximum(np.sqrt((x.astype(np.float64) ** 2).sum(1, keepdims=True)), 1e-12)
+            return (g - xn * (xn * g).sum(1, keepdims=True)) / nrm
+        d_an, d_bn = thr(a, an, d_an), thr(b, bn, d_bn)
+    _gclose(at.grad, g1 + d_an, rel=2e-4)
+    _gclose(bt.grad, g2 + d_bn, rel=2e-4)
+
+
+def test_info_nce_loss_round_trip_properties(Ls):
+    """Size-independent checks at a size the dense formulation cannot allocate comfortably
+    (100K x 100K logits = 40 GB): identical views give lse_i >= pos_i = 1/temp, the loss is
+    symmetric in its arguments, and permuting both views together leaves it unchanged."""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    z1 = torch.randn(100_000, 64, device="cuda", generator=g)
+    z2 = z1 + 0.3 * torch.randn(100_000, 64, device="cuda", generator=g)
+    l12 = float(Ls.info_nce_loss(z1, z2, 0.2))
+    l21 = float(Ls.info_nce_loss(z2, z1, 0.2))
+    assert l12 == pytest.approx(l21, rel=1e-5)
+    perm = torch.randperm(100_000, device="cuda", generator=g)
+    assert float(Ls.info_nce_loss(z1[perm], z2[perm], 0.2)) == pytest.approx(l12, rel=1e-5)
+    from recommendation_amd import functional as F2
+    lse, pos = F2.infonce_stats(z1, z1, None, 0.2)
+    assert float((pos - 5.0).abs().max()) < 1e-4 and bool((lse >= pos - 1e-4).all())

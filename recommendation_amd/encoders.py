@@ -1,0 +1,134 @@
+"""Host-side mirror of the reference's data / encoder classes for the hot path, on top of the HIP
+ops: same constructor arguments, attribute names and return values, so a reference script swaps
+its class for this one and keeps its training loop.
+
+  Interaction     ncl.py:46-88 (= directau.py:102-144, univariate/sept.py:109-152)
+  LGCNEncoder     ncl.py:397-422 (= directau.py:269-293, selfcf.py:457-485 with normalised=True)
+  LightGCN        lightgcn.py:12-27
+  sept_encoder    univariate/sept.py:220-226
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import functional as Fn
+from .graph import CsrGraph
+
+
+def _device(device=None):
+    return torch.device(device) if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
+
+
+class Interaction:
+    """ncl.py:46-88.  `train`/`test` are lists of (user, item, rating) with hashable raw ids.
+    Dense ids follow sorted raw-id order (ncl.py:60-61).  Besides the reference's attributes
+    (`user`, `item`, `id2user`, `id2item`, `user_num`, `item_num`, `training_data`,
+    `training_set_u`, `test_set`) it carries the device-resident operator `norm_adj` (a CsrGraph:
+    the raw 0/1 adjacency with duplicates kept, exactly what the reference calls norm_adj, Q1) and
+    the sorted per-user training rows the device sampler rejects against."""
+
+    def __init__(self, conf, train, test, device=None, normalised=False):
+        self.train, self.test = train, test
+        self.device = _device(device)
+        users = sorted({t[0] for t in train})
+        items = sorted({t[1] for t in train})
+        self.user = {u: k for k, u in enumerate(users)}
+        self.item = {i: k for k, i in enumerate(items)}
+        self.id2user = {k: u for u, k in self.user.items()}
+        self.id2item = {k: i for i, k in self.item.items()}
+        self.user_num, self.item_num = len(users), len(items)
+        self.training_data = [(t[0], t[1]) for t in train]
+        self.training_set_u = {u: set() for u in self.user}
+        for t in train:
+            self.training_set_u[t[0]].add(t[1])
+        self.test_set = {}
+        for t in test:
+            self.test_set.setdefault(t[0], {})[t[1]] = 1
+        self.uid = np.fromiter((self.user[t[0]] for t in train), dtype=np.int64, count=len(train))
+        self.iid = np.fromiter((self.item[t[1]] for t in train), dtype=np.int64, count=len(train))
+        build = CsrGraph.bipartite_sym_norm if normalised else CsrGraph.bipartite_raw
+        self.norm_adj = build(self.uid, self.iid, self.user_num, self.item_num, self.device)
+        # sorted, de-duplicated positives per user for the rejection sampler
+        keys = np.unique(self.uid * max(self.item_num, 1) + self.iid)
+        pu, pi = keys // max(self.item_num, 1), keys % max(self.item_num, 1)
+        rowptr = np.zeros(self.user_num + 1, dtype=np.int64)
+        np.cumsum(np.bincount(pu, minlength=self.user_num), out=rowptr[1:])
+        self.user_rowptr = torch.from_numpy(rowptr).to(self.device)
+        self.user_items_sorted = torch.from_numpy(pi.astype(np.int32)).to(self.device)
+        self.uid_dev = torch.from_numpy(self.uid).to(self.device)
+        self.iid_dev = torch.from_numpy(self.iid).to(self.device)
+
+    def get_user_id(self, user):
+        return self.user[user]
+
+    def user_rated(self, user):
+        return list(self.training_set_u[user]), []
+
+
+class LGCNEncoder(nn.Module):
+    """ncl.py:397-422: `forward()` -> (user_emb [U, d], item_emb [I, d], all_emb list of K+1 [N, d]),
+    final = mean of the K+1 layer outputs; K SpMMs with the mean fused into the epilogue."""
+
+    def __init__(self, data, emb_size, n_layers):
+        super().__init__()
+        self.data = data
+        self.latent_size = emb_size
+        self.layers = n_layers
+        self.norm_adj = data.norm_adj
+        init = nn.init.xavier_uniform_
+        self.embedding_dict = nn.ParameterDict({
+            "user_emb": nn.Parameter(init(torch.empty(data.user_num, emb_size))),
+            "item_emb": nn.Parameter(init(torch.empty(data.item_num, emb_size))),
+        }).to(data.device)
+
+    def forward(self):
+        emb = torch.cat([self.embedding_dict["user_emb"], self.embedding_dict["item_emb"]], 0)
+        final, all_emb = Fn.lightgcn_propagate(self.norm_adj, emb, self.layers, combine="mean", return_layers=True)
+        return final[: self.data.user_num], final[self.data.user_num:], all_emb
+
+
+class LightGCN(nn.Module):
+    """lightgcn.py:12-27: `forward(edge_index)` -> (user_emb, item_emb) = SUM over layers 0..K of the
+    LGConv propagation (no division, Q3).  The gcn_norm weights + CSR are prepared once per
+    edge_index tensor and cached (the reference recomputes them in every LGConv call)."""
+
+    def __init__(self, num_users, num_items, embedding_dim=64, num_layers=3):
+        super().__init__()
+        self.user_embedding = nn.Embedding(num_users, embedding_dim)
+        self.item_embedding = nn.Embedding(num_items, embedding_dim)
+        self.num_layers = num_layers
+        nn.init.xavier_uniform_(self.user_embedding.weight)
+        nn.init.xavier_uniform_(self.item_embedding.weight)
+        self._graph_key, self._graph = None, None
+
+    def prepare(self, edge_index, symmetric=None):
+        """Builds (or returns the cached) operator for `edge_index` int64 [2, nnz]."""
+        key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version)
+        if self._graph_key != key:
+            n = self.user_embedding.num_embeddings + self.item_embedding.num_embeddings
+            ei = edge_index.detach().cpu().numpy()
+            if symmetric is None:  # lightgcn.py:38-39 always passes [[u; i+U], [i+U; u]]
+                half = ei.shape[1] // 2
+                symmetric = ei.shape[1] % 2 == 0 and np.array_equal(ei[0, :half], ei[1, half:]) and \
+                    np.array_equal(ei[1, :half], ei[0, half:])
+            self._graph = CsrGraph.from_edge_index_gcn_norm(ei, n, self.user_embedding.weight.device, symmetric=symmetric)
+            self._graph_key = key
+        return self._graph
+
+    def forward(self, edge_index):
+        graph = edge_index if isinstance(edge_index, CsrGraph) else self.prepare(edge_index)
+        x = torch.cat([self.user_embedding.weight, self.item_embedding.weight], dim=0)
+        x = Fn.lightgcn_propagate(graph, x, self.num_layers, combine="sum")
+        nu = self.user_embedding.num_embeddings
+        return x[:nu], x[nu:]
+
+
+def sept_encoder(emb, adj: CsrGraph, n_layers: int):
+    """univariate/sept.py:220-226: emb_k = normalize(A emb_{k-1}) per layer, mean over K+1."""
+    all_embs, e = [emb], emb
+    for _ in range(n_layers):
+        e = Fn.spmm_l2norm(adj, e)
+        all_embs.append(e)
+    return torch.stack(all_embs, dim=0).mean(0)

@@ -32,12 +32,15 @@ WORKLOADS = {
     "cfg4": dict(users=10_000_000, items=1_000_000, edges=100_000_000, layers=3),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA = vector rate
 SEED = 20250919
 
 
-def synth_interactions_device(n_users, n_items, n_edges, seed, device):
+def synth_interactions_device(n_users, n_items, n_edges, seed, device, perm_seed=None):
     """Same recipe as oracle_np.synthetic_interactions (users uniform, items Zipf(1) capped at
-    0.5 % each, unique pairs, every user >= 1 edge), generated with torch on the GPU."""
+    0.5 % each, unique pairs, every user >= 1 edge), generated with torch on the GPU.
+    `perm_seed` fixes the popularity-rank -> item-id permutation separately from the draws (the
+    ranks of a sharded run share one item popularity law but draw their own users' edges)."""
     g = torch.Generator(device=device).manual_seed(seed)
     p = 1.0 / torch.arange(1, n_items + 1, device=device, dtype=torch.float64)
     p /= p.sum()
@@ -51,7 +54,8 @@ def synth_interactions_device(n_users, n_items, n_edges, seed, device):
         p[~over] += excess * p[~over] / p[~over].sum()
     cdf = torch.cumsum(p, 0)
     cdf[-1] = 1.0
-    perm = torch.randperm(n_items, generator=g, device=device)
+    gp = g if perm_seed is None else torch.Generator(device=device).manual_seed(perm_seed)
+    perm = torch.randperm(n_items, generator=gp, device=device)
 
     def draw_items(n):
         r = torch.rand(n, generator=g, device=device, dtype=torch.float64)
@@ -113,9 +117,8 @@ def main():
     import recommendation_amd as ra
     from recommendation_amd import functional as Fn
 
-    if world > 1:
-        from recommendation_amd import distributed as gdist
-        return gdist.bench_main(args, rank, world, dev)
+    if world > 1 or os.environ.get("GCR_BENCH_FORCE_DIST") == "1":
+        return main_sharded(args, rank, world, dev, ra)
 
     name = args.workload or "cfg2"
     wl = WORKLOADS[name]
@@ -161,10 +164,21 @@ def main():
                 "bytes_alg_per_launch": bytes_alg, "avg_launch_ms": round(avg_launch_ms, 4),
                 "compulsory_bytes_per_launch": nnz * 8 + (n + 1) * 4 + 2 * n * 4 * d}
 
+    # HBM traffic per launch from the committed rocprofv3 --pmc passes of the same workload
+    # (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, MI355X_MICROARCH.md §HBM); null when not profiled
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pmc = json.load(f).get(name)
+        if pmc and d == 64:
+            roofline["traffic"] = pmc["bytes_per_launch"]
+            roofline["traffic_source"] = pmc["source"]
+    except OSError:
+        pass
+
     extra = {"graph_build_s": round(t_build, 2), "nnz": nnz, "n_nodes": n,
              "spmm_parts": graph.plan.n_parts, "spmm_split_rows": graph.plan.n_long}
     if not args.no_extra:
-        extra.update(bench_extra(ra, Fn, graph, x0, k_layers, nnz, dev))
+        extra.update(bench_extra(ra, Fn, graph, x0, k_layers, nnz, dev, n_u, n_i))
 
     cpu = None
     if not args.no_cpu_baseline:
@@ -183,7 +197,92 @@ def main():
     print(json.dumps(line))
 
 
-def bench_extra(ra, Fn, graph, x0, k_layers, nnz, dev):
+def main_sharded(args, rank, world, dev, ra):
+    """N > 1: one rank per GPU, users row-sharded, items all-gathered / reduce-scattered over
+    xGMI every layer (recommendation_amd/distributed.py).  WEAK scaling: every rank brings its
+    own cfg2-sized block (1M users / 10M interactions by default) and the item side grows with N
+    (100K x N items), so N = 8 is 8M users x 800K items / 80M interactions — the cfg4 regime."""
+    import torch.distributed as dist
+    from recommendation_amd import distributed as gdist
+
+    if not dist.is_initialized():
+        dist.init_process_group(backend="nccl", device_id=dev)
+    name = args.workload or "cfg2"
+    wl = WORKLOADS[name]
+    n_u, n_e, k_layers, d = wl["users"], wl["edges"], wl["layers"], args.dim
+    n_i = wl["items"] * world
+    per_i, i_pad = gdist.shard_bounds(n_i, world)
+
+    users, items = synth_interactions_device(n_u, n_i, n_e, SEED + 7919 * (rank + 1), dev, perm_seed=SEED)
+    deg_i = torch.bincount(items, minlength=i_pad)
+    dist.all_reduce(deg_i)                                       # global item degrees (integer)
+    deg_u = torch.bincount(users, minlength=n_u)
+    du, di = deg_u.float().pow(-0.5), deg_i.float().pow(-0.5)
+    du[torch.isinf(du)] = 0.0
+    di[torch.isinf(di)] = 0.0
+
+    def block(row, col, n_rows, n_cols, rscale, cscale):
+        order = torch.argsort(row * n_cols + col)
+        r, c = row[order], col[order]
+        rowptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=dev)
+        rowptr[1:] = torch.cumsum(torch.bincount(r, minlength=n_rows), 0)
+        return ra.CsrGraph(rowptr, c.to(torch.int32), rscale[r] * cscale[c], n_rows, n_cols, dev)
+
+    r_ui = block(users, items, n_u, i_pad, du, di)
+    r_iu = block(items, users, i_pad, n_u, di, du)
+    graph = gdist.ShardedBipartiteGraph(r_ui, r_iu, n_u, n_i, per_i, rank, world)
+    nnz_local = r_ui.nnz + r_iu.nnz
+    gen = torch.Generator(device=dev).manual_seed(rank)
+    bound = (6.0 / (n_u * world + n_i + d)) ** 0.5                # xavier_uniform of the global table
+    x_u = (torch.rand(n_u, d, device=dev, generator=gen) * 2 - 1) * bound
+    x_i = (torch.rand(per_i, d, device=dev, generator=gen) * 2 - 1) * bound
+    torch.cuda.synchronize()
+
+    def step():
+        with torch.no_grad():
+            return gdist.sharded_propagate_raw(graph, x_u, x_i, k_layers, 1.0)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    nnz_all = torch.tensor([nnz_local], device=dev, dtype=torch.int64)
+    dist.all_reduce(nnz_all)
+    elapsed, nnz_all = float(elapsed.item()), int(nnz_all.item())
+    if rank == 0:
+        n_nodes = n_u * world + n_i
+        bytes_alg = nnz_all * (8 + 4 * d) + n_nodes * (4 * d + 4)
+        per_layer_s = elapsed / (args.steps * k_layers)
+        achieved = bytes_alg / per_layer_s / 1e9
+        line = {
+            "metric": "edges propagated/sec (LightGCN d=%d, %d-layer fwd message pass)" % (d, k_layers),
+            "value": nnz_all * k_layers * args.steps / elapsed, "unit": "edges/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{name} x{world} (weak): LightGCN {k_layers}-layer d={d}, {n_u * world} users "
+                                   f"(row-sharded, {n_u}/GPU) x {n_i} items / {n_e * world} interactions "
+                                   f"(nnz={nnz_all}); all-gather + reduce-scatter of the item table per layer",
+                       "users": n_u * world, "items": n_i, "interactions": n_e * world, "layers": k_layers, "dim": d,
+                       "parallelism": f"user-row shards x{world}, items replicated for compute"},
+            "roofline": {"bound": "hbm", "kernel": "spmm_parts (per-layer wall time incl. collectives)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                         "frac": round(achieved / (HBM_PEAK_GBS * world), 4), "traffic": None},
+            "cpu_baseline": None,
+        }
+        print(json.dumps(line))
+    dist.destroy_process_group()
+
+
+def bench_extra(ra, Fn, graph, x0, k_layers, nnz, dev, n_u, n_i):
     """Secondary rates, each timed on its own (not part of `value`)."""
     out = {}
 
@@ -205,6 +304,57 @@ def bench_extra(ra, Fn, graph, x0, k_layers, nnz, dev):
     t = timeit(fwd_bwd, 5)
     out["fwd_bwd_edges_per_s"] = nnz * 2 * k_layers / t
     out["fwd_bwd_ms"] = 1e3 * t
+    del xg
+
+    # InfoNCE pairs/s at the NCL per-batch shapes: B=2048 anchors against all users
+    # and all items (ncl.py:358-367) + two 2048 x 2048 prototype blocks (ncl.py:369-375)
+    from recommendation_amd import losses as Ls
+    d = x0.shape[1]
+    gen = torch.Generator(device=dev).manual_seed(1)
+    bsz = 2048
+    uidx = torch.randint(0, n_u, (bsz,), device=dev, generator=gen)
+    iidx = torch.randint(0, n_i, (bsz,), device=dev, generator=gen)
+    ctx = x0 + 0.1 * torch.randn(x0.shape, device=dev, generator=gen)
+    cent = torch.randn(2000, d, device=dev, generator=gen)
+    u2c = torch.randint(0, 2000, (n_u,), device=dev, generator=gen)
+    i2c = torch.randint(0, 2000, (n_i,), device=dev, generator=gen)
+    pairs = bsz * (n_u + n_i) + 2 * bsz * bsz
+
+    def ncl_contrast(x_init, x_ctx):
+        return Ls.ssl_layer_loss(x_ctx, x_init, uidx, iidx, n_u, 0.1, 1e-6, 1.5) + \
+            Ls.ProtoNCE_loss(x_init, uidx, iidx, n_u, cent, u2c, cent, i2c, 0.1, 8e-8, bsz)
+
+    with torch.no_grad():
+        t_f = timeit(lambda: ncl_contrast(x0, ctx), 5)
+    xi, xc = x0.clone().requires_grad_(True), ctx.clone().requires_grad_(True)
+
+    def contrast_fb():
+        xi.grad = xc.grad = None
+        ncl_contrast(xi, xc).backward()
+
+    t_fb = timeit(contrast_fb, 3)
+    out["infonce"] = {
+        "shapes": f"{bsz} x {n_u} + {bsz} x {n_i} + 2 x {bsz} x {bsz}, d={d}",
+        "pairs_per_s_fwd": pairs / t_f, "fwd_ms": 1e3 * t_f, "fwd_tflops": 2 * pairs * d / t_f / 1e12,
+        "pairs_per_s_fwd_bwd": pairs / t_fb, "fwd_bwd_ms": 1e3 * t_fb,
+        "fwd_frac_of_fp32_mfma_peak": round(2 * pairs * d / t_f / 1e12 / FP32_MFMA_PEAK_TF, 4),
+        "note": "fwd includes gathers, row norms, positive logits and the loss reductions"}
+    del xi, xc, ctx
+
+    # BPR + sampler (B = 2048 as ncl.py:293; and lightgcn.py's full batch B = E)
+    ut, it = x0[:n_u], x0[n_u:]
+    for name, b in (("b2048", 2048), ("full_batch", nnz // 2)):
+        u = torch.randint(0, n_u, (b,), device=dev, generator=gen)
+        i = torch.randint(0, n_i, (b,), device=dev, generator=gen)
+        j = torch.randint(0, n_i, (b,), device=dev, generator=gen)
+        with torch.no_grad():
+            t_b = timeit(lambda: Fn.bpr_sums(ut, it, u, i, j, Fn.BPR_NCL), 10)
+        out[f"bpr_triples_per_s_{name}"] = b / t_b
+    rowptr_u = graph.rowptr[: n_u + 1].contiguous()
+    items_u = (graph.col[: int(rowptr_u[-1])] - n_u).contiguous()
+    ub = torch.randint(0, n_u, (1 << 20,), device=dev, generator=gen)
+    t_s = timeit(lambda: Fn.neg_sample(rowptr_u, items_u, ub, 1, n_i, 7, 0, 101), 10)
+    out["neg_samples_per_s"] = ub.numel() / t_s
     return out
 
 

@@ -1,0 +1,176 @@
+"""Row-sharded LightGCN propagation over the GPUs of one node (one process per GPU, RCCL/xGMI).
+
+The reference is single-process (no collective anywhere); this is the multi-GPU
+form of ncl.py:415-422 / lightgcn.py:21-27 required by BASELINE.json.  Partition:
+
+  * USERS are split into `world` contiguous blocks; rank g owns the embedding rows of its users,
+    the CSR block R_g = A[users_g, items] and its transpose R_g^T = A[items, users_g];
+  * ITEM embeddings are owned in `world` equal shards but replicated for compute.
+
+Per layer (forward), with X_u local and X_i sharded:
+      all-gather   X_i (shards -> full)                 || item-side SpMM  P_i = R_g^T X_u   (local users only)
+      reduce-scatter P_i -> Y_i shard (sum over ranks)   || user-side SpMM  Y_u = R_g X_i
+so the 2.56 GB user table never crosses xGMI and both collectives hide behind the other half of the
+SpMM.  The operator is symmetric and linear, so the backward pass is the same schedule applied to
+the gradients (item gradients from the loss are reduce-scattered to their owner shard first).
+
+`spmm` is injectable so that the choreography can be exercised with gloo on CPU tensors by the
+tests (world_size 2); the default is the HIP kernel.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from . import functional as Fn
+from .graph import CsrGraph
+
+
+def _hip_spmm(graph, x, acc_in=None, acc_scale=1.0, want_y=True):
+    y = torch.empty(graph.n_rows, x.shape[1], dtype=torch.float32, device=x.device) if want_y else None
+    acc = torch.empty(graph.n_rows, x.shape[1], dtype=torch.float32, device=x.device) if acc_in is not None else None
+    Fn.spmm_into(graph, x, y=y, acc_in=acc_in, acc_out=acc, acc_scale=acc_scale)
+    return y, acc
+
+
+def shard_bounds(n, world):
+    """Contiguous, equal-size (padded) shards: returns (per_rank, padded_total)."""
+    per = (n + world - 1) // world
+    return per, per * world
+
+
+class ShardedBipartiteGraph:
+    """Rank-local blocks of the symmetric bipartite operator.
+
+    r_ui : CsrGraph [U_g, I_pad]   user rows of this rank -> all items
+    r_iu : CsrGraph [I_pad, U_g]   all items -> this rank's users (the transpose block)
+    Items are padded to a multiple of `world` (padding items have no edges) so that every owner
+    shard has `items_per_rank` rows.
+    """
+
+    def __init__(self, r_ui, r_iu, n_local_users, num_items, items_per_rank, rank, world, group=None):
+        self.r_ui, self.r_iu = r_ui, r_iu
+        self.n_local_users, self.num_items = n_local_users, num_items
+        self.items_per_rank, self.rank, self.world, self.group = items_per_rank, rank, world, group
+        self.items_padded = items_per_rank * world
+
+    @classmethod
+    def from_local_interactions(cls, local_uid, iid, n_local_users, num_items, user_deg, item_deg_global, rank, world,
+                                device, group=None, graph_cls=CsrGraph, **kw):
+        """local_uid in [0, U_g), iid in [0, num_items): this rank's interactions (unique pairs).
+        user_deg [U_g], item_deg_global [num_items]: degrees of the GLOBAL graph (the item degrees
+        need an all-reduce over ranks, done by the caller).  Values: d_u^-1/2 d_i^-1/2
+        (selfcf.py:240-249 on the global operator)."""
+        import numpy as np
+        local_uid = np.asarray(local_uid, dtype=np.int64)
+        iid = np.asarray(iid, dtype=np.int64)
+        per, padded = shard_bounds(num_items, world)
+        with np.errstate(divide="ignore"):
+            du = np.power(np.asarray(user_deg, dtype=np.float32), np.float32(-0.5))
+            di = np.power(np.asarray(item_deg_global, dtype=np.float32), np.float32(-0.5))
+        du[np.isinf(du)] = 0.0
+        di[np.isinf(di)] = 0.0
+        val = (du[local_uid] * di[iid]).astype(np.float32)
+        r_ui = graph_cls.from_coo(local_uid, iid, val, n_local_users, padded, device, coalesce=True, **kw)
+        r_iu = graph_cls.from_coo(iid, local_uid, val, padded, n_local_users, device, coalesce=True, **kw)
+        return cls(r_ui, r_iu, n_local_users, num_items, per, rank, world, group)
+
+
+def _all_gather(full, shard, group, async_op):
+    if dist.get_backend(group) == "gloo":
+        parts = list(full.chunk(dist.get_world_size(group)))
+        return dist.all_gather(parts, shard, group=group, async_op=async_op)
+    return dist.all_gather_into_tensor(full, shard, group=group, async_op=async_op)
+
+
+def _reduce_scatter(shard, full, group, async_op):
+    if dist.get_backend(group) == "gloo":  # gloo has no reduce_scatter: all-reduce + slice
+        dist.all_reduce(full, group=group)
+        w, r = dist.get_world_size(group), dist.get_rank(group)
+        shard.copy_(full.chunk(w)[r])
+        return None
+    return dist.reduce_scatter_tensor(shard, full, group=group, async_op=async_op)
+
+
+def sharded_propagate_raw(g: ShardedBipartiteGraph, x_user, x_item_shard, n_layers, scale, spmm=_hip_spmm,
+                          overlap=True):
+    """final_u [U_g, d], final_i_shard [I/world, d] = scale * sum_{k=0..K} (A^k x)  on the sharded
+    operator; no autograd.  `overlap` issues the collectives asynchronously so that they run
+    beside the other half of the SpMM."""
+    world = g.world
+    d = x_user.shape[1]
+    dev = x_user.device
+    acc_u, acc_i = x_user, x_item_shard.clone()
+    cur_u, cur_i = x_user, x_item_shard
+    x_item_full = torch.empty(g.items_padded, d, dtype=torch.float32, device=dev)
+    for k in range(n_layers):
+        last = k == n_layers - 1
+        if world > 1:
+            h_ag = _all_gather(x_item_full, cur_i.contiguous(), g.group, overlap)
+        else:
+            x_item_full = cur_i
+            h_ag = None
+        part_i, _ = spmm(g.r_iu, cur_u)                                   # item side: local users only
+        if h_ag is not None:
+            h_ag.wait()
+        y_i = torch.empty_like(cur_i)
+        if world > 1:
+            h_rs = _reduce_scatter(y_i, part_i, g.group, overlap)
+        else:
+            y_i, h_rs = part_i, None
+        y_u, acc_u = spmm(g.r_ui, x_item_full, acc_in=acc_u, acc_scale=scale if last else 1.0, want_y=not last)
+        if h_rs is not None:
+            h_rs.wait()
+        acc_i = acc_i + y_i
+        cur_u, cur_i = y_u, y_i
+    if n_layers == 0:
+        acc_u = x_user * scale
+    return acc_u, acc_i * scale
+
+
+class _ShardedPropagate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_user, x_item_shard, g, n_layers, scale, spmm, overlap):
+        ctx.g, ctx.n_layers, ctx.scale, ctx.spmm, ctx.overlap = g, n_layers, scale, spmm, overlap
+        return sharded_propagate_raw(g, x_user.contiguous(), x_item_shard.contiguous(), n_layers, scale, spmm, overlap)
+
+    @staticmethod
+    def backward(ctx, g_user, g_item_shard):
+        # symmetric linear operator: same schedule on the gradients
+        gu, gi = sharded_propagate_raw(ctx.g, g_user.contiguous(), g_item_shard.contiguous(), ctx.n_layers,
+                                       ctx.scale, ctx.spmm, ctx.overlap)
+        return gu, gi, None, None, None, None, None
+
+
+def sharded_lightgcn_propagate(g: ShardedBipartiteGraph, x_user, x_item_shard, n_layers, combine="mean",
+                               spmm=_hip_spmm, overlap=True):
+    """Differentiable sharded K-layer propagation; returns (user rows of this rank, item shard of
+    this rank).  Use `gather_items` to replicate the item side for the loss."""
+    scale = 1.0 / (n_layers + 1) if combine == "mean" else 1.0
+    return _ShardedPropagate.apply(x_user, x_item_shard, g, int(n_layers), scale, spmm, overlap)
+
+
+class _GatherItems(torch.autograd.Function):
+    """All-gather of the item shards; backward = reduce-scatter of the (partial) item gradients to
+    their owner shard — 'a reduce-scatter of embedding gradients after the loss'."""
+
+    @staticmethod
+    def forward(ctx, shard, group):
+        ctx.group = group
+        w = dist.get_world_size(group)
+        full = torch.empty(shard.shape[0] * w, shard.shape[1], dtype=shard.dtype, device=shard.device)
+        _all_gather(full, shard.contiguous(), group, False)
+        return full
+
+    @staticmethod
+    def backward(ctx, g_full):
+        out = torch.empty(g_full.shape[0] // dist.get_world_size(ctx.group), g_full.shape[1], dtype=g_full.dtype,
+                          device=g_full.device)
+        _reduce_scatter(out, g_full.contiguous().clone(), ctx.group, False)
+        return out, None
+
+
+def gather_items(item_shard, group=None):
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return item_shard
+    return _GatherItems.apply(item_shard, group)

@@ -1,0 +1,105 @@
+"""world_size-2 gloo test of the row-sharded propagation choreography (distributed.py) on CPU
+tensors: the per-rank SpMM is injected from the CPU oracle (tests may use the oracle; the
+product default is the HIP kernel), so what is checked here is the partition, the collectives
+and the autograd wiring:  N-rank result == 1-rank result on the same synthetic graph."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import oracle_np as O
+
+N_USERS, N_ITEMS, N_EDGES, D, K = 120, 53, 1500, 16, 3   # 53 items: not divisible by 2 -> padding path
+
+
+def oracle_spmm(graph, x, acc_in=None, acc_scale=1.0, want_y=True):
+    y = O.spmm_csr(graph.rowptr_host, graph.col.numpy(), graph.val.numpy(), x.detach().numpy())
+    y = torch.from_numpy(y.astype(np.float32))
+    acc = None if acc_in is None else (acc_in + y) * acc_scale
+    return (y if want_y else None), acc
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from recommendation_amd import distributed as gd
+        u, i = O.synthetic_interactions(N_USERS, N_ITEMS, N_EDGES, seed=1)
+        per_u = N_USERS // world
+        lo, hi = rank * per_u, (rank + 1) * per_u
+        sel = (u >= lo) & (u < hi)
+        deg_u = np.bincount(u, minlength=N_USERS)[lo:hi]
+        deg_i_local = torch.from_numpy(np.bincount(i[sel], minlength=N_ITEMS))
+        dist.all_reduce(deg_i_local)                       # global item degrees, as the bench does
+        g = gd.ShardedBipartiteGraph.from_local_interactions(u[sel] - lo, i[sel], per_u, N_ITEMS, deg_u,
+                                                             deg_i_local.numpy(), rank, world, "cpu", validate=False)
+        rng = np.random.default_rng(0)
+        x_all = rng.standard_normal((N_USERS + g.items_padded, D)).astype(np.float32)
+        x_all[N_USERS + N_ITEMS:] = 0                     # padding items
+        w_all = rng.standard_normal((N_USERS + g.items_padded, D)).astype(np.float32)
+        ipr = g.items_per_rank
+        xu = torch.from_numpy(x_all[lo:hi]).requires_grad_(True)
+        xi = torch.from_numpy(x_all[N_USERS + rank * ipr: N_USERS + (rank + 1) * ipr]).requires_grad_(True)
+        fu, fi = gd.sharded_lightgcn_propagate(g, xu, xi, K, combine="mean", spmm=oracle_spmm, overlap=True)
+        items_full = gd.gather_items(fi)                   # replicate for the loss; backward = reduce-scatter
+        wu = torch.from_numpy(w_all[lo:hi])
+        wi = torch.from_numpy(w_all[N_USERS:])
+        # every rank holds the full item table, so weight the item term by 1/world to make the
+        # summed per-rank losses equal the single-process loss
+        loss = (fu * wu).sum() + (items_full * wi).sum() / world
+        loss.backward()
+        out[rank] = dict(fu=fu.detach().numpy(), fi=fi.detach().numpy(), gu=xu.grad.numpy(), gi=xi.grad.numpy(),
+                         lo=lo, hi=hi, ipr=ipr, pad=g.items_padded)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2])
+def test_sharded_propagation_equals_single_process(world):
+    from recommendation_amd import _build, _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _build.build()
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, world, port, out)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(180)
+            assert p.exitcode == 0
+        res = {r: out[r] for r in range(world)}
+    pad = res[0]["pad"]
+    u, i = O.synthetic_interactions(N_USERS, N_ITEMS, N_EDGES, seed=1)
+    rowptr, col, val = O.norm_adj_csr(u, i, N_USERS, pad)          # global operator incl. padding items
+    rng = np.random.default_rng(0)
+    x_all = rng.standard_normal((N_USERS + pad, D)).astype(np.float32)
+    x_all[N_USERS + N_ITEMS:] = 0
+    w_all = rng.standard_normal((N_USERS + pad, D)).astype(np.float32)
+    ref, _ = O.lgcn_encoder_forward(rowptr, col, val, x_all, K, combine="mean")
+    gacc, g = w_all.astype(np.float64), w_all.astype(np.float64)
+    for _ in range(K):
+        g = O.spmm_backward(rowptr, col, val, g, N_USERS + pad)
+        gacc = gacc + g
+    gref = gacc / (K + 1)
+    tol = dict(rtol=2e-5, atol=2e-5 * np.abs(ref).max())
+    for r in range(world):
+        lo, hi, ipr = res[r]["lo"], res[r]["hi"], res[r]["ipr"]
+        np.testing.assert_allclose(res[r]["fu"], ref[lo:hi], **tol)
+        np.testing.assert_allclose(res[r]["fi"], ref[N_USERS + r * ipr: N_USERS + (r + 1) * ipr], **tol)
+        gt = dict(rtol=2e-5, atol=2e-5 * np.abs(gref).max())
+        np.testing.assert_allclose(res[r]["gu"], gref[lo:hi], **gt)
+        np.testing.assert_allclose(res[r]["gi"], gref[N_USERS + r * ipr: N_USERS + (r + 1) * ipr], **gt)

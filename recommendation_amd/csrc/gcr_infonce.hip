@@ -19,6 +19,8 @@
 // a column range of the table; table tiles of 32 rows are staged global -> registers -> LDS
 // (normalised on the way) one tile ahead of the MFMAs (double buffer, one barrier per tile).
 // Grid = anchor blocks x column splits; split partials (max, sum) are merged by a second kernel.
+#include <stdlib.h>
+
 #include "gcr_common.h"
 
 namespace {
@@ -42,6 +44,8 @@ struct Shape {
 // C/D layout of the 32x32 accumulator: register r of lane (col = lane&31, h = lane>>5) is row
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+// Branch-free staging load (keeps the tile loop one scheduling region): rows past the table are
+// clamped to the last row and multiplied by 0.
 template <int D>
 __device__ __forceinline__ void stage_load(const float* __restrict__ b, const float* __restrict__ b_scale,
                                            int64_t n_rows, int64_t j0, int tid, float4 (&regs)[Shape<D>::NLD]) {
@@ -50,14 +54,11 @@ __device__ __forceinline__ void stage_load(const float* __restrict__ b, const fl
     const int idx = tid + 256 * u;
     const int row = idx / (D / 4), c4 = idx % (D / 4);
     const int64_t j = j0 + row;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (j < n_rows) {
-      v = *reinterpret_cast<const float4*>(b + j * D + 4 * c4);
-      if (b_scale != nullptr) {
-        const float s = b_scale[j];
-        v.x *= s; v.y *= s; v.z *= s; v.w *= s;
-      }
-    }
+    const int64_t jj = j < n_rows ? j : n_rows - 1;
+    float4 v = *reinterpret_cast<const float4*>(b + jj * D + 4 * c4);
+    float s = b_scale != nullptr ? b_scale[jj] : 1.0f;
+    s = j < n_rows ? s : 0.f;
+    v.x *= s; v.y *= s; v.z *= s; v.w *= s;
     regs[u] = v;
   }
 }
@@ -112,8 +113,38 @@ __device__ __forceinline__ void score_tile(const float* __restrict__ tile, int i
   }
 }
 
+// online-softmax update with one finished score tile; `rem` = table rows left from this lane's
+// first accumulator row (n_rows - j0 - 4h): rows at or past it are masked out (ragged last tile).
+template <int NT>
+__device__ __forceinline__ void lse_update(const f32x16 (&acc)[NT], int rem, float (&m_run)[NT], float (&l_run)[NT]) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = ((r & 3) + 8 * (r >> 2) < rem) ? acc[t][r] : -INFINITY;
+    float tmax = v[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, v[r]);
+    const float m_new = fmaxf(m_run[t], tmax);
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sum += __builtin_amdgcn_exp2f(v[r] - m_new);
+    l_run[t] = l_run[t] * __builtin_amdgcn_exp2f(m_run[t] - m_new) + sum;
+    m_run[t] = m_new;
+  }
+}
+
+__device__ __forceinline__ int rows_left(int64_t n_rows, int64_t j0, int h) {
+  const int64_t rem = n_rows - j0 - 4 * h;
+  return (int)(rem > 64 ? 64 : (rem < 0 ? 0 : rem));
+}
+
+// d <= 64 runs 3 blocks per CU: two symmetric waves on one SIMD fall into lock-step (their MFMA
+// phases and exp2 phases coincide, scripts/exp_infonce.hip), a third wave breaks it (109 -> 126 TF
+// on the bare tile loop); needs VGPRs <= 168.  (Folding a logit bound into the MFMA C operand to
+// drop the running max was tried: not faster, and it costs ~1e-5 of the lse - pos difference.)
 template <int D>
-__global__ __launch_bounds__(256, 2) void infonce_fwd_kernel(const float* __restrict__ a,
+__global__ __launch_bounds__(256, (D <= 64 ? 3 : 2)) void infonce_fwd_kernel(const float* __restrict__ a,
                                                              const float* __restrict__ a_scale, int64_t m_rows,
                                                              const float* __restrict__ b,
                                                              const float* __restrict__ b_scale, int64_t n_rows,
@@ -149,33 +180,13 @@ __global__ __launch_bounds__(256, 2) void infonce_fwd_kernel(const float* __rest
   __syncthreads();
   for (int64_t tt = tile0; tt < tile1; ++tt) {
     const int cur = (int)((tt - tile0) & 1);
-    const bool more = tt + 1 < tile1;
-    if (more) stage_load<D>(b, b_scale, n_rows, (tt + 1) * kTileJ, tid, regs);
-
+    // always stage a tile (the last iteration re-stages its own): keeps the loop body branch-free
+    const int64_t nxt = tt + 1 < tile1 ? tt + 1 : tt;
+    stage_load<D>(b, b_scale, n_rows, nxt * kTileJ, tid, regs);
     f32x16 acc[S::NT];
     score_tile<D>(lds[cur], i32, h, bfrag, acc);
-    const int64_t j0 = tt * kTileJ;
-    if (j0 + kTileJ > n_rows) {  // ragged last tile: rows past the table never contribute
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if (j0 + acc_row(r, h) >= n_rows) {
-#pragma unroll
-          for (int t = 0; t < S::NT; ++t) acc[t][r] = -INFINITY;
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < S::NT; ++t) {
-      float tmax = acc[t][0];
-#pragma unroll
-      for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, acc[t][r]);
-      const float m_new = fmaxf(m_run[t], tmax);
-      float sum = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sum += __builtin_amdgcn_exp2f(acc[t][r] - m_new);
-      l_run[t] = l_run[t] * __builtin_amdgcn_exp2f(m_run[t] - m_new) + sum;
-      m_run[t] = m_new;
-    }
-    if (more) stage_store<D>(lds[cur ^ 1], tid, regs);
+    lse_update<S::NT>(acc, rows_left(n_rows, tt * kTileJ, h), m_run, l_run);
+    stage_store<D>(lds[cur ^ 1], tid, regs);
     __syncthreads();
   }
 
@@ -272,7 +283,12 @@ FwdPlan plan_fwd(int64_t m, int64_t n, int anchors_per_block) {
   FwdPlan p;
   p.m_blocks = (m + anchors_per_block - 1) / anchors_per_block;
   const int64_t total_tiles = (n + kTileJ - 1) / kTileJ;
-  int64_t want = (512 + p.m_blocks - 1) / p.m_blocks;  // ~2 blocks per CU over 256 CUs
+  static const int64_t target_blocks = [] {
+    const char* e = getenv("GCR_INFONCE_BLOCKS");  // tuning knob; default 3 blocks per CU over 256 CUs
+    const int64_t v = e ? atoll(e) : 0;
+    return v > 0 ? v : 768;
+  }();
+  int64_t want = (target_blocks + p.m_blocks - 1) / p.m_blocks;
   if (want > total_tiles) want = total_tiles;
   if (want < 1) want = 1;
   p.tiles_per_split = (total_tiles + want - 1) / want;

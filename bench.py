@@ -126,8 +126,9 @@ def main():
     n = n_u + n_i
     t_build = time.time()
     users, items = synth_interactions_device(n_u, n_i, n_e, SEED, dev)
-    rowptr, col, val = sym_norm_csr_device(users, items, n_u, n_i)
-    graph = ra.CsrGraph(rowptr, col, val, n, n, dev, symmetric=True)
+    # graph ingest through the library: gcr_coo_to_csr (radix sort + merge) + gcr_csr_sym_norm_f32
+    graph = ra.CsrGraph.bipartite_sym_norm(users, items, n_u, n_i, dev)
+    del users, items
     nnz = graph.nnz
     x0 = torch.empty(n, d, device=dev)
     torch.nn.init.xavier_uniform_(x0, generator=torch.Generator(device=dev).manual_seed(0))

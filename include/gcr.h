@@ -200,6 +200,46 @@ int32_t gcr_infonce_pos_bwd_f32(const float* x, const float* x_scale, const floa
 int32_t gcr_normalize_bwd_f32(const float* x, const float* inv_norm, const float* ghat, int64_t n, int32_t d,
                               float* out, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Graph ingest on the device (integer work, bit-exact with the reference's host construction).
+ * --------------------------------------------------------------------------------------------- */
+int64_t gcr_coo_to_csr_workspace_bytes(int64_t nnz);
+
+/*
+ * COO (row, col int64 [nnz], val fp32 or NULL = ones) -> CSR.
+ *   coalesce == 0: stable sort by row, COO order kept inside a row, duplicates kept — the layout
+ *     torch.sparse.mm sees for the uncoalesced COO of ncl.py:74-85,203-209; perm_out (optional)
+ *     receives the source position of every output non-zero;
+ *   coalesce != 0: sorted by (row, col) with duplicate pairs summed — scipy's `tmp + tmp.T`
+ *     selfcf.py:297, `.coalesce()` sept.py:50.
+ * Outputs are sized for nnz entries; *nnz_out (device) is the number actually produced.  Entries
+ * with a row/col outside the matrix are dropped and counted in *n_errors (device).
+ */
+int32_t gcr_coo_to_csr(const int64_t* row, const int64_t* col, const float* val, int64_t nnz,
+                       int64_t n_rows, int64_t n_cols, int32_t coalesce,
+                       int64_t* rowptr, int32_t* col_out, float* val_out, int64_t* perm_out,
+                       int64_t* nnz_out, int64_t* n_errors, void* workspace, void* stream);
+
+/*
+ * val_out[e] = dinv_row[row(e)] * val[e] * dinv_col[col[e]],  dinv = (row sum)^-1/2 with inf -> 0.
+ * Square symmetric operator (rowptr_t == NULL): Graph.normalize_graph_mat selfcf.py:240-249,
+ * ssl4rec.py:85-88; with val == NULL on a dst-major CSR it is gcn_norm(add_self_loops=False) of
+ * lightgcn.py's LGConv (in-degree counts).  Rectangular: pass the transposed CSR's rowptr_t / val_t
+ * for the column sums.  dinv_row [n_rows] / dinv_col [n_cols] are caller-provided scratch.
+ */
+int32_t gcr_csr_sym_norm_f32(const int64_t* rowptr, const int32_t* col, const float* val,
+                             int64_t n_rows, int64_t n_cols, const int64_t* rowptr_t, const float* val_t,
+                             float* dinv_row, float* dinv_col, float* val_out, void* stream);
+
+/*
+ * Keep bitmap with EXACTLY n_keep of nnz bits set, a uniformly random subset without replacement
+ * (64-bit Philox key per edge, stable radix sort, first n_keep win):
+ * GraphAugmentor.edge_dropout univariate/sept.py:55-61 with n_keep = int(nnz * (1 - drop_rate)).
+ */
+int64_t gcr_edge_mask_exact_workspace_bytes(int64_t nnz);
+int32_t gcr_edge_mask_exact_bits(int64_t nnz, int64_t n_keep, uint64_t seed, uint32_t* bits,
+                                 void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -407,3 +407,14 @@ def infonce_stats(a, b, pos=None, temperature=0.2, normalize=True, want_col=Fals
         if pos.shape != (a.shape[0],):
             raise ValueError("pos must be [M]")
     return _InfoNCEStats.apply(a, b, pos, 1.0 / float(temperature), bool(normalize), bool(want_col))
+
+
+def edge_mask_exact_bits(nnz, n_keep, seed, device):
+    """Keep bitmap with exactly n_keep of nnz bits set, a uniformly random subset without replacement
+    (univariate/sept.py:55-61: `np.random.choice(idx, int(len(idx) * (1 - drop_rate)), replace=False)`)."""
+    L = _lib.lib()
+    bits = torch.empty((nnz + 31) // 32, dtype=torch.int32, device=device)
+    ws = torch.empty(int(L.gcr_edge_mask_exact_workspace_bytes(nnz)), dtype=torch.uint8, device=device)
+    _lib.check(L.gcr_edge_mask_exact_bits(int(nnz), int(n_keep), int(seed) & (2 ** 64 - 1), _lib.dptr(bits),
+                                          _lib.dptr(ws), _lib.cur_stream(device)), "gcr_edge_mask_exact_bits")
+    return bits

@@ -100,6 +100,14 @@ class CsrGraph:
     @property
     def t(self) -> "CsrGraph":
         """Transposed operator (for the backward pass dX = A^T dY); `self` when symmetric."""
+        if self._t is None and self.device.type == "cuda":
+            rows = torch.repeat_interleave(torch.arange(self.n_rows, device=self.device),
+                                           self.rowptr[1:] - self.rowptr[:-1])
+            rp, c, v, perm = coo_to_csr_device(self.col.to(torch.int64), rows, self.val, self.n_cols, self.n_rows,
+                                               self.device, want_perm=True)
+            self._t = CsrGraph(rp, c, v, self.n_cols, self.n_rows, self.device, symmetric=False,
+                               nnz_per_part=self.plan.nnz_per_part, validate=False, transpose=self)
+            self._t.perm_from_transpose = perm     # non-zero e of A^T is non-zero perm[e] of A (shared edge masks)
         if self._t is None:
             col_host = self.col.cpu().numpy().astype(np.int64)
             rows = np.repeat(np.arange(self.n_rows, dtype=np.int64), np.diff(self.rowptr_host))
@@ -114,7 +122,12 @@ class CsrGraph:
     def from_coo(cls, row, col, val, n_rows, n_cols, device, coalesce=False, symmetric=False, **kw):
         """Stable sort by row (COO order kept inside a row, duplicates kept — torch.sparse.mm on the
         uncoalesced COO of ncl.py:203-209 sums them), or (row, col)-sorted with duplicates summed
-        when `coalesce` (scipy `tmp + tmp.T`, selfcf.py:297; `.coalesce()`, sept.py:50)."""
+        when `coalesce` (scipy `tmp + tmp.T`, selfcf.py:297; `.coalesce()`, sept.py:50).
+        On a GPU device the sort / merge runs in gcr_coo_to_csr; the numpy path only serves
+        CPU-resident graphs (host logic, gloo tests)."""
+        if torch.device(device).type == "cuda":
+            rp, c, v, _ = coo_to_csr_device(row, col, val, n_rows, n_cols, device, coalesce=coalesce)
+            return cls(rp, c, v, n_rows, n_cols, device, symmetric=symmetric, **kw)
         row, col = _np_i64(row), _np_i64(col)
         if val is not None and isinstance(val, torch.Tensor):
             val = val.detach().cpu().numpy()
@@ -127,8 +140,13 @@ class CsrGraph:
     @classmethod
     def bipartite_raw(cls, uid, iid, num_users, num_items, device, **kw):
         """ncl.py:74-85: rows/cols [(u, i+U), (i+U, u)] per interaction, value 1, duplicates kept (Q1)."""
-        uid, iid = _np_i64(uid), _np_i64(iid) + num_users
         n = num_users + num_items
+        if torch.device(device).type == "cuda":
+            u, i = _dev_i64(uid, device), _dev_i64(iid, device) + num_users
+            row = torch.stack([u, i], 1).reshape(-1)      # (u, i+U) then (i+U, u) per interaction
+            col = torch.stack([i, u], 1).reshape(-1)
+            return cls.from_coo(row, col, None, n, n, device, symmetric=True, **kw)
+        uid, iid = _np_i64(uid), _np_i64(iid) + num_users
         row = np.empty(2 * uid.size, dtype=np.int64)
         col = np.empty_like(row)
         row[0::2], row[1::2] = uid, iid
@@ -139,8 +157,12 @@ class CsrGraph:
     def bipartite_sym_norm(cls, uid, iid, num_users, num_items, device, **kw):
         """selfcf.py:291-306 + 240-255 (ssl4rec.py:79-88): A = R~ + R~^T with duplicate interactions
         summed, then D^-1/2 A D^-1/2 with 1/sqrt(0) -> 0, float32."""
-        uid, iid = _np_i64(uid), _np_i64(iid) + num_users
         n = num_users + num_items
+        if torch.device(device).type == "cuda":
+            u, i = _dev_i64(uid, device), _dev_i64(iid, device) + num_users
+            rp, c, v, _ = coo_to_csr_device(torch.cat([u, i]), torch.cat([i, u]), None, n, n, device, coalesce=True)
+            return cls(rp, c, sym_norm_device(rp, c, v, n), n, n, device, symmetric=True, **kw)
+        uid, iid = _np_i64(uid), _np_i64(iid) + num_users
         rp, c, v = _coalesce_host(np.concatenate([uid, iid]), np.concatenate([iid, uid]), None, n, n)
         rows = np.repeat(np.arange(n), np.diff(rp))
         rowsum = np.zeros(n, dtype=np.float32)
@@ -154,6 +176,11 @@ class CsrGraph:
     def from_edge_index_gcn_norm(cls, edge_index, num_nodes, device, symmetric=False, **kw):
         """lightgcn.py:25 `LGConv()(x, edge_index)`: deg[v] = #edges with target v; w_e =
         deg^-1/2[src] deg^-1/2[dst] (inf -> 0); out[dst] += w_e x[src]  => CSR over rows = dst."""
+        if torch.device(device).type == "cuda":
+            ei = _dev_i64(edge_index, device)
+            rp, c, _, _ = coo_to_csr_device(ei[1].contiguous(), ei[0].contiguous(), None, num_nodes, num_nodes, device)
+            return cls(rp, c, sym_norm_device(rp, c, None, num_nodes), num_nodes, num_nodes, device,
+                       symmetric=symmetric, **kw)
         ei = _np_i64(edge_index)
         src, dst = ei[0], ei[1]
         deg = np.bincount(dst, minlength=num_nodes).astype(np.float32)
@@ -162,6 +189,50 @@ class CsrGraph:
         dis[np.isinf(dis)] = 0.0
         return cls.from_coo(dst, src, (dis[src] * dis[dst]).astype(np.float32), num_nodes, num_nodes, device,
                             symmetric=symmetric, **kw)
+
+
+def _dev_i64(a, device):
+    if isinstance(a, np.ndarray):
+        a = torch.from_numpy(np.ascontiguousarray(a))
+    return torch.as_tensor(a).to(device=device, dtype=torch.int64).contiguous()
+
+
+def coo_to_csr_device(row, col, val, n_rows, n_cols, device, coalesce=False, want_perm=False):
+    """gcr_coo_to_csr: returns (rowptr int64 [n_rows+1], col int32 [nnz'], val fp32 [nnz'] or None,
+    perm int64 [nnz'] or None) as device tensors.  Raises on ids outside the matrix."""
+    L = _lib.lib()
+    row, col = _dev_i64(row, device), _dev_i64(col, device)
+    nnz = row.numel()
+    if col.numel() != nnz:
+        raise ValueError("row / col length mismatch")
+    if val is not None:
+        val = torch.as_tensor(val).to(device=device, dtype=torch.float32).contiguous()
+    rowptr = torch.empty(n_rows + 1, dtype=torch.int64, device=device)
+    col_out = torch.empty(max(nnz, 1), dtype=torch.int32, device=device)
+    keep_val = val is not None or coalesce
+    val_out = torch.empty(max(nnz, 1), dtype=torch.float32, device=device) if keep_val else None
+    perm = torch.empty(max(nnz, 1), dtype=torch.int64, device=device) if (want_perm and not coalesce) else None
+    meta = torch.zeros(2, dtype=torch.int64, device=device)
+    ws = torch.empty(int(L.gcr_coo_to_csr_workspace_bytes(nnz)), dtype=torch.uint8, device=device)
+    _lib.check(L.gcr_coo_to_csr(_lib.dptr(row), _lib.dptr(col), _lib.dptr(val), nnz, n_rows, n_cols, int(coalesce),
+                                _lib.dptr(rowptr), _lib.dptr(col_out), _lib.dptr(val_out), _lib.dptr(perm),
+                                _lib.dptr(meta[0:1]), _lib.dptr(meta[1:2]), _lib.dptr(ws), _lib.cur_stream(device)),
+               "gcr_coo_to_csr")
+    n_out, n_err = (int(v) for v in meta.tolist())
+    if n_err:
+        raise ValueError(f"{n_err} COO entries have a row / column outside [{n_rows}, {n_cols}]")
+    return (rowptr, col_out[:n_out].contiguous(), None if val_out is None else val_out[:n_out].contiguous(),
+            None if perm is None else perm[:n_out].contiguous())
+
+
+def sym_norm_device(rowptr, col, val, n):
+    """gcr_csr_sym_norm_f32 on a square symmetric operator: D^-1/2 A D^-1/2 (val None = ones)."""
+    dinv = torch.empty(n, dtype=torch.float32, device=rowptr.device)
+    out = torch.empty(col.numel(), dtype=torch.float32, device=rowptr.device)
+    _lib.check(_lib.lib().gcr_csr_sym_norm_f32(_lib.dptr(rowptr), _lib.dptr(col), _lib.dptr(val), n, n, None, None,
+                                               _lib.dptr(dinv), None, _lib.dptr(out), _lib.cur_stream(rowptr.device)),
+               "gcr_csr_sym_norm_f32")
+    return out
 
 
 def _coo_to_csr_host(row, col, val, n_rows):

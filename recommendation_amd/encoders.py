@@ -29,11 +29,17 @@ class Interaction:
     the raw 0/1 adjacency with duplicates kept, exactly what the reference calls norm_adj, Q1) and
     the sorted per-user training rows the device sampler rejects against."""
 
-    def __init__(self, conf, train, test, device=None, normalised=False):
+    def __init__(self, conf, train, test, device=None, normalised=False, id_order="sorted"):
         self.train, self.test = train, test
         self.device = _device(device)
-        users = sorted({t[0] for t in train})
-        items = sorted({t[1] for t in train})
+        if id_order == "sorted":          # ncl.py:60-61, directau.py:116-117, sept.py:122-123
+            users = sorted({t[0] for t in train})
+            items = sorted({t[1] for t in train})
+        elif id_order == "first_seen":    # selfcf.py:279-288, ssl4rec.py:69-75 (dict insertion order)
+            users = list(dict.fromkeys(t[0] for t in train))
+            items = list(dict.fromkeys(t[1] for t in train))
+        else:
+            raise ValueError("id_order must be 'sorted' or 'first_seen'")
         self.user = {u: k for k, u in enumerate(users)}
         self.item = {i: k for k, i in enumerate(items)}
         self.id2user = {k: u for u, k in self.user.items()}
@@ -132,3 +138,47 @@ def sept_encoder(emb, adj: CsrGraph, n_layers: int):
         e = Fn.spmm_l2norm(adj, e)
         all_embs.append(e)
     return torch.stack(all_embs, dim=0).mean(0)
+
+
+def load_data(train_path, test_path, device=None):
+    """lightgcn.py:30-40 / gcl.py:67-78: space-separated `user item rating` lines with integer ids;
+    num_users / num_items = max id over train and test + 1; edge_index = [[u; i+U], [i+U; u]] int64
+    [2, 2E].  Returns (edge_index, train (users, items), test (users, items), num_users, num_items);
+    the reference returns pandas frames where this returns int64 arrays."""
+    def read(path):
+        rows = np.loadtxt(path, dtype=np.float64, ndmin=2)
+        return rows[:, 0].astype(np.int64), rows[:, 1].astype(np.int64)
+
+    tu, ti = read(train_path)
+    su, si = read(test_path)
+    num_users = int(max(tu.max(), su.max())) + 1
+    num_items = int(max(ti.max(), si.max())) + 1
+    u = torch.from_numpy(tu)
+    i = torch.from_numpy(ti) + num_users
+    edge_index = torch.stack([torch.cat([u, i]), torch.cat([i, u])]).to(_device(device))
+    return edge_index, (tu, ti), (su, si), num_users, num_items
+
+
+def multi_stream_spmm(graphs, xs, streams=None, l2norm=False):
+    """BASELINE config 5 (univariate/mhcn.py:440-456): the per-layer SpMMs over independent operators
+    (H_s, H_j, H_p, R^T, R) launched on separate HIP streams so that they fill the chip together and
+    can hide each other's tails / a concurrent all-gather.  Returns the outputs in order; the caller's
+    current stream waits for all of them (event join).  Autograd-aware (each op is `spmm` /
+    `spmm_l2norm`)."""
+    cur = torch.cuda.current_stream()
+    if streams is None:
+        streams = [torch.cuda.Stream() for _ in graphs]
+    start = torch.cuda.Event()
+    start.record(cur)
+    outs = []
+    for g, x, s in zip(graphs, xs, streams):
+        s.wait_event(start)
+        with torch.cuda.stream(s):
+            outs.append(Fn.spmm_l2norm(g, x) if l2norm else Fn.spmm(g, x))
+            x.record_stream(s)
+    for s, o in zip(streams, outs):
+        done = torch.cuda.Event()
+        done.record(s)
+        cur.wait_event(done)
+        o.record_stream(cur)
+    return outs

@@ -173,3 +173,45 @@ def test_full_ncl_training_step_against_dense_cpu(golden):
     for got, ref in ((enc.embedding_dict["user_emb"].grad, uw.grad), (enc.embedding_dict["item_emb"].grad, iw.grad)):
         ref = ref.numpy()
         np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-4, atol=2e-5 * np.abs(ref).max())
+
+
+def test_first_seen_ids_and_load_data(golden, tmp_path):
+    from recommendation_amd.encoders import Interaction, load_data
+    train, g = _triples(golden)
+    data = Interaction({}, train, [], device="cuda", normalised=True, id_order="first_seen")   # selfcf.py:258-306
+    assert [data.id2user[k] for k in range(data.user_num)] == g["seen_user_ids"].tolist()
+    assert [data.id2item[k] for k in range(data.item_num)] == g["seen_item_ids"].tolist()
+    assert np.array_equal(data.norm_adj.rowptr.cpu().numpy(), g["norm_indptr"])
+    np.testing.assert_allclose(data.norm_adj.val.cpu().numpy(), g["norm_data"], rtol=3e-7)
+    tr, te = tmp_path / "train.txt", tmp_path / "test.txt"
+    tr.write_text("".join(f"{a} {b} 1\n" for a, b in zip(g["gcl_user"], g["gcl_item"])))
+    te.write_text("".join(f"{a} {b} 1\n" for a, b in zip(g["gcl_test_user"], g["gcl_test_item"])))
+    ei, _, _, nu, ni = load_data(str(tr), str(te), device="cuda")
+    assert (nu, ni) == (int(g["gcl_num_users"]), int(g["gcl_num_items"]))
+    assert np.array_equal(ei.cpu().numpy(), g["gcl_edge_index"])          # gcl.load_data's own output
+
+
+def test_multi_stream_spmm_mhcn_pattern():
+    """config 5: three U x U channel operators + R^T / R launched on separate streams (mhcn.py:440-456)
+    give the same results as serial launches, forward and backward."""
+    import recommendation_amd as ra
+    from recommendation_amd.encoders import multi_stream_spmm
+    rng = np.random.default_rng(0)
+    n_u, n_i, d = 3000, 800, 64
+    graphs, xs, refs = [], [], []
+    for k, (nr, nc, nnz) in enumerate([(n_u, n_u, 40000), (n_u, n_u, 25000), (n_u, n_u, 60000), (n_i, n_u, 30000), (n_u, n_i, 30000)]):
+        row, col = rng.integers(0, nr, nnz), rng.integers(0, nc, nnz)
+        val = rng.random(nnz).astype(np.float32)
+        graphs.append(ra.CsrGraph.from_coo(row, col, val, nr, nc, "cuda"))
+        x = rng.standard_normal((nc, d)).astype(np.float32)
+        xs.append(torch.from_numpy(x).cuda().requires_grad_(True))
+        rp, c, v, _ = O.coo_to_csr_stable(row, col, val, nr)
+        refs.append(O.row_l2_normalize(O.spmm_csr(rp, c, v, x)))
+    outs = multi_stream_spmm(graphs, xs, l2norm=True)
+    for o, r in zip(outs, refs):
+        np.testing.assert_allclose(o.detach().cpu().numpy(), r, rtol=1e-5, atol=1e-5)
+    sum(o.sum() for o in outs).backward()
+    serial = [ra.functional.spmm_l2norm(g, x.detach().clone().requires_grad_(True)) for g, x in zip(graphs, xs)]
+    for o, s in zip(outs, serial):
+        assert torch.equal(o, s)
+    assert all(x.grad is not None and torch.isfinite(x.grad).all() for x in xs)

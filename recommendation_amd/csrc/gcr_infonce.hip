@@ -279,20 +279,33 @@ struct FwdPlan {
   int64_t m_blocks;
 };
 
-FwdPlan plan_fwd(int64_t m, int64_t n, int anchors_per_block) {
+// Column split.  `resident` = blocks the chip holds at once (256 CUs x blocks/CU of the kernel).
+//  * few row blocks: ONE wave of blocks, nsplit = floor(resident / m_blocks): a grid slightly larger
+//    than the resident set (784 vs 768) costs a whole extra round (2.15 -> 3.0 ms measured);
+//  * many row blocks: several rounds are unavoidable, so make them short: <= 320 tiles per block and
+//    >= 3 rounds (100K x 100K: 95 TF at 782 blocks, 119 TF at 3128; scripts/perf_infonce_ab.py);
+//  * never fewer than 16 tiles per block (anchor prologue + partial merge dominate below that).
+// GCR_INFONCE_BLOCKS overrides the block target; read per call so A/B rounds interleave in-process.
+FwdPlan plan_fwd(int64_t m, int64_t n, int anchors_per_block, int64_t resident) {
   FwdPlan p;
   p.m_blocks = (m + anchors_per_block - 1) / anchors_per_block;
   const int64_t total_tiles = (n + kTileJ - 1) / kTileJ;
-  static const int64_t target_blocks = [] {
-    const char* e = getenv("GCR_INFONCE_BLOCKS");  // tuning knob; default 3 blocks per CU over 256 CUs
-    const int64_t v = e ? atoll(e) : 0;
-    return v > 0 ? v : 768;
-  }();
-  int64_t want = (target_blocks + p.m_blocks - 1) / p.m_blocks;
-  if (want > total_tiles) want = total_tiles;
-  if (want < 1) want = 1;
-  p.tiles_per_split = (total_tiles + want - 1) / want;
-  if (p.tiles_per_split < 1) p.tiles_per_split = 1;
+  const char* env_blocks = getenv("GCR_INFONCE_BLOCKS");
+  const int64_t env_v = env_blocks ? atoll(env_blocks) : 0;
+  int64_t nsplit;
+  if (env_v > 0) {
+    nsplit = (env_v + p.m_blocks - 1) / p.m_blocks;
+  } else if (p.m_blocks * 2 <= resident) {
+    nsplit = resident / p.m_blocks;
+  } else {
+    nsplit = (total_tiles + 319) / 320;
+    if (p.m_blocks * nsplit < 3 * resident) nsplit = (3 * resident + p.m_blocks - 1) / p.m_blocks;
+  }
+  const int64_t max_split = total_tiles / 16 > 0 ? total_tiles / 16 : 1;
+  if (env_v <= 0 && nsplit > max_split) nsplit = max_split;
+  if (nsplit > total_tiles) nsplit = total_tiles;
+  if (nsplit < 1) nsplit = 1;
+  p.tiles_per_split = (total_tiles + nsplit - 1) / nsplit;
   p.nsplit = (int)((total_tiles + p.tiles_per_split - 1) / p.tiles_per_split);
   if (p.nsplit < 1) p.nsplit = 1;
   return p;
@@ -508,7 +521,17 @@ __global__ __launch_bounds__(256) void normalize_bwd_kernel(const float* __restr
 }
 
 template <int D>
-FwdPlan plan_bwd(int64_t mx, int64_t ny) { return plan_fwd(mx, ny, BwdShape<D>::ROWS_PER_BLOCK); }
+FwdPlan plan_bwd(int64_t mx, int64_t ny) {
+  FwdPlan p = plan_fwd(mx, ny, BwdShape<D>::ROWS_PER_BLOCK, 512);
+  // every split keeps an [mx, D] fp32 partial: with many stationary rows the row blocks alone fill
+  // the chip, and the partials must stay small (cap 1 GiB)
+  const int64_t total_tiles = (ny + kTileJ - 1) / kTileJ;
+  while (p.nsplit > 1 && (p.m_blocks >= 1536 || (int64_t)p.nsplit * mx * D * 4 > (1ll << 30))) {
+    p.tiles_per_split *= 2;
+    p.nsplit = (int)((total_tiles + p.tiles_per_split - 1) / p.tiles_per_split);
+  }
+  return p;
+}
 
 template <int D>
 int32_t launch_bwd(const float* x, const float* x_scale, int64_t mx, const float* y, const float* y_scale, int64_t ny,
@@ -538,7 +561,7 @@ int anchors_per_block_for(int d) { return d <= 128 ? 256 : 128; }
 template <int D>
 int32_t launch_fwd(const float* a, const float* a_scale, int64_t m, const float* b, const float* b_scale, int64_t n,
                    float inv_tau, float* lse, void* workspace, hipStream_t s) {
-  const FwdPlan p = plan_fwd(m, n, Shape<D>::ANCHORS_PER_BLOCK);
+  const FwdPlan p = plan_fwd(m, n, Shape<D>::ANCHORS_PER_BLOCK, D <= 64 ? 768 : 512);
   float2* part = reinterpret_cast<float2*>(workspace);
   hipLaunchKernelGGL((infonce_fwd_kernel<D>), dim3((unsigned)(p.m_blocks * p.nsplit)), dim3(256), 0, s, a, a_scale, m,
                      b, b_scale, n, inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part);
@@ -554,7 +577,7 @@ bool dim_supported(int d) { return d == 32 || d == 64 || d == 128 || d == 256; }
 
 extern "C" int64_t gcr_infonce_fwd_workspace_bytes(int64_t m, int64_t n, int32_t d) {
   if (m <= 0 || n <= 0 || !dim_supported(d)) return 0;
-  const FwdPlan p = plan_fwd(m, n, anchors_per_block_for(d));
+  const FwdPlan p = plan_fwd(m, n, anchors_per_block_for(d), d <= 64 ? 768 : 512);
   return (int64_t)p.nsplit * m * (int64_t)sizeof(float2);
 }
 

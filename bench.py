@@ -375,9 +375,26 @@ def cpu_baseline(graph, x0, k_layers, nnz):
         oracle_c.lightgcn_propagate(rowptr, col, val, xh, k_layers, "sum")
         spent += time.perf_counter() - t
         reps += 1
-    return {"value": nnz * k_layers * reps / spent, "unit": "edges/s", "cores": threads, "kind": "port",
-            "sample": f"{reps} x full {k_layers}-layer CSR propagation of the same graph (oracle/oracle.c, "
-                      f"OpenMP {threads} threads, fp32)"}
+    out = {"value": nnz * k_layers * reps / spent, "unit": "edges/s", "cores": threads, "kind": "port",
+           "sample": f"{reps} x full {k_layers}-layer CSR propagation of the same graph (oracle/oracle.c, "
+                     f"OpenMP {threads} threads, fp32)"}
+    # the op the reference itself calls (stock PyTorch, ncl.py:203-209,419): torch.sparse.mm on the
+    # uncoalesced COO tensor, one layer, timed on the same host cores (informative companion line)
+    try:
+        import numpy as np
+        rows = np.repeat(np.arange(rowptr.size - 1, dtype=np.int64), np.diff(rowptr))
+        idx = torch.from_numpy(np.stack([rows, col.astype(np.int64)]))
+        a_coo = torch.sparse_coo_tensor(idx, torch.from_numpy(val), (rowptr.size - 1, rowptr.size - 1))
+        xt = torch.from_numpy(xh)
+        torch.sparse.mm(a_coo, xt)
+        t = time.perf_counter()
+        torch.sparse.mm(a_coo, xt)
+        dt = time.perf_counter() - t
+        out["torch_sparse_mm_coo_edges_per_s"] = nnz / dt
+        out["torch_threads"] = torch.get_num_threads()
+    except Exception as e:  # informative only
+        out["torch_sparse_mm_coo_error"] = str(e)[:100]
+    return out
 
 
 if __name__ == "__main__":

@@ -201,6 +201,21 @@ int32_t gcr_normalize_bwd_f32(const float* x, const float* inv_norm, const float
                               float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * k-means E-step of NCL's prototype contrast (ncl.py:340-356: faiss.Kmeans(d, k).train(x) +
+ * index.search(x, 1); faiss itself is an un-vendored dependency: semantics = plain Lloyd).
+ * --------------------------------------------------------------------------------------------- */
+/* assign[i] = argmin_c ||x_i - centroids_c||^2 (ties -> smaller c) on the MFMA tile engine;
+ * half_sqnorm[c] = 0.5 ||centroids_c||^2 (kept up to date by gcr_kmeans_update_f32);
+ * best_score (optional) = <x_i, c> - 0.5 ||c||^2 of the winner.  d in {32, 64, 128, 256}. */
+int32_t gcr_kmeans_assign_f32(const float* x, int64_t n, const float* centroids, const float* half_sqnorm,
+                              int64_t k, int32_t d, int64_t* assign, float* best_score, void* stream);
+/* centroids_c <- mean of the rows assigned to c (empty clusters keep their centroid), and
+ * half_sqnorm refreshed.  n == 0 only refreshes half_sqnorm (initialisation).
+ * sums [k, d] / counts [k] are fp32 scratch. */
+int32_t gcr_kmeans_update_f32(const float* x, int64_t n, int32_t d, const int64_t* assign, int64_t k,
+                              float* centroids, float* half_sqnorm, float* sums, float* counts, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Graph ingest on the device (integer work, bit-exact with the reference's host construction).
  * --------------------------------------------------------------------------------------------- */
 int64_t gcr_coo_to_csr_workspace_bytes(int64_t nnz);

@@ -507,3 +507,29 @@ def synthetic_interactions(num_users, num_items, num_edges, seed=20250919, zipf_
         need = num_edges - keys.size
     keys = keys[rng.permutation(keys.size)]
     return keys // num_items, keys % num_items
+
+
+# --------------------------------------------------------------------------
+# k-means E-step (K1) — ncl.py:340-356 delegates to faiss (absent: PARITY UNPINNED); this is the
+# plain Lloyd iteration the HIP path implements, for an implementation-vs-restatement check.
+# --------------------------------------------------------------------------
+
+
+def kmeans_lloyd(x, init_centroids, niter=20):
+    """Assignment = argmin_c ||x - c||^2 (ties -> smaller c); update = mean of members, an empty
+    cluster keeps its centroid; final assignment against the final centroids (index.search(x, 1))."""
+    x = np.asarray(x, dtype=F64)
+    cent = np.asarray(init_centroids, dtype=F64).copy()
+
+    def assign(c):
+        score = x @ c.T - 0.5 * (c * c).sum(1)[None, :]
+        return np.argmax(score, axis=1)
+
+    for _ in range(niter):
+        a = assign(cent)
+        sums = np.zeros_like(cent)
+        np.add.at(sums, a, x)
+        cnt = np.bincount(a, minlength=cent.shape[0])
+        nz = cnt > 0
+        cent[nz] = sums[nz] / cnt[nz, None]
+    return cent, assign(cent)

@@ -40,6 +40,8 @@ SIGNATURES = {
     "gcr_infonce_bwd_f32": (c_int32, [_P, _P, c_int64, _P, _P, c_int64, c_int32, c_float, _P, _P, _P, _P, _P, _P, _P]),
     "gcr_infonce_pos_bwd_f32": (c_int32, [_P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int32, c_float, _P, _P, _P]),
     "gcr_normalize_bwd_f32": (c_int32, [_P, _P, _P, c_int64, c_int32, _P, _P]),
+    "gcr_kmeans_assign_f32": (c_int32, [_P, c_int64, _P, _P, c_int64, c_int32, _P, _P, _P]),
+    "gcr_kmeans_update_f32": (c_int32, [_P, c_int64, c_int32, _P, c_int64, _P, _P, _P, _P, _P]),
     "gcr_coo_to_csr_workspace_bytes": (c_int64, [c_int64]),
     "gcr_coo_to_csr": (c_int32, [_P, _P, _P, c_int64, c_int64, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gcr_csr_sym_norm_f32": (c_int32, [_P, _P, _P, c_int64, c_int64, _P, _P, _P, _P, _P, _P]),

@@ -573,7 +573,165 @@ int32_t launch_fwd(const float* a, const float* a_scale, int64_t m, const float*
 
 bool dim_supported(int d) { return d == 32 || d == 64 || d == 128 || d == 256; }
 
+// ------------------------------------------------------------------------------------------
+// Nearest-centroid assignment for the NCL prototype step (ncl.py:340-356: faiss.Kmeans.train +
+// index.search(x, 1)): argmin_k ||x_i - c_k||^2 = argmax_k (<x_i, c_k> - 0.5 ||c_k||^2).  Same MFMA
+// tile engine as the InfoNCE forward (points stationary on the lanes, centroids streamed through
+// LDS); the epilogue is an in-lane running arg-max instead of an exp2-sum.  Ties go to the
+// smaller centroid id.
+// ------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256, (D <= 64 ? 3 : 2)) void kmeans_assign_kernel(
+    const float* __restrict__ x, int64_t n, const float* __restrict__ cent, const float* __restrict__ half_sq,
+    int64_t k, int64_t* __restrict__ assign, float* __restrict__ best_out) {
+  using S = Shape<D>;
+  __shared__ __align__(16) float lds[2][kTileJ * S::STRIDE];
+  __shared__ __align__(16) float st_bias[2][kTileJ];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i32 = lane & 31, h = lane >> 5;
+  const int64_t i0 = ((int64_t)blockIdx.x * 4 + wave) * (32 * S::NT);
+  float bfrag[S::NT][S::KH];
+#pragma unroll
+  for (int t = 0; t < S::NT; ++t) load_stationary<D>(x, nullptr, n, i0 + 32 * t + i32, h, 1.0f, bfrag[t]);
+  float best[S::NT];
+  int bidx[S::NT];
+#pragma unroll
+  for (int t = 0; t < S::NT; ++t) {
+    best[t] = -INFINITY;
+    bidx[t] = 0x7fffffff;
+  }
+  const int64_t tiles = (k + kTileJ - 1) / kTileJ;
+  float4 regs[S::NLD];
+  float bias = 0.f;
+  auto load_bias = [&](int64_t j0) {
+    if (tid < kTileJ) bias = (j0 + tid < k) ? -half_sq[j0 + tid] : -INFINITY;  // rows past k never win
+  };
+  stage_load<D>(cent, nullptr, k, 0, tid, regs);
+  load_bias(0);
+  stage_store<D>(lds[0], tid, regs);
+  if (tid < kTileJ) st_bias[0][tid] = bias;
+  __syncthreads();
+  for (int64_t tt = 0; tt < tiles; ++tt) {
+    const int cur = (int)(tt & 1);
+    const int64_t nxt = tt + 1 < tiles ? tt + 1 : tt;
+    stage_load<D>(cent, nullptr, k, nxt * kTileJ, tid, regs);
+    load_bias(nxt * kTileJ);
+    f32x16 acc[S::NT];
+    score_tile<D>(lds[cur], i32, h, bfrag, acc);
+    const int j0 = (int)(tt * kTileJ);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 bb = *reinterpret_cast<const float4*>(&st_bias[cur][8 * g + 4 * h]);
+      const float be[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g + e;
+        const int j = j0 + acc_row(r, h);
+#pragma unroll
+        for (int t = 0; t < S::NT; ++t) {
+          const float v = acc[t][r] + be[e];
+          const bool better = v > best[t] || (v == best[t] && j < bidx[t]);
+          best[t] = better ? v : best[t];
+          bidx[t] = better ? j : bidx[t];
+        }
+      }
+    }
+    stage_store<D>(lds[cur ^ 1], tid, regs);
+    if (tid < kTileJ) st_bias[cur ^ 1][tid] = bias;
+    __syncthreads();
+  }
+#pragma unroll
+  for (int t = 0; t < S::NT; ++t) {
+    const float v_o = __shfl_xor(best[t], 32, 64);
+    const int j_o = __shfl_xor(bidx[t], 32, 64);
+    const bool other = v_o > best[t] || (v_o == best[t] && j_o < bidx[t]);
+    const float v = other ? v_o : best[t];
+    const int j = other ? j_o : bidx[t];
+    const int64_t row = i0 + 32 * t + i32;
+    if (h == 0 && row < n) {
+      assign[row] = j;
+      if (best_out != nullptr) best_out[row] = v;
+    }
+  }
+}
+
+// sums[c] += x_i (256-B float-atomic rows), counts[c] += 1, one wave per point
+__global__ __launch_bounds__(256) void kmeans_accumulate_kernel(const float* __restrict__ x, int64_t n, int d,
+                                                                const int64_t* __restrict__ assign, int64_t k,
+                                                                float* __restrict__ sums, float* __restrict__ counts) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += (int64_t)gridDim.x * 4) {
+    const int64_t c = assign[i];
+    if (c < 0 || c >= k) continue;
+    for (int col = lane; col < d; col += 64) atomicAdd(sums + c * d + col, x[i * d + col]);
+    if (lane == 0) atomicAdd(counts + c, 1.0f);
+  }
+}
+
+// centroid = sum / count (empty clusters keep their previous centroid); half_sq = 0.5 ||c||^2
+__global__ __launch_bounds__(256) void kmeans_finalize_kernel(const float* __restrict__ sums,
+                                                              const float* __restrict__ counts, int64_t k, int d,
+                                                              float* __restrict__ cent, float* __restrict__ half_sq) {
+  const int l16 = threadIdx.x & 15;
+  for (int64_t c = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); c < k; c += (int64_t)gridDim.x * 16) {
+    const float cnt = counts != nullptr ? counts[c] : 0.f;
+    float ss = 0.f;
+    for (int col = l16; col < d; col += 16) {
+      float v = cent[c * d + col];
+      if (cnt > 0.f) {
+        v = sums[c * d + col] / cnt;
+        cent[c * d + col] = v;
+      }
+      ss += v * v;
+    }
+    ss = group16_sum(ss);
+    if (l16 == 0) half_sq[c] = 0.5f * ss;
+  }
+}
+
 }  // namespace
+
+extern "C" int32_t gcr_kmeans_assign_f32(const float* x, int64_t n, const float* centroids, const float* half_sqnorm,
+                                         int64_t k, int32_t d, int64_t* assign, float* best_score, void* stream) {
+  GCR_CHECK_ARG(n >= 0 && k >= 1 && k < (1ll << 31));
+  if (!dim_supported(d)) return GCR_EUNSUPPORTED;
+  if (n == 0) return GCR_OK;
+  GCR_CHECK_ARG(x && centroids && half_sqnorm && assign);
+  hipStream_t s = (hipStream_t)stream;
+#define GCR_KM(DD)                                                                                             \
+  hipLaunchKernelGGL((kmeans_assign_kernel<DD>), dim3((unsigned)((n + Shape<DD>::ANCHORS_PER_BLOCK - 1) /      \
+                                                                 Shape<DD>::ANCHORS_PER_BLOCK)),               \
+                     dim3(256), 0, s, x, n, centroids, half_sqnorm, k, assign, best_score)
+  switch (d) {
+    case 32: GCR_KM(32); break;
+    case 64: GCR_KM(64); break;
+    case 128: GCR_KM(128); break;
+    default: GCR_KM(256); break;
+  }
+#undef GCR_KM
+  return GCR_LAUNCH_STATUS();
+}
+
+extern "C" int32_t gcr_kmeans_update_f32(const float* x, int64_t n, int32_t d, const int64_t* assign, int64_t k,
+                                         float* centroids, float* half_sqnorm, float* sums, float* counts,
+                                         void* stream) {
+  GCR_CHECK_ARG(n >= 0 && k >= 1 && d >= 1);
+  GCR_CHECK_ARG(centroids && half_sqnorm);
+  hipStream_t s = (hipStream_t)stream;
+  if (n > 0) {
+    GCR_CHECK_ARG(x && assign && sums && counts);
+    hipError_t err = hipMemsetAsync(sums, 0, sizeof(float) * (size_t)(k * d), s);
+    if (err == hipSuccess) err = hipMemsetAsync(counts, 0, sizeof(float) * (size_t)k, s);
+    if (err != hipSuccess) return gcr_hip_status(err);
+    const int64_t want = (n + 3) / 4;
+    hipLaunchKernelGGL(kmeans_accumulate_kernel, dim3((unsigned)(want > 16384 ? 16384 : want)), dim3(256), 0, s, x, n,
+                       d, assign, k, sums, counts);
+  }
+  const int64_t wantk = (k + 15) / 16;
+  hipLaunchKernelGGL(kmeans_finalize_kernel, dim3((unsigned)(wantk > 4096 ? 4096 : wantk)), dim3(256), 0, s, sums,
+                     n > 0 ? counts : nullptr, k, d, centroids, half_sqnorm);
+  return GCR_LAUNCH_STATUS();
+}
 
 extern "C" int64_t gcr_infonce_fwd_workspace_bytes(int64_t m, int64_t n, int32_t d) {
   if (m <= 0 || n <= 0 || !dim_supported(d)) return 0;

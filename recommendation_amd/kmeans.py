@@ -1,0 +1,57 @@
+"""k-means E-step of NCL (ncl.py:340-356) on the GPU: `run_kmeans(x)` -> (centroids, assignment).
+
+The reference delegates to `faiss.Kmeans(d, k, gpu=False).train(x)` + `kmeans.index.search(x, 1)`;
+faiss is an un-vendored dependency that is not installed here, so parity with it is UNPINNED.  What
+is implemented is plain Lloyd iteration with faiss' defaults that matter for the result shape
+(niter = 20, initial centroids = a random sample of k points, L2 nearest centroid); an empty
+cluster keeps its previous centroid (faiss re-splits a big cluster instead).  The assignment runs on
+the fp32 MFMA tile engine (gcr_kmeans_assign_f32), the update is float-atomic row adds.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from . import functional as Fn
+
+
+def kmeans_assign(x, centroids, half_sq):
+    L = _lib.lib()
+    n, d = x.shape
+    assign = torch.empty(n, dtype=torch.int64, device=x.device)
+    _lib.check(L.gcr_kmeans_assign_f32(_lib.dptr(x), n, _lib.dptr(centroids), _lib.dptr(half_sq), centroids.shape[0], d,
+                                       _lib.dptr(assign), None, _lib.cur_stream(x.device)), "gcr_kmeans_assign_f32")
+    return assign
+
+
+def run_kmeans(x, k, niter=20, seed=1234, init_centroids=None):
+    """ncl.py:347-356.  x: float32 [n, d] on the GPU.  Returns (centroids [k', d], assignment int64 [n])
+    with k' = min(k, max(2, n // 39)) exactly as ncl.py:350-351 clamps it."""
+    _lib.require_cuda(x)
+    if x.dim() != 2 or x.dtype != torch.float32:
+        raise ValueError("x must be float32 [n, d]")
+    n, d_orig = x.shape
+    k = min(int(k), max(2, n // 39))
+    if init_centroids is None:
+        g = torch.Generator(device=x.device).manual_seed(int(seed))
+        init_centroids = x[torch.randperm(n, device=x.device, generator=g)[:k]]
+    xp = Fn._pad_dim(x.detach()).contiguous()
+    cent = Fn._pad_dim(init_centroids.detach().to(torch.float32)).contiguous().clone()
+    k = cent.shape[0]
+    d = xp.shape[1]
+    L = _lib.lib()
+    half_sq = torch.empty(k, dtype=torch.float32, device=x.device)
+    sums = torch.empty(k, d, dtype=torch.float32, device=x.device)
+    counts = torch.empty(k, dtype=torch.float32, device=x.device)
+    stream = _lib.cur_stream(x.device)
+
+    def update(assign, n_rows):
+        _lib.check(L.gcr_kmeans_update_f32(_lib.dptr(xp), n_rows, d, _lib.dptr(assign), k, _lib.dptr(cent),
+                                           _lib.dptr(half_sq), _lib.dptr(sums), _lib.dptr(counts), stream),
+                   "gcr_kmeans_update_f32")
+
+    update(None, 0)                      # half_sq of the initial centroids
+    for _ in range(niter):
+        update(kmeans_assign(xp, cent, half_sq), n)
+    assign = kmeans_assign(xp, cent, half_sq)       # kmeans.index.search(x, 1) against the final centroids
+    return cent[:, :d_orig].contiguous(), assign

@@ -356,6 +356,16 @@ def bench_extra(ra, Fn, graph, x0, k_layers, nnz, dev, n_u, n_i):
     ub = torch.randint(0, n_u, (1 << 20,), device=dev, generator=gen)
     t_s = timeit(lambda: Fn.neg_sample(rowptr_u, items_u, ub, 1, n_i, 7, 0, 101), 10)
     out["neg_samples_per_s"] = ub.numel() / t_s
+
+    # the stages either side of the path: NCL's k-means E-step and full-ranking eval
+    from recommendation_amd.evaluate import rank_topk
+    from recommendation_amd.kmeans import run_kmeans
+    if n_u >= 100000:
+        t_k = timeit(lambda: run_kmeans(x0[:n_u], 2000, niter=20), 2)
+        out["kmeans_users_k2000_20iter_ms"] = 1e3 * t_k
+        q = torch.arange(0, min(n_u, 100000), device=dev)
+        t_r = timeit(lambda: rank_topk(ut, it, q, rowptr_u, items_u, 50), 2)
+        out["full_ranking_users_per_s"] = q.numel() / t_r
     return out
 
 

@@ -216,6 +216,24 @@ int32_t gcr_kmeans_update_f32(const float* x, int64_t n, int32_t d, const int64_
                               float* centroids, float* half_sqnorm, float* sums, float* counts, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Full-ranking evaluation: user x ALL-items scores, training positives masked, exact top-N.
+ * --------------------------------------------------------------------------------------------- */
+/* scores[q, j] = <user_emb[user_ids[q]], item_emb[j]>  (user_ids == NULL: q itself), fp32 [n_query,
+ * n_items] row-major.  replaces torch.matmul(user_emb, item_emb.t()) lightgcn.py:50, gcl.py:88,
+ * `torch.matmul(self.user_emb[u], self.item_emb.T)` ncl.py:394.  d in {32, 64, 128, 256}. */
+int32_t gcr_score_rows_f32(const float* user_emb, const int64_t* user_ids, int64_t n_query, int64_t n_users,
+                           const float* item_emb, int64_t n_items, int32_t d, float* scores, void* stream);
+/* Per query row: scores[q, training items of the user] = -inf (in place), then the k largest scores
+ * in descending order, ties -> smaller item id; rows with fewer than k finite items are padded with
+ * (-1, -inf).  replaces `scores_user[list(known_pos)] = -np.inf; np.argsort(-scores_user)[:k]`
+ * lightgcn.py:55-57, gcl.py:93-96 and `candidates[...] = -1e8; torch.topk(candidates, max_N)`
+ * ncl.py:257-261.  user_rowptr / user_items_sorted (CSR of training positives) may both be NULL.
+ * k <= 256. */
+int32_t gcr_topk_masked_f32(float* scores, int64_t n_query, int64_t n_items, const int64_t* user_ids,
+                            int64_t n_users, const int64_t* user_rowptr, const int32_t* user_items_sorted,
+                            int32_t k, int64_t* top_items, float* top_scores, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Graph ingest on the device (integer work, bit-exact with the reference's host construction).
  * --------------------------------------------------------------------------------------------- */
 int64_t gcr_coo_to_csr_workspace_bytes(int64_t nnz);

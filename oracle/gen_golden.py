@@ -266,5 +266,33 @@ def main():
         print("  ", fn, os.path.getsize(os.path.join(OUT, fn)), "bytes")
 
 
+def gen_eval():
+    """tests/golden/eval.json: ncl.py's own ranking_evaluation / Metric (ncl.py:133-177) on a seeded
+    (test_set, rec_list) pair — the strings the reference prints."""
+    import json
+    import math
+    tree = ast.parse(open(os.path.join(REF, "ncl.py")).read())
+    wanted = [n for n in tree.body if (isinstance(n, ast.ClassDef) and n.name == "Metric")
+              or (isinstance(n, ast.FunctionDef) and n.name == "ranking_evaluation")]
+    ns = {"np": np, "math": math}
+    exec(compile(ast.Module(body=wanted, type_ignores=[]), "ncl.py", "exec"), ns)
+    rng = np.random.default_rng(11)
+    users = [f"u{k}" for k in range(40)]
+    origin = {u: {f"i{int(j)}": 1 for j in rng.choice(200, int(rng.integers(1, 9)), replace=False)} for u in users}
+    res = {u: [(f"i{int(j)}", float(s)) for j, s in zip(rng.choice(200, 50, replace=False), -np.sort(-rng.random(50)))]
+           for u in users}
+    for u in users[:25]:        # make sure there are hits at different ranks
+        k = list(origin[u])[0]
+        pos = int(rng.integers(0, 50))
+        res[u][pos] = (k, res[u][pos][1])
+    out = ns["ranking_evaluation"](origin, res, [10, 20, 30, 50])
+    with open(os.path.join(OUT, "eval.json"), "w") as f:
+        json.dump({"origin": origin, "res": res, "N": [10, 20, 30, 50], "lines": out}, f)
+    print("wrote eval.json:", "".join(out[:5]).replace("\n", " | "))
+
+
 if __name__ == "__main__":
-    main()
+    if "--eval" in sys.argv:
+        gen_eval()
+    else:
+        main()

@@ -1,0 +1,345 @@
+// Full-ranking evaluation: scores of a block of users against ALL items on the fp32
+// MFMA, training positives masked, exact top-N per user.
+//
+// Replaces  torch.matmul(user_emb, item_emb.t()) + per-user python masking + argsort / topk
+//   lightgcn.py:48-57, gcl.py:87-96 (`scores_user[known] = -inf; argsort(-scores)[:k]`),
+//   ncl.py:253-264,390-394 (`candidates[rated] = -1e8; torch.topk(candidates, max_N)`).
+//
+// score_rows: the tile is oriented with ITEMS on the lanes (stationary, 64 per wave in registers)
+//   and gathered USER rows streamed through LDS, so that one accumulator register of the 32x32
+//   tile is 32 consecutive items of one user: the store is a coalesced 128-B row segment.
+// topk_masked: one 256-thread block per user row: scatter -inf over the user's training items,
+//   3-pass radix select (11 + 11 + 10 bits) of the k-th largest key over the L2-resident row, gather
+//   the winners, bitonic sort by (score desc, item id asc).  Ties at the threshold are resolved
+//   towards the smaller item id (deterministic).
+#include "gcr_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kTile = 32;
+
+template <int D>
+struct RShape {
+  static constexpr int KH = D / 2;
+  static constexpr int STRIDE = D + 4;
+  static constexpr int NT = D <= 128 ? 2 : 1;
+  static constexpr int NLD = (kTile * D / 4) / 256;
+  static constexpr int ITEMS_PER_BLOCK = 4 * 32 * NT;
+};
+
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void score_rows_kernel(const float* __restrict__ user_emb,
+                                                            const int64_t* __restrict__ user_ids, int64_t n_query,
+                                                            int64_t n_users, const float* __restrict__ item_emb,
+                                                            int64_t n_items, int64_t q_tiles_per_split, int nsplit,
+                                                            float* __restrict__ scores) {
+  using S = RShape<D>;
+  __shared__ __align__(16) float lds[2][kTile * S::STRIDE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i32 = lane & 31, h = lane >> 5;
+  const int64_t iblk = blockIdx.x / nsplit;
+  const int split = blockIdx.x % nsplit;
+  const int64_t j0 = (iblk * 4 + wave) * (32 * S::NT);
+
+  float bfrag[S::NT][S::KH];
+#pragma unroll
+  for (int t = 0; t < S::NT; ++t) {
+    const int64_t j = j0 + 32 * t + i32;
+    const bool valid = j < n_items;
+    const float* p = item_emb + (valid ? j : 0) * D + h * S::KH;
+#pragma unroll
+    for (int q = 0; q < S::KH / 4; ++q) {
+      const float4 v = valid ? *reinterpret_cast<const float4*>(p + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+      bfrag[t][4 * q + 0] = v.x;
+      bfrag[t][4 * q + 1] = v.y;
+      bfrag[t][4 * q + 2] = v.z;
+      bfrag[t][4 * q + 3] = v.w;
+    }
+  }
+  const int64_t total_tiles = (n_query + kTile - 1) / kTile;
+  const int64_t tile0 = (int64_t)split * q_tiles_per_split;
+  const int64_t tile1 = min(total_tiles, tile0 + q_tiles_per_split);
+  float4 regs[S::NLD];
+  auto stage_load = [&](int64_t q0) {
+#pragma unroll
+    for (int u = 0; u < S::NLD; ++u) {
+      const int idx = tid + 256 * u;
+      const int row = idx / (D / 4), c4 = idx % (D / 4);
+      const int64_t q = q0 + row;
+      int64_t uid = q < n_query ? (user_ids != nullptr ? user_ids[q] : q) : 0;
+      const bool ok = q < n_query && uid >= 0 && uid < n_users;
+      uid = ok ? uid : 0;
+      float4 v = *reinterpret_cast<const float4*>(user_emb + uid * D + 4 * c4);
+      if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      regs[u] = v;
+    }
+  };
+  auto stage_store = [&](float* tile) {
+#pragma unroll
+    for (int u = 0; u < S::NLD; ++u) {
+      const int idx = tid + 256 * u;
+      const int row = idx / (D / 4), c4 = idx % (D / 4);
+      *reinterpret_cast<float4*>(tile + row * S::STRIDE + 4 * c4) = regs[u];
+    }
+  };
+  if (tile0 < tile1) {
+    stage_load(tile0 * kTile);
+    stage_store(lds[0]);
+  }
+  __syncthreads();
+  for (int64_t tt = tile0; tt < tile1; ++tt) {
+    const int cur = (int)((tt - tile0) & 1);
+    const int64_t nxt = tt + 1 < tile1 ? tt + 1 : tt;
+    stage_load(nxt * kTile);
+    f32x16 acc[S::NT];
+#pragma unroll
+    for (int t = 0; t < S::NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const float* base = lds[cur] + i32 * S::STRIDE + h * S::KH;
+#pragma unroll
+    for (int q = 0; q < S::KH / 4; ++q) {
+      const float4 av = *reinterpret_cast<const float4*>(base + 4 * q);
+      const float ae[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int t = 0; t < S::NT; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae[e], bfrag[t][4 * q + e], acc[t], 0, 0, 0);
+    }
+    // register r = query row acc_row(r, h) of this tile, lane = item: 128-B coalesced row segments
+    const int64_t q0 = tt * kTile;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t q = q0 + acc_row(r, h);
+      if (q < n_query) {
+#pragma unroll
+        for (int t = 0; t < S::NT; ++t) {
+          const int64_t j = j0 + 32 * t + i32;
+          if (j < n_items) scores[q * n_items + j] = acc[t][r];
+        }
+      }
+    }
+    stage_store(lds[cur ^ 1]);
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ uint32_t order_key(float f) {
+  const uint32_t b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);   // larger float -> larger key; -inf smallest
+}
+
+constexpr int kTopThreads = 256;
+constexpr int kMaxK = 256;
+constexpr int kEqCap = 1024;
+
+// finds, scanning bins from the top, the bin where the cumulative count reaches `want`
+__device__ int pick_bin(const uint32_t* hist, int nbins, uint32_t want, uint32_t* above_out, uint32_t* sh) {
+  // 256 threads: each sums a contiguous slice from the top, then thread 0 walks the slice sums
+  const int tid = threadIdx.x;
+  const int per = (nbins + kTopThreads - 1) / kTopThreads;
+  uint32_t s = 0;
+  for (int b = 0; b < per; ++b) {
+    const int bin = nbins - 1 - (tid * per + b);
+    if (bin >= 0) s += hist[bin];
+  }
+  sh[tid] = s;
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t cum = 0;
+    int slice = 0;
+    for (; slice < kTopThreads; ++slice) {
+      if (cum + sh[slice] >= want) break;
+      cum += sh[slice];
+    }
+    int bin = nbins - 1 - slice * per;
+    for (int b = 0; b < per; ++b, --bin) {
+      const uint32_t c = bin >= 0 ? hist[bin] : 0;
+      if (cum + c >= want) break;
+      cum += c;
+    }
+    if (bin < 0) bin = 0;
+    sh[kTopThreads] = (uint32_t)bin;
+    sh[kTopThreads + 1] = cum;
+  }
+  __syncthreads();
+  *above_out = sh[kTopThreads + 1];
+  const int bin = (int)sh[kTopThreads];
+  __syncthreads();
+  return bin;
+}
+
+__global__ __launch_bounds__(kTopThreads) void topk_masked_kernel(float* __restrict__ scores, int64_t n_query,
+                                                                  int64_t n_items, const int64_t* __restrict__ user_ids,
+                                                                  int64_t n_users,
+                                                                  const int64_t* __restrict__ user_rowptr,
+                                                                  const int32_t* __restrict__ user_items, int k,
+                                                                  int64_t* __restrict__ top_items,
+                                                                  float* __restrict__ top_scores) {
+  __shared__ uint32_t hist[2048];
+  __shared__ uint32_t sh[kTopThreads + 2];
+  __shared__ unsigned long long cand[kMaxK];   // (key << 32) | (0xFFFFFFFF - item)
+  __shared__ uint32_t eq_idx[kEqCap];
+  __shared__ uint32_t n_gt, n_eq;
+  const int tid = threadIdx.x;
+  for (int64_t q = blockIdx.x; q < n_query; q += gridDim.x) {
+    float* row = scores + q * n_items;
+    const int64_t uid = user_ids != nullptr ? user_ids[q] : q;
+    if (user_rowptr != nullptr && uid >= 0 && uid < n_users) {
+      for (int64_t e = user_rowptr[uid] + tid; e < user_rowptr[uid + 1]; e += kTopThreads) {
+        const int32_t it = user_items[e];
+        if (it >= 0 && it < n_items) row[it] = -INFINITY;
+      }
+    }
+    __syncthreads();
+    const int kk = (int)(k < n_items ? k : n_items);
+    // --- pass A: top 11 bits
+    for (int b = tid; b < 2048; b += kTopThreads) hist[b] = 0;
+    __syncthreads();
+    for (int64_t j = tid; j < n_items; j += kTopThreads) atomicAdd(&hist[order_key(row[j]) >> 21], 1u);
+    __syncthreads();
+    uint32_t above = 0;
+    const uint32_t b1 = (uint32_t)pick_bin(hist, 2048, (uint32_t)kk, &above, sh);
+    uint32_t want = (uint32_t)kk - above;
+    // --- pass B: next 11 bits inside bin b1
+    for (int b = tid; b < 2048; b += kTopThreads) hist[b] = 0;
+    __syncthreads();
+    for (int64_t j = tid; j < n_items; j += kTopThreads) {
+      const uint32_t key = order_key(row[j]);
+      if ((key >> 21) == b1) atomicAdd(&hist[(key >> 10) & 0x7FFu], 1u);
+    }
+    __syncthreads();
+    const uint32_t b2 = (uint32_t)pick_bin(hist, 2048, want, &above, sh);
+    want -= above;
+    // --- pass C: last 10 bits
+    for (int b = tid; b < 1024; b += kTopThreads) hist[b] = 0;
+    __syncthreads();
+    const uint32_t prefix = (b1 << 11) | b2;
+    for (int64_t j = tid; j < n_items; j += kTopThreads) {
+      const uint32_t key = order_key(row[j]);
+      if ((key >> 10) == prefix) atomicAdd(&hist[key & 0x3FFu], 1u);
+    }
+    __syncthreads();
+    const uint32_t b3 = (uint32_t)pick_bin(hist, 1024, want, &above, sh);
+    const uint32_t need_eq = want - above;          // how many elements equal to the threshold to take
+    const uint32_t thr = (prefix << 10) | b3;
+    // --- gather: everything above the threshold, and the `need_eq` smallest item ids equal to it
+    if (tid == 0) {
+      n_gt = 0;
+      n_eq = 0;
+    }
+    __syncthreads();
+    for (int64_t j = tid; j < n_items; j += kTopThreads) {
+      const uint32_t key = order_key(row[j]);
+      if (key > thr) {
+        const uint32_t p = atomicAdd(&n_gt, 1u);
+        if (p < (uint32_t)kMaxK) cand[p] = ((unsigned long long)key << 32) | (0xFFFFFFFFu - (uint32_t)j);
+      } else if (key == thr) {
+        const uint32_t p = atomicAdd(&n_eq, 1u);
+        if (p < (uint32_t)kEqCap) eq_idx[p] = (uint32_t)j;
+      }
+    }
+    __syncthreads();
+    const uint32_t gt = n_gt;
+    if (n_eq <= (uint32_t)kEqCap) {
+      // rank of each tied id among the ties (O(n_eq^2 / threads), n_eq is tiny for real scores)
+      for (uint32_t a = tid; a < n_eq; a += kTopThreads) {
+        const uint32_t me = eq_idx[a];
+        uint32_t rank = 0;
+        for (uint32_t b = 0; b < n_eq; ++b) rank += eq_idx[b] < me;
+        if (rank < need_eq) cand[gt + rank] = ((unsigned long long)thr << 32) | (0xFFFFFFFFu - me);
+      }
+    } else if (tid == 0) {
+      // pathological (huge tie, e.g. an all-equal row): first `need_eq` ids in index order
+      uint32_t taken = 0;
+      for (int64_t j = 0; j < n_items && taken < need_eq; ++j)
+        if (order_key(row[j]) == thr) cand[gt + taken++] = ((unsigned long long)thr << 32) | (0xFFFFFFFFu - (uint32_t)j);
+    }
+    __syncthreads();
+    // --- bitonic sort (descending) of the kk candidates, padded to a power of two with 0
+    int n2 = 1;
+    while (n2 < kk) n2 <<= 1;
+    for (int i = kk + tid; i < n2; i += kTopThreads) cand[i] = 0ull;
+    __syncthreads();
+    for (int size = 2; size <= n2; size <<= 1) {
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        for (int i = tid; i < n2; i += kTopThreads) {
+          const int partner = i ^ stride;
+          if (partner > i) {
+            const bool desc = (i & size) == 0;
+            const unsigned long long a = cand[i], b = cand[partner];
+            if ((a < b) == desc) {
+              cand[i] = b;
+              cand[partner] = a;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+    for (int i = tid; i < k; i += kTopThreads) {
+      if (i < kk) {
+        const uint32_t item = 0xFFFFFFFFu - (uint32_t)(cand[i] & 0xFFFFFFFFull);
+        top_items[q * k + i] = item;
+        top_scores[q * k + i] = row[item];
+      } else {
+        top_items[q * k + i] = -1;
+        top_scores[q * k + i] = -INFINITY;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+bool rank_dim_supported(int d) { return d == 32 || d == 64 || d == 128 || d == 256; }
+
+template <int D>
+int32_t launch_score(const float* user_emb, const int64_t* user_ids, int64_t n_query, int64_t n_users,
+                     const float* item_emb, int64_t n_items, float* scores, hipStream_t s) {
+  const int64_t iblocks = (n_items + RShape<D>::ITEMS_PER_BLOCK - 1) / RShape<D>::ITEMS_PER_BLOCK;
+  const int64_t total_tiles = (n_query + kTile - 1) / kTile;
+  int64_t nsplit = iblocks * 2 <= 512 ? 512 / iblocks : (total_tiles + 63) / 64;
+  if (nsplit > total_tiles) nsplit = total_tiles;
+  if (nsplit < 1) nsplit = 1;
+  const int64_t tps = (total_tiles + nsplit - 1) / nsplit;
+  nsplit = (total_tiles + tps - 1) / tps;
+  hipLaunchKernelGGL((score_rows_kernel<D>), dim3((unsigned)(iblocks * nsplit)), dim3(256), 0, s, user_emb, user_ids,
+                     n_query, n_users, item_emb, n_items, tps, (int)nsplit, scores);
+  return GCR_LAUNCH_STATUS();
+}
+
+}  // namespace
+
+extern "C" int32_t gcr_score_rows_f32(const float* user_emb, const int64_t* user_ids, int64_t n_query, int64_t n_users,
+                                      const float* item_emb, int64_t n_items, int32_t d, float* scores, void* stream) {
+  GCR_CHECK_ARG(n_query >= 0 && n_users >= 1 && n_items >= 1);
+  if (!rank_dim_supported(d)) return GCR_EUNSUPPORTED;
+  if (n_query == 0) return GCR_OK;
+  GCR_CHECK_ARG(user_emb && item_emb && scores);
+  GCR_CHECK_ARG(n_query * n_items < (1ll << 40));
+  hipStream_t s = (hipStream_t)stream;
+  switch (d) {
+    case 32: return launch_score<32>(user_emb, user_ids, n_query, n_users, item_emb, n_items, scores, s);
+    case 64: return launch_score<64>(user_emb, user_ids, n_query, n_users, item_emb, n_items, scores, s);
+    case 128: return launch_score<128>(user_emb, user_ids, n_query, n_users, item_emb, n_items, scores, s);
+    default: return launch_score<256>(user_emb, user_ids, n_query, n_users, item_emb, n_items, scores, s);
+  }
+}
+
+extern "C" int32_t gcr_topk_masked_f32(float* scores, int64_t n_query, int64_t n_items, const int64_t* user_ids,
+                                       int64_t n_users, const int64_t* user_rowptr, const int32_t* user_items_sorted,
+                                       int32_t k, int64_t* top_items, float* top_scores, void* stream) {
+  GCR_CHECK_ARG(n_query >= 0 && n_items >= 1 && n_items < (1ll << 32) - 1 && k >= 1 && k <= kMaxK);
+  if (n_query == 0) return GCR_OK;
+  GCR_CHECK_ARG(scores && top_items && top_scores);
+  GCR_CHECK_ARG((user_rowptr == nullptr) == (user_items_sorted == nullptr));
+  const int64_t blocks = n_query < 65536 ? n_query : 65536;
+  hipLaunchKernelGGL(topk_masked_kernel, dim3((unsigned)blocks), dim3(kTopThreads), 0, (hipStream_t)stream, scores,
+                     n_query, n_items, user_ids, n_users, user_rowptr, user_items_sorted, k, top_items, top_scores);
+  return GCR_LAUNCH_STATUS();
+}

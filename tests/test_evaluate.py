@@ -1,0 +1,97 @@
+"""Full-ranking evaluation: metric bookkeeping pinned against the reference's own
+ranking_evaluation output (tests/golden/eval.json, CPU), and the GPU score + mask + top-N kernels
+against a numpy argsort of float64 scores."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle_np as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "eval.json")
+
+
+def test_ranking_evaluation_strings_match_reference():
+    """ncl.py:133-177: Hit Ratio / Precision / Recall / NDCG lines for N in [10, 20, 30, 50]."""
+    from recommendation_amd.evaluate import ranking_evaluation
+    g = json.load(open(GOLDEN))
+    res = {u: [tuple(p) for p in lst] for u, lst in g["res"].items()}
+    assert ranking_evaluation(g["origin"], res, g["N"]) == g["lines"]
+
+
+def _ref_topk(ue, ie, uids, pos, k):
+    s = ue[uids].astype(np.float64) @ ie.astype(np.float64).T
+    for r, u in enumerate(uids):
+        s[r, list(pos.get(int(u), []))] = -np.inf
+    order = np.lexsort((np.arange(s.shape[1])[None, :].repeat(len(uids), 0), -s), axis=1)[:, :k]
+    return order, np.take_along_axis(s, order, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_u,n_i,d,k", [(300, 1682, 64, 50), (200, 257, 32, 10), (100, 5000, 128, 20), (64, 40, 64, 50)])
+def test_rank_topk_matches_numpy(n_u, n_i, d, k):
+    from recommendation_amd.evaluate import rank_topk
+    rng = np.random.default_rng(n_u + n_i)
+    ue = rng.standard_normal((n_u, d)).astype(np.float32)
+    ie = rng.standard_normal((n_i, d)).astype(np.float32)
+    u, i = O.synthetic_interactions(n_u, n_i, min(n_u * n_i // 3, n_u * 20), seed=1)
+    order = np.lexsort((i, u))
+    rowptr = np.concatenate([[0], np.cumsum(np.bincount(u, minlength=n_u))]).astype(np.int64)
+    items_sorted = i[order].astype(np.int32)
+    pos = {}
+    for a, b in zip(u, i):
+        pos.setdefault(int(a), []).append(int(b))
+    uids = rng.permutation(n_u)[: max(1, n_u // 2)]
+    got_i, got_s = rank_topk(torch.from_numpy(ue).cuda(), torch.from_numpy(ie).cuda(), uids,
+                             torch.from_numpy(rowptr).cuda(), torch.from_numpy(items_sorted).cuda(), k,
+                             chunk_bytes=4 * n_i * 37)          # several chunks
+    ref_i, ref_s = _ref_topk(ue, ie, uids, pos, k)
+    got_i, got_s = got_i.cpu().numpy(), got_s.cpu().numpy()
+    kk = min(k, n_i)
+    finite = np.isfinite(ref_s[:, :kk])
+    np.testing.assert_allclose(got_s[:, :kk][finite], ref_s[:, :kk][finite], rtol=1e-5, atol=1e-5)
+    # identical item lists except where two fp32 scores are within rounding of each other
+    same = got_i[:, :kk] == ref_i[:, :kk]
+    assert same[finite].mean() > 0.995
+    for r, c in zip(*np.nonzero(~same & finite)):
+        assert abs(ref_s[r, c] - (ue[uids[r]].astype(np.float64) @ ie[got_i[r, c]].astype(np.float64))) < 1e-4
+    # never a training positive, never a duplicate
+    for r, uq in enumerate(uids):
+        row = got_i[r][got_i[r] >= 0]
+        assert len(set(row.tolist())) == len(row)
+        assert not (set(row[np.isfinite(got_s[r][: len(row)])].tolist()) & set(pos.get(int(uq), [])))
+    if k > n_i:
+        assert (got_i[:, n_i:] == -1).all()
+
+
+@pytest.mark.gpu
+def test_topk_ties_and_reference_protocol(golden):
+    """Exact ties resolve to the smaller item id; `test()` returns the ncl.py:253-264 structure."""
+    from recommendation_amd.encoders import Interaction
+    from recommendation_amd.evaluate import Metric, rank_topk, ranking_evaluation, test as run_test
+    ue = torch.zeros(4, 64, device="cuda")
+    ue[:, 0] = 1.0
+    ie = torch.zeros(300, 64, device="cuda")
+    ie[:, 0] = torch.tensor([float(j % 7) for j in range(300)], device="cuda")     # 7 score levels, many ties
+    items, scores = rank_topk(ue, ie, [0, 1], None, None, 60)
+    exp = sorted(range(300), key=lambda j: (-(j % 7), j))[:60]
+    assert items[0].cpu().tolist() == exp and items[1].cpu().tolist() == exp
+    assert scores[0].cpu().tolist() == [float(j % 7) for j in exp]
+    g = golden("graph_build.npz")
+    train = [[a, b, 1.0] for a, b in zip(g["train_user"].tolist(), g["train_item"].tolist())]
+    test_set = [[train[k][0], train[(k * 5) % len(train)][1], 1.0] for k in range(0, 90, 3)]
+    data = Interaction({}, train, test_set, device="cuda")
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    U = torch.randn(data.user_num, 64, device="cuda", generator=gen)
+    V = torch.randn(data.item_num, 64, device="cuda", generator=gen)
+    rec = run_test(data, U, V, 20)
+    assert set(rec) == set(data.test_set)
+    for u, lst in rec.items():
+        assert len(lst) <= 20 and all(name not in data.training_set_u[u] for name, _ in lst)
+        assert [s for _, s in lst] == sorted((s for _, s in lst), reverse=True)
+    lines = ranking_evaluation(data.test_set, rec, [10, 20])
+    assert lines[0] == "Top 10\n" and lines[5] == "Top 20\n" and len(lines) == 10
+    hits = Metric.hits(data.test_set, rec)
+    assert 0 <= Metric.hit_ratio(data.test_set, hits) <= 1

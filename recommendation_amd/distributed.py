@@ -174,3 +174,23 @@ def gather_items(item_shard, group=None):
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return item_shard
     return _GatherItems.apply(item_shard, group)
+
+
+def sharded_info_nce_loss(z1_local, z2_local, temp=0.2, group=None, stats_fn=None):
+    """gcl.py:28-35 over row-sharded views (BASELINE config 4): every rank holds the same row block of
+    z1 and z2 ([M/world, d] each, equal sizes).  Both cross-entropies are row problems with LOCAL
+    anchors against the ALL-GATHERED other view (CE(sim) from z1's rows, CE(sim.T) from z2's rows),
+    so no column statistics cross ranks; the gathered table's gradient returns by reduce-scatter
+    (`gather_items`).  Returns this rank's share of the loss: summing it over ranks (all-reduce) gives
+    the single-process value; gradients are already the full-loss gradients of the local rows.
+    `stats_fn` defaults to the HIP `functional.infonce_stats`."""
+    stats = stats_fn or Fn.infonce_stats
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    m_local = z1_local.shape[0]
+    pos = torch.arange(m_local, device=z1_local.device, dtype=torch.int64) + rank * m_local
+    z2_full, z1_full = gather_items(z2_local, group), gather_items(z1_local, group)
+    lse12, pos12 = stats(z1_local, z2_full, pos, temp, True)[:2]
+    lse21, pos21 = stats(z2_local, z1_full, pos, temp, True)[:2]
+    m_total = m_local * world
+    return ((lse12 - pos12).sum() + (lse21 - pos21).sum()) / (2 * m_total)

@@ -154,10 +154,17 @@ int64_t gcr_infonce_fwd_workspace_bytes(int64_t m, int64_t n, int32_t d);
  *           F.cross_entropy(sim, labels) / (sim.T, labels)       gcl.py:31-34
  *           torch.exp(torch.matmul(norm_cu, F.normalize(iu).T) / t).sum(1)   ncl.py:363-366
  *           torch.exp(user_emb @ item_emb.T / t).sum(dim=1)      ssl4rec.py:29
+ *
+ * col_sum (optional, [n]): in the SAME pass also col_sum[j] = sum_i exp(s_ij - col_bound) over all
+ * anchors (float atomics), from which the column logsumexp of gcl.py:34 (`cross_entropy(sim.T)`)
+ * is col_bound + log(col_sum[j]).  col_bound must bound every logit from above (unit-norm rows:
+ * inv_tau) and keep exp(-2 col_bound) representable; pass NULL / 0 otherwise and run a second
+ * call with a and b swapped.
  */
 int32_t gcr_infonce_fwd_f32(const float* a, const float* a_scale, int64_t m,
                             const float* b, const float* b_scale, int64_t n, int32_t d,
-                            float inv_tau, float* lse, void* workspace, void* stream);
+                            float inv_tau, float* lse, float* col_sum, float col_bound,
+                            void* workspace, void* stream);
 
 /*
  * out[i] = scale * a_scale[i] * b_scale[p] * <a_i, b_p>, p = pos[i] (pos == NULL: p = i) — the

@@ -143,13 +143,31 @@ __device__ __forceinline__ int rows_left(int64_t n_rows, int64_t j0, int h) {
 // phases and exp2 phases coincide, scripts/exp_infonce.hip), a third wave breaks it (109 -> 126 TF
 // on the bare tile loop); needs VGPRs <= 168.  (Folding a logit bound into the MFMA C operand to
 // drop the running max was tried: not faster, and it costs ~1e-5 of the lse - pos difference.)
-template <int D>
+//
+// COLSUM (gcl.py:34, the `sim.T` cross-entropy): the same pass also accumulates, for every table row
+// j, sum_i exp2(t_ij - col_bound2) over the anchors: 32 extra exp2 per tile, a 5-step DPP row
+// reduction per accumulator register (lane 31 / 63 end up with the two half-wave sums) and one
+// float atomic per (wave, table row).  It needs a known logit bound (unit-norm rows: |t| <= scale2),
+// and replaces a whole second pass with the roles swapped.
+__device__ __forceinline__ float half_wave_sum_to_last_lane(float v) {
+  // inclusive DPP scan inside each row of 16, then row 0 -> row 1 and row 2 -> row 3 broadcast-add:
+  // lane 31 = sum(lanes 0..31), lane 63 = sum(lanes 32..63)
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, true));
+  return v;
+}
+
+template <int D, bool COLSUM>
 __global__ __launch_bounds__(256, (D <= 64 ? 3 : 2)) void infonce_fwd_kernel(const float* __restrict__ a,
                                                              const float* __restrict__ a_scale, int64_t m_rows,
                                                              const float* __restrict__ b,
                                                              const float* __restrict__ b_scale, int64_t n_rows,
                                                              float scale2, int nsplit, int64_t tiles_per_split,
-                                                             float2* __restrict__ part) {
+                                                             float2* __restrict__ part, float* __restrict__ col_sum,
+                                                             float col_bound2) {
   using S = Shape<D>;
   __shared__ __align__(16) float lds[2][kTileJ * S::STRIDE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -162,11 +180,12 @@ __global__ __launch_bounds__(256, (D <= 64 ? 3 : 2)) void infonce_fwd_kernel(con
 #pragma unroll
   for (int t = 0; t < S::NT; ++t) load_stationary<D>(a, a_scale, m_rows, i0 + 32 * t + i32, h, scale2, bfrag[t]);
 
-  float m_run[S::NT], l_run[S::NT];
+  float m_run[S::NT], l_run[S::NT], a_valid[S::NT];
 #pragma unroll
   for (int t = 0; t < S::NT; ++t) {
     m_run[t] = kNegBig;
     l_run[t] = 0.f;
+    a_valid[t] = (i0 + 32 * t + i32 < m_rows) ? 1.0f : 0.f;   // padding anchors add nothing to a column
   }
 
   const int64_t total_tiles = (n_rows + kTileJ - 1) / kTileJ;
@@ -186,6 +205,18 @@ __global__ __launch_bounds__(256, (D <= 64 ? 3 : 2)) void infonce_fwd_kernel(con
     f32x16 acc[S::NT];
     score_tile<D>(lds[cur], i32, h, bfrag, acc);
     lse_update<S::NT>(acc, rows_left(n_rows, tt * kTileJ, h), m_run, l_run);
+    if (COLSUM) {
+      const int64_t j0 = tt * kTileJ;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float e = 0.f;
+#pragma unroll
+        for (int t = 0; t < S::NT; ++t) e += a_valid[t] * __builtin_amdgcn_exp2f(acc[t][r] - col_bound2);
+        e = half_wave_sum_to_last_lane(e);
+        const int64_t j = j0 + acc_row(r, h);
+        if (i32 == 31 && j < n_rows) atomicAdd(col_sum + j, e);
+      }
+    }
     stage_store<D>(lds[cur ^ 1], tid, regs);
     __syncthreads();
   }
@@ -560,11 +591,19 @@ int anchors_per_block_for(int d) { return d <= 128 ? 256 : 128; }
 
 template <int D>
 int32_t launch_fwd(const float* a, const float* a_scale, int64_t m, const float* b, const float* b_scale, int64_t n,
-                   float inv_tau, float* lse, void* workspace, hipStream_t s) {
+                   float inv_tau, float* lse, float* col_sum, float col_bound, void* workspace, hipStream_t s) {
   const FwdPlan p = plan_fwd(m, n, Shape<D>::ANCHORS_PER_BLOCK, D <= 64 ? 768 : 512);
   float2* part = reinterpret_cast<float2*>(workspace);
-  hipLaunchKernelGGL((infonce_fwd_kernel<D>), dim3((unsigned)(p.m_blocks * p.nsplit)), dim3(256), 0, s, a, a_scale, m,
-                     b, b_scale, n, inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part);
+  const dim3 grid((unsigned)(p.m_blocks * p.nsplit));
+  if (col_sum != nullptr) {
+    hipError_t err = hipMemsetAsync(col_sum, 0, sizeof(float) * (size_t)n, s);
+    if (err != hipSuccess) return gcr_hip_status(err);
+    hipLaunchKernelGGL((infonce_fwd_kernel<D, true>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale, n,
+                       inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part, col_sum, col_bound * kLog2e);
+  } else {
+    hipLaunchKernelGGL((infonce_fwd_kernel<D, false>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale, n,
+                       inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part, col_sum, 0.f);
+  }
   int32_t st = GCR_LAUNCH_STATUS();
   if (st != GCR_OK) return st;
   hipLaunchKernelGGL(infonce_merge_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, part, p.nsplit, m, lse);
@@ -741,7 +780,7 @@ extern "C" int64_t gcr_infonce_fwd_workspace_bytes(int64_t m, int64_t n, int32_t
 
 extern "C" int32_t gcr_infonce_fwd_f32(const float* a, const float* a_scale, int64_t m, const float* b,
                                        const float* b_scale, int64_t n, int32_t d, float inv_tau, float* lse,
-                                       void* workspace, void* stream) {
+                                       float* col_sum, float col_bound, void* workspace, void* stream) {
   GCR_CHECK_ARG(m >= 0 && n >= 1);
   if (!dim_supported(d)) return GCR_EUNSUPPORTED;
   if (m == 0) return GCR_OK;
@@ -749,10 +788,10 @@ extern "C" int32_t gcr_infonce_fwd_f32(const float* a, const float* a_scale, int
   GCR_CHECK_ARG(m < (1ll << 40) && n < (1ll << 40));
   hipStream_t s = (hipStream_t)stream;
   switch (d) {
-    case 32: return launch_fwd<32>(a, a_scale, m, b, b_scale, n, inv_tau, lse, workspace, s);
-    case 64: return launch_fwd<64>(a, a_scale, m, b, b_scale, n, inv_tau, lse, workspace, s);
-    case 128: return launch_fwd<128>(a, a_scale, m, b, b_scale, n, inv_tau, lse, workspace, s);
-    default: return launch_fwd<256>(a, a_scale, m, b, b_scale, n, inv_tau, lse, workspace, s);
+    case 32: return launch_fwd<32>(a, a_scale, m, b, b_scale, n, inv_tau, lse, col_sum, col_bound, workspace, s);
+    case 64: return launch_fwd<64>(a, a_scale, m, b, b_scale, n, inv_tau, lse, col_sum, col_bound, workspace, s);
+    case 128: return launch_fwd<128>(a, a_scale, m, b, b_scale, n, inv_tau, lse, col_sum, col_bound, workspace, s);
+    default: return launch_fwd<256>(a, a_scale, m, b, b_scale, n, inv_tau, lse, col_sum, col_bound, workspace, s);
   }
 }
 

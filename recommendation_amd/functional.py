@@ -277,6 +277,10 @@ def edge_mask_bits(nnz, pe, seed, device, edge_id=None):
 # ---------------------------------------------------------------------------------------------
 _MFMA_DIMS = (32, 64, 128, 256)
 
+# True: the column logsumexp of the symmetric loss (gcl.py:34) is computed by a second, bitwise
+# reproducible pass instead of float atomics in the first one
+COL_DETERMINISTIC = False
+
 
 def _pad_dim(x):
     """Zero-pad the feature dim to the next width the MFMA kernels are built for (dot products
@@ -300,17 +304,23 @@ def row_inv_norm(x, eps=1e-12):
     return out
 
 
-def infonce_lse_raw(a, a_scale, b, b_scale, inv_tau):
-    """lse[i] = log sum_j exp(inv_tau * a_scale[i] b_scale[j] <a_i, b_j>) (no autograd)."""
+def infonce_lse_raw(a, a_scale, b, b_scale, inv_tau, col_bound=None):
+    """lse[i] = log sum_j exp(inv_tau * a_scale[i] b_scale[j] <a_i, b_j>) (no autograd).
+    col_bound (an upper bound of every logit, e.g. inv_tau for unit rows): also return the column
+    logsumexp over the anchors [N] from the same pass (float atomics) as a second value."""
     L = _lib.lib()
     m, d = a.shape
     n = b.shape[0]
     lse = torch.empty(m, dtype=torch.float32, device=a.device)
+    col_sum = torch.empty(n, dtype=torch.float32, device=a.device) if col_bound is not None else None
     ws = torch.empty(max(int(L.gcr_infonce_fwd_workspace_bytes(m, n, d)), 8) // 4, dtype=torch.float32, device=a.device)
     _lib.check(L.gcr_infonce_fwd_f32(_lib.dptr(a), _lib.dptr(a_scale), m, _lib.dptr(b), _lib.dptr(b_scale), n, d,
-                                     float(inv_tau), _lib.dptr(lse), _lib.dptr(ws), _lib.cur_stream(a.device)),
-               "gcr_infonce_fwd_f32")
-    return lse
+                                     float(inv_tau), _lib.dptr(lse), _lib.dptr(col_sum),
+                                     float(col_bound) if col_bound is not None else 0.0, _lib.dptr(ws),
+                                     _lib.cur_stream(a.device)), "gcr_infonce_fwd_f32")
+    if col_bound is None:
+        return lse
+    return lse, torch.log(col_sum) + float(col_bound)
 
 
 def pos_logit_raw(a, a_scale, b, b_scale, pos, scale):
@@ -345,9 +355,16 @@ class _InfoNCEStats(torch.autograd.Function):
         a_p, b_p = _pad_dim(a).contiguous(), _pad_dim(b).contiguous()
         sa = row_inv_norm(a_p) if normalize else None
         sb = row_inv_norm(b_p) if normalize else None
-        lse = infonce_lse_raw(a_p, sa, b_p, sb, inv_tau)
+        # unit-norm rows bound every logit by 1/tau: row and column LSE come out of ONE pass (the
+        # column sums by float atomics); COL_DETERMINISTIC forces the bitwise-reproducible second
+        # pass with the roles swapped, which is also the path for un-normalised inputs
+        one_pass = want_col and normalize and inv_tau <= 40.0 and not COL_DETERMINISTIC
+        if one_pass:
+            lse, col = infonce_lse_raw(a_p, sa, b_p, sb, inv_tau, col_bound=inv_tau * 1.0001)
+        else:
+            lse = infonce_lse_raw(a_p, sa, b_p, sb, inv_tau)
+            col = infonce_lse_raw(b_p, sb, a_p, sa, inv_tau) if want_col else None
         pl = pos_logit_raw(a_p, sa, b_p, sb, pos, inv_tau)
-        col = infonce_lse_raw(b_p, sb, a_p, sa, inv_tau) if want_col else None
         ctx.save_for_backward(a_p, b_p, pos, sa, sb, lse, col)
         ctx.inv_tau, ctx.d = inv_tau, a.shape[1]
         if want_col:

@@ -18,7 +18,9 @@ import torch
 
 from . import _lib
 
-DEFAULT_NNZ_PER_PART = 256
+# interleaved A/B on MI355X (scripts/perf_spmm_ab.py): 64 -> 0.713 ms, 128 -> 0.652, 256 -> 0.629,
+# 512 -> 0.617, 1024 -> 0.631 per cfg2 layer; cfg4 7.97 / 7.22 / 6.87 / 6.70 / 6.67 ms
+DEFAULT_NNZ_PER_PART = 512
 
 
 def _np_i64(a):

@@ -179,6 +179,33 @@ def test_stats_grads_match_oracle(Fn, m, n, d, normalize, sym):
     _gclose(bt.grad, g2 + d_bn, rel=2e-4)
 
 
+@pytest.mark.parametrize("m,n,d,temp", [(300, 300, 64, 0.2), (1000, 257, 64, 0.05), (97, 4100, 128, 0.5), (64, 64, 32, 0.1)])
+def test_one_pass_column_lse_matches_two_pass_and_oracle(Fn, m, n, d, temp):
+    """gcl.py:34 `cross_entropy(sim.T)`: column LSE from the same pass (atomics) vs the swapped-role
+    second pass (deterministic) vs the float64 oracle."""
+    rng = np.random.default_rng(m + n)
+    a = rng.standard_normal((m, d)).astype(np.float32)
+    b = rng.standard_normal((n, d)).astype(np.float32)
+    at, bt = Fn._pad_dim(torch.from_numpy(a).cuda()).contiguous(), Fn._pad_dim(torch.from_numpy(b).cuda()).contiguous()
+    sa, sb = Fn.row_inv_norm(at), Fn.row_inv_norm(bt)
+    lse1, col1 = Fn.infonce_lse_raw(at, sa, bt, sb, 1 / temp, col_bound=1.0001 / temp)
+    col2 = Fn.infonce_lse_raw(bt, sb, at, sa, 1 / temp)
+    _, s = O.row_lse_scores(a, b, 1 / temp, True)
+    ref_col = np.log(np.exp(s - s.max(0)).sum(0)) + s.max(0)
+    np.testing.assert_allclose(col1.cpu().numpy(), ref_col, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(col2.cpu().numpy(), ref_col, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(lse1.cpu().numpy(), O.row_lse_scores(a, b, 1 / temp, True)[0], rtol=1e-5, atol=1e-5)
+    try:
+        Fn.COL_DETERMINISTIC = True
+        x, y = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+        if m <= n:
+            o1 = Fn.infonce_stats(x, y, None, temp, True, want_col=True)
+            o2 = Fn.infonce_stats(x, y, None, temp, True, want_col=True)
+            assert torch.equal(o1[2], o2[2])
+    finally:
+        Fn.COL_DETERMINISTIC = False
+
+
 def test_info_nce_loss_round_trip_properties(Ls):
     """Size-independent checks at a size the dense formulation cannot allocate comfortably
     (100K x 100K logits = 40 GB): identical views give lse_i >= pos_i = 1/temp, the loss is

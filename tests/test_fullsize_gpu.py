@@ -1,0 +1,86 @@
+"""Parity at BASELINE.json's full single-GPU sizes (cfg2 / cfg3: 1M users x 100K items, 10M
+interactions, nnz = 20M, d = 64, B = 2048) against the C restatement of the reference arithmetic
+(oracle/oracle.c, fp32 like the CPU PyTorch path), plus size-independent properties.  The graphs come
+from the bench's device generator (same recipe as oracle_np.synthetic_interactions)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle_c as C
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cfg2():
+    import bench
+    import recommendation_amd as ra
+    dev = torch.device("cuda", 0)
+    wl = bench.WORKLOADS["cfg2"]
+    users, items = bench.synth_interactions_device(wl["users"], wl["items"], wl["edges"], bench.SEED, dev)
+    graph = ra.CsrGraph.bipartite_sym_norm(users, items, wl["users"], wl["items"], dev)
+    n = wl["users"] + wl["items"]
+    x0 = torch.empty(n, 64, device=dev)
+    torch.nn.init.xavier_uniform_(x0, generator=torch.Generator(device=dev).manual_seed(0))
+    return dict(graph=graph, x0=x0, n_u=wl["users"], n_i=wl["items"], users=users, items=items)
+
+
+def test_cfg2_three_layer_propagation_matches_c_oracle(cfg2):
+    """BASELINE configs[1]: LightGCN 3-layer d=64 over the 20M-nnz operator, every output element."""
+    from recommendation_amd import functional as Fn
+    g, x0 = cfg2["graph"], cfg2["x0"]
+    assert g.nnz == 20_000_000
+    # integer structure: sorted by (row, col), symmetric, every pair once
+    rows = torch.repeat_interleave(torch.arange(g.n_rows, device=x0.device), g.rowptr[1:] - g.rowptr[:-1])
+    key = rows * g.n_rows + g.col
+    assert bool((key[1:] > key[:-1]).all())
+    assert torch.equal(torch.sort(g.col.to(torch.int64) * g.n_rows + rows).values, key)
+    with torch.no_grad():
+        final, layers = Fn.lightgcn_propagate(g, x0, 3, combine="mean", return_layers=True)
+    ref = C.lightgcn_propagate(g.rowptr_host, g.col.cpu().numpy(), g.val.cpu().numpy(), x0.cpu().numpy(), 3, "mean")
+    got = final.cpu().numpy()
+    scale = np.abs(ref).max()
+    assert np.abs(got - ref).max() <= 1e-5 * scale
+    # row-sum identity on the last layer input: A 1 = rowsum(val)
+    ones = Fn.spmm(g, torch.ones_like(x0))
+    rowsum = torch.zeros(g.n_rows, device=x0.device, dtype=torch.float64).index_add_(0, rows, g.val.double())
+    assert float((ones[:, 0].double() - rowsum).abs().max()) <= 1e-5 * float(rowsum.max())
+
+
+def test_cfg3_structure_contrast_matches_c_oracle(cfg2):
+    """BASELINE configs[2] shape (ncl.py:358-367): 2048 anchors against ALL 1M user rows + 100K item rows."""
+    from recommendation_amd import functional as Fn
+    x0, n_u = cfg2["x0"], cfg2["n_u"]
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    ctx = x0 + 0.05 * torch.randn(x0.shape, device="cuda", generator=gen)
+    uidx = torch.randint(0, n_u, (2048,), device="cuda", generator=gen)
+    with torch.no_grad():
+        lse, pos = Fn.infonce_stats(ctx[:n_u][uidx], x0[:n_u], uidx, 0.1, True)
+    # the C oracle over 2048 x 1M pairs takes ~10 s of host time: check a 256-anchor sample
+    sel = torch.arange(0, 2048, 8, device="cuda")
+    ref_lse, ref_pos = C.row_lse(ctx[:n_u][uidx][sel].cpu().numpy(), x0[:n_u].cpu().numpy(), uidx[sel].cpu().numpy(), 10.0, True)
+    np.testing.assert_allclose(lse[sel].cpu().numpy(), ref_lse, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(pos[sel].cpu().numpy(), ref_pos, rtol=1e-5, atol=2e-5)
+    assert bool((lse >= pos).all())            # the positive is one of the summed terms
+
+
+def test_cfg2_full_batch_bpr_and_sampler(cfg2):
+    """lightgcn.py:86-108 full batch (B = E = 10M): BPR value vs the C oracle; negatives never hit a
+    training positive across all 10M slots."""
+    from recommendation_amd import functional as Fn
+    g, x0, n_u, n_i = cfg2["graph"], cfg2["x0"], cfg2["n_u"], cfg2["n_i"]
+    users, items = cfg2["users"], cfg2["items"]
+    rowptr_u = g.rowptr[: n_u + 1].contiguous()
+    items_u = (g.col[: int(rowptr_u[-1])] - n_u).contiguous()
+    neg = Fn.neg_sample(rowptr_u, items_u, users, 1, n_i, 2025, 0, 101)
+    assert int(neg.min()) >= 0 and int(neg.max()) < n_i
+    pos_keys = torch.sort(users * n_i + items).values
+    hit = torch.searchsorted(pos_keys, users * n_i + neg)
+    hit = pos_keys[hit.clamp(max=pos_keys.numel() - 1)] == users * n_i + neg
+    assert not bool(hit.any())
+    ut, it = x0[:n_u].contiguous(), x0[n_u:].contiguous()
+    with torch.no_grad():
+        sums = Fn.bpr_sums(ut, it, users, items, neg, Fn.BPR_LOG_SIGMOID)
+    ref = C.bpr_loss(ut.cpu().numpy(), it.cpu().numpy(), users.cpu().numpy(), items.cpu().numpy(), neg.cpu().numpy(), 2)
+    assert float(sums[0]) / users.numel() == pytest.approx(ref, rel=1e-5)
+    assert float(sums[4]) == 0.0

@@ -1,0 +1,112 @@
+"""NCLModel with the reference's interface (ncl.py:282-394), every per-step stage on the HIP path:
+
+    NCLModel(conf, train_set, test_set).train()  ->  {'Hit Ratio': .., 'Precision': .., 'Recall': .., 'NDCG': ..}
+
+Stage by stage (reference line -> here):
+    Interaction / LGCNEncoder            ncl.py:46-88, 397-422   encoders.py (gcr_coo_to_csr, gcr_spmm_csr_f32)
+    next_batch_pairwise                  ncl.py:91-114            sampler.py  (gcr_neg_sample)
+    e_step / run_kmeans (faiss)          ncl.py:340-356           kmeans.py   (gcr_kmeans_*; parity with faiss unpinned)
+    bpr_loss, l2_reg_loss                ncl.py:116-123           losses.py   (gcr_bpr_*)
+    ssl_layer_loss, ProtoNCE_loss        ncl.py:358-375           losses.py   (gcr_infonce_*)
+    test / evaluate                      ncl.py:253-264, 377-384  evaluate.py (gcr_score_rows_f32, gcr_topk_masked_f32)
+The tuner, logging and result files around it are out of scope.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import losses as Ls
+from .encoders import Interaction, LGCNEncoder
+from .evaluate import ranking_evaluation, test as rank_test
+from .kmeans import run_kmeans
+from .sampler import next_batch_pairwise
+
+
+class NCLModel:
+    def __init__(self, conf, train_set, test_set, device=None, seed=0):
+        self.config = conf
+        self.model_name = conf.get("model", {}).get("name", "NCL")
+        self.ranking = conf.get("item.ranking.topN", [10, 20, 30, 50])
+        self.topN = [int(n) for n in self.ranking]
+        self.max_N = max(self.topN)
+        self.data = Interaction(conf, train_set, test_set, device=device)
+        args = conf["NCL"]
+        self.n_layers = args["n_layers"]
+        self.ssl_temp = args["tau"]
+        self.ssl_reg = args["ssl_reg"]
+        self.proto_reg = args["proto_reg"]
+        self.hyper_layers = args["hyper_layers"]
+        self.alpha = args["alpha"]
+        self.k = args["num_clusters"]
+        self.batch_size = conf.get("batch.size", 2048)
+        self.emb_size = conf.get("embedding.size", 64)
+        self.lRate = conf.get("learning.rate", 0.001)
+        self.reg = conf.get("reg.lambda", 0.0001)
+        self.max_epoch = conf.get("max.epoch", 1)
+        self.seed = seed
+        self.model = LGCNEncoder(self.data, self.emb_size, self.n_layers)
+        self.user_centroids = self.user_2cluster = self.item_centroids = self.item_2cluster = None
+        self.bestPerformance = []
+
+    # ncl.py:340-356
+    def e_step(self):
+        with torch.no_grad():
+            user_emb, item_emb, _ = self.model()
+            self.user_centroids, self.user_2cluster = run_kmeans(user_emb.contiguous(), self.k, seed=self.seed)
+            self.item_centroids, self.item_2cluster = run_kmeans(item_emb.contiguous(), self.k, seed=self.seed + 1)
+
+    # ncl.py:358-367
+    def ssl_layer_loss(self, context, initial, user, item):
+        return Ls.ssl_layer_loss(context, initial, user, item, self.data.user_num, self.ssl_temp, self.ssl_reg, self.alpha)
+
+    # ncl.py:369-375
+    def ProtoNCE_loss(self, initial_emb, user_idx, item_idx):
+        return Ls.ProtoNCE_loss(initial_emb, user_idx, item_idx, self.data.user_num, self.user_centroids,
+                                self.user_2cluster, self.item_centroids, self.item_2cluster, self.ssl_temp,
+                                self.proto_reg, self.batch_size)
+
+    def train_step(self, batch, optimizer):
+        """One iteration of the loop body ncl.py:311-329."""
+        user_idx, pos_idx, neg_idx = batch
+        rec_user_emb, rec_item_emb, emb_list = self.model()
+        user_emb, pos_emb, neg_emb = rec_user_emb[user_idx], rec_item_emb[pos_idx], rec_item_emb[neg_idx]
+        rec_loss = Ls.bpr_loss(user_emb, pos_emb, neg_emb)
+        initial_emb = emb_list[0]
+        context_emb = emb_list[-1] if self.hyper_layers * 2 >= len(emb_list) else emb_list[self.hyper_layers * 2]
+        ssl_loss = self.ssl_layer_loss(context_emb, initial_emb, user_idx, pos_idx)
+        self.e_step()                                                       # ncl.py:324 (every batch, Q8)
+        proto_loss = self.ProtoNCE_loss(initial_emb, user_idx, pos_idx)
+        total = rec_loss + Ls.l2_reg_loss(self.reg, user_emb, pos_emb, neg_emb) / self.batch_size + ssl_loss + proto_loss
+        optimizer.zero_grad()
+        total.backward()
+        optimizer.step()
+        return rec_loss, ssl_loss, proto_loss, total
+
+    def train(self):
+        optimizer = torch.optim.Adam(self.model.parameters(), lr=self.lRate)
+        self.model.train()
+        for epoch in range(self.max_epoch):
+            self.e_step()
+            batches = next_batch_pairwise(self.data, self.batch_size, seed=self.seed, epoch=epoch)
+            for n, batch in enumerate(batches):
+                rec, ssl, proto, total = self.train_step(batch, optimizer)
+                if (n + 1) % 100 == 0:
+                    print(f"Batch {n + 1}: Rec_loss={rec.item():.4f}, ssl_loss={ssl.item():.4f}, "
+                          f"Proto_loss={proto.item():.4f}, Total_loss={total.item():.4f}")
+        self.model.eval()
+        with torch.no_grad():
+            self.user_emb, self.item_emb, _ = self.model()
+        return self.evaluate()
+
+    def test(self):
+        return rank_test(self.data, self.user_emb.contiguous(), self.item_emb.contiguous(), self.max_N)
+
+    def evaluate(self):
+        metrics = ranking_evaluation(self.data.test_set, self.test(), self.topN)
+        print("Detailed TopN Evaluation :")
+        print("".join(metrics))
+        return {k: float(v) for m in metrics[1:] if ":" in m for k, v in [m.split(":", 1)]}
+
+    def predict(self, u):
+        uid = self.data.get_user_id(u)
+        return torch.matmul(self.user_emb[uid], self.item_emb.T).cpu().numpy()

@@ -170,7 +170,7 @@ struct Carve {
 size_t sort_temp_bytes(int64_t n) {
   size_t bytes = 0;
   int64_t* k = nullptr;
-  rocprim::radix_sort_pairs(nullptr, bytes, k, k, k, k, (size_t)n, 0, 64, (hipStream_t)0);
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, k, k, (size_t)n, 0, 64, (hipStream_t)0);
   return bytes;
 }
 
@@ -178,7 +178,7 @@ size_t rbk_temp_bytes(int64_t n) {
   size_t bytes = 0;
   int64_t* k = nullptr;
   float* v = nullptr;
-  rocprim::reduce_by_key(nullptr, bytes, k, v, (size_t)n, k, v, k, rocprim::plus<float>(), rocprim::equal_to<int64_t>(),
+  (void)rocprim::reduce_by_key(nullptr, bytes, k, v, (size_t)n, k, v, k, rocprim::plus<float>(), rocprim::equal_to<int64_t>(),
                          (hipStream_t)0);
   return bytes;
 }

@@ -195,3 +195,33 @@ def test_linearity_and_determinism_at_scale(ra):
     rowsum = torch.zeros(n, device="cuda", dtype=torch.float64).index_add_(0, rows, graph.val.double())
     assert float((ones[:, 0].double() - rowsum).abs().max()) <= 1e-5 * float(rowsum.abs().max())
     assert float((ones - ones[:, :1]).abs().max()) == 0.0
+
+
+def test_hipgraph_capture_and_replay(ra):
+    """The C ABI allocates nothing and never synchronises, so a whole cfg1 forward step (2-layer
+    propagation + full-batch BPR, lightgcn.py:85-108) can be captured into a hipGraph and replayed."""
+    u, i = O.synthetic_interactions(943, 1682, 80000, seed=20250919)
+    g = ra.CsrGraph.bipartite_sym_norm(u, i, 943, 1682, "cuda")
+    x = torch.randn(943 + 1682, 64, device="cuda")
+    ut, it = torch.from_numpy(u).cuda(), torch.from_numpy(i).cuda()
+    jt = torch.randint(0, 1682, (80000,), device="cuda")
+
+    def step():
+        f = ra.functional.lightgcn_propagate(g, x, 2, combine="sum")
+        return ra.functional.bpr_sums(f[:943].contiguous(), f[943:].contiguous(), ut, it, jt, 2)
+
+    with torch.no_grad():
+        ref = step().clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = step()
+        x.mul_(2.0)                       # new input values, same buffers
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, step())   # replay == eager on the updated input
+        assert not torch.equal(out, ref)

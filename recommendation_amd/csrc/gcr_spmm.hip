@@ -165,36 +165,51 @@ __global__ __launch_bounds__(256) void spmm_parts(const int64_t* __restrict__ de
   }
 }
 
-// one wave per long row: add its chunk partials in chunk order, then the common epilogue
+// one 4-wave block per long row: wave w adds chunk partials w, w+4, ... (4 loads in flight each),
+// the four wave sums are combined through LDS in wave order, then the common epilogue.  The order
+// of additions is fixed by the plan, so the result stays bitwise reproducible.  (One wave per row
+// took 24 us per cfg2 layer — hub rows have ~100 chunks — i.e. 3 % of the layer.)
 template <int NV, bool D64>
 __global__ __launch_bounds__(256) void spmm_long_rows(const int32_t* __restrict__ long_row,
                                                       const int32_t* __restrict__ long_slot0, int64_t n_long,
                                                       const float* __restrict__ partials, int d, Epilogue ep) {
+  __shared__ float red[3][NV * 64];
   const int lane = threadIdx.x & 63;
-  const int64_t i = (int64_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));
-  if (i >= n_long) return;
+  const int wave = threadIdx.x >> 6;
+  const int64_t i = blockIdx.x;
   const int s0 = long_slot0[i], s1 = long_slot0[i + 1];
   float acc[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) acc[v] = 0.f;
-  int s = s0;
-  for (; s + 4 <= s1; s += 4) {
+  int s = s0 + wave;
+  for (; s + 12 < s1; s += 16) {
     float t[4][NV];
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
       for (int v = 0; v < NV; ++v)
-        t[u][v] = (D64 || lane + 64 * v < d) ? partials[(int64_t)(s + u) * d + lane + 64 * v] : 0.f;
+        t[u][v] = (D64 || lane + 64 * v < d) ? partials[(int64_t)(s + 4 * u) * d + lane + 64 * v] : 0.f;
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
       for (int v = 0; v < NV; ++v) acc[v] += t[u][v];
   }
-  for (; s < s1; ++s)
+  for (; s < s1; s += 4)
 #pragma unroll
     for (int v = 0; v < NV; ++v)
       if (D64 || lane + 64 * v < d) acc[v] += partials[(int64_t)s * d + lane + 64 * v];
-  store_row<NV, D64>(ep, (int64_t)long_row[i], d, lane, acc);
+  if (wave > 0) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) red[wave - 1][v * 64 + lane] = acc[v];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+      for (int v = 0; v < NV; ++v) acc[v] += red[w][v * 64 + lane];
+    store_row<NV, D64>(ep, (int64_t)long_row[i], d, lane, acc);
+  }
 }
 
 __global__ void csr_validate_kernel(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
@@ -232,7 +247,7 @@ int32_t launch_spmm(const int64_t* desc, int64_t n_parts, const int32_t* long_ro
     if (st != GCR_OK) return st;
   }
   if (n_long > 0) {
-    hipLaunchKernelGGL((spmm_long_rows<NV, D64>), dim3((unsigned)((n_long + 3) / 4)), dim3(256), 0, stream,
+    hipLaunchKernelGGL((spmm_long_rows<NV, D64>), dim3((unsigned)n_long), dim3(256), 0, stream,
                        long_row, long_slot0, n_long, partials, d, ep);
     return GCR_LAUNCH_STATUS();
   }

@@ -115,13 +115,13 @@ __device__ __forceinline__ void score_tile(const float* __restrict__ tile, int i
 
 // online-softmax update with one finished score tile; `rem` = table rows left from this lane's
 // first accumulator row (n_rows - j0 - 4h): rows at or past it are masked out (ragged last tile).
-template <int NT>
+template <int NT, bool MASK>
 __device__ __forceinline__ void lse_update(const f32x16 (&acc)[NT], int rem, float (&m_run)[NT], float (&l_run)[NT]) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     float v[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = ((r & 3) + 8 * (r >> 2) < rem) ? acc[t][r] : -INFINITY;
+    for (int r = 0; r < 16; ++r) v[r] = (!MASK || (r & 3) + 8 * (r >> 2) < rem) ? acc[t][r] : -INFINITY;
     float tmax = v[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, v[r]);
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256, (D <= 64 ? 3 : 2)) void infonce_fwd_kernel(con
                                                              const float* __restrict__ b_scale, int64_t n_rows,
                                                              float scale2, int nsplit, int64_t tiles_per_split,
                                                              float2* __restrict__ part, float* __restrict__ col_sum,
-                                                             float col_bound2) {
+                                                             float col_bound2, int force_mask) {
   using S = Shape<D>;
   __shared__ __align__(16) float lds[2][kTileJ * S::STRIDE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -204,7 +204,10 @@ __global__ __launch_bounds__(256, (D <= 64 ? 3 : 2)) void infonce_fwd_kernel(con
     stage_load<D>(b, b_scale, n_rows, nxt * kTileJ, tid, regs);
     f32x16 acc[S::NT];
     score_tile<D>(lds[cur], i32, h, bfrag, acc);
-    lse_update<S::NT>(acc, rows_left(n_rows, tt * kTileJ, h), m_run, l_run);
+    if (force_mask || (tt + 1) * kTileJ > n_rows)   // only the table's ragged last tile pays for the row mask
+      lse_update<S::NT, true>(acc, rows_left(n_rows, tt * kTileJ, h), m_run, l_run);
+    else
+      lse_update<S::NT, false>(acc, 64, m_run, l_run);
     if (COLSUM) {
       const int64_t j0 = tt * kTileJ;
 #pragma unroll
@@ -595,14 +598,16 @@ int32_t launch_fwd(const float* a, const float* a_scale, int64_t m, const float*
   const FwdPlan p = plan_fwd(m, n, Shape<D>::ANCHORS_PER_BLOCK, D <= 64 ? 768 : 512);
   float2* part = reinterpret_cast<float2*>(workspace);
   const dim3 grid((unsigned)(p.m_blocks * p.nsplit));
+  const char* fm = getenv("GCR_INFONCE_FORCE_MASK");   // A/B knob
+  const int force_mask = fm != nullptr && fm[0] == '1';
   if (col_sum != nullptr) {
     hipError_t err = hipMemsetAsync(col_sum, 0, sizeof(float) * (size_t)n, s);
     if (err != hipSuccess) return gcr_hip_status(err);
     hipLaunchKernelGGL((infonce_fwd_kernel<D, true>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale, n,
-                       inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part, col_sum, col_bound * kLog2e);
+                       inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part, col_sum, col_bound * kLog2e, force_mask);
   } else {
     hipLaunchKernelGGL((infonce_fwd_kernel<D, false>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale, n,
-                       inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part, col_sum, 0.f);
+                       inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part, col_sum, 0.f, force_mask);
   }
   int32_t st = GCR_LAUNCH_STATUS();
   if (st != GCR_OK) return st;

@@ -100,16 +100,25 @@ __global__ void rowptr_fill_dev_n_kernel(const int64_t* __restrict__ key, const 
 }
 
 // one thread per row: dinv[r] = (sum of the row's values)^-1/2, inf -> 0   (selfcf.py:243-245)
+// (one 16-lane group per row with a fixed-shape tree sum: a thread per row spent 3.6 ms on the
+// 50K-entry hub rows of cfg2; row sums of the 0/1/2-valued adjacency are exact in any order)
 __global__ void row_dinv_kernel(const int64_t* __restrict__ rowptr, const float* __restrict__ val, int64_t n_rows,
                                 float* __restrict__ dinv) {
-  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * blockDim.x) {
+  const int l16 = threadIdx.x & 15;
+  for (int64_t r = (int64_t)blockIdx.x * (blockDim.x / 16) + (threadIdx.x >> 4); r < n_rows;
+       r += (int64_t)gridDim.x * (blockDim.x / 16)) {
     float s = 0.f;
-    if (val != nullptr)
-      for (int64_t e = rowptr[r]; e < rowptr[r + 1]; ++e) s += val[e];
-    else
+    if (val != nullptr) {
+      for (int64_t e = rowptr[r] + l16; e < rowptr[r + 1]; e += 16) s += val[e];
+      s += __shfl_xor(s, 8, 16);
+      s += __shfl_xor(s, 4, 16);
+      s += __shfl_xor(s, 2, 16);
+      s += __shfl_xor(s, 1, 16);
+    } else {
       s = (float)(rowptr[r + 1] - rowptr[r]);
+    }
     const float d = 1.0f / sqrtf(s);   // s == 0 -> inf -> 0, like np.power(0, -0.5) then isinf -> 0
-    dinv[r] = isinf(d) ? 0.f : d;
+    if (l16 == 0) dinv[r] = isinf(d) ? 0.f : d;
   }
 }
 
@@ -117,10 +126,17 @@ __global__ void row_dinv_kernel(const int64_t* __restrict__ rowptr, const float*
 __global__ void scale_values_kernel(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                     const float* __restrict__ val, const float* __restrict__ dinv_row,
                                     const float* __restrict__ dinv_col, int64_t n_rows, float* __restrict__ val_out) {
-  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * blockDim.x) {
-    const float dr = dinv_row[r];
-    for (int64_t e = rowptr[r]; e < rowptr[r + 1]; ++e)
-      val_out[e] = dr * (val != nullptr ? val[e] : 1.0f) * dinv_col[col[e]];
+  // one thread per non-zero; its row by binary search in rowptr (a thread per row spent 12.5 ms on
+  // cfg2's hub rows)
+  const int64_t nnz = rowptr[n_rows];
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * blockDim.x) {
+    int64_t lo = 0, hi = n_rows;            // largest r with rowptr[r] <= e
+    while (hi - lo > 1) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (rowptr[mid] <= e) lo = mid;
+      else hi = mid;
+    }
+    val_out[e] = dinv_row[lo] * (val != nullptr ? val[e] : 1.0f) * dinv_col[col[e]];
   }
 }
 
@@ -261,13 +277,13 @@ extern "C" int32_t gcr_csr_sym_norm_f32(const int64_t* rowptr, const int32_t* co
   GCR_CHECK_ARG(rowptr && col && dinv_row && val_out);
   GCR_CHECK_ARG(rowptr_t == nullptr || dinv_col != nullptr);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(row_dinv_kernel, dim3(grid_for(n_rows)), dim3(kBlock), 0, s, rowptr, val, n_rows, dinv_row);
+  hipLaunchKernelGGL(row_dinv_kernel, dim3(grid_for(n_rows * 16)), dim3(kBlock), 0, s, rowptr, val, n_rows, dinv_row);
   const float* dcol = dinv_row;   // square symmetric operator: column scale = row scale
   if (rowptr_t != nullptr) {      // rectangular / asymmetric: column sums come from the transposed CSR
-    hipLaunchKernelGGL(row_dinv_kernel, dim3(grid_for(n_cols)), dim3(kBlock), 0, s, rowptr_t, val_t, n_cols, dinv_col);
+    hipLaunchKernelGGL(row_dinv_kernel, dim3(grid_for(n_cols * 16)), dim3(kBlock), 0, s, rowptr_t, val_t, n_cols, dinv_col);
     dcol = dinv_col;
   }
-  hipLaunchKernelGGL(scale_values_kernel, dim3(grid_for(n_rows)), dim3(kBlock), 0, s, rowptr, col, val, dinv_row, dcol,
+  hipLaunchKernelGGL(scale_values_kernel, dim3(16384), dim3(kBlock), 0, s, rowptr, col, val, dinv_row, dcol,
                      n_rows, val_out);
   return GCR_LAUNCH_STATUS();
 }

@@ -13,15 +13,18 @@
 //   * column ids / values of 64 non-zeros are fetched with one coalesced vector load each and
 //     handed out with v_readlane (scalar), so all control flow (row boundaries, edge mask,
 //     tails) is scalar and divergence-free;
-//   * UNR gathers are issued back to back before the first FMA to keep >= UNR x 256 B per wave
-//     in flight; at 8 waves/SIMD that is >= 64 KiB per CU;
+//   * UNR (16 at d <= 64) gathers are issued back to back before the first FMA to keep >= 4 KiB per
+//     wave in flight; at 8 waves/SIMD that is >= 128 KiB per CU;
 //   * long rows: chunk partial sums go to a workspace and are added in chunk order by
 //     spmm_long_rows (deterministic; no float atomics).
 #include "gcr_common.h"
 
 namespace {
 
-constexpr int UNR = 8;
+// gathers in flight per wave before the first FMA: interleaved A/B on MI355X (scripts/perf_spmm_ab.py)
+// 4 -> 0.647 ms, 8 -> 0.612 ms, 16 -> 0.598 ms per cfg2 layer (cfg4: 7.52 / 7.06 / 6.91 ms)
+template <int NV>
+constexpr int unroll_for() { return NV == 1 ? 16 : 8; }
 
 struct Epilogue {
   float val_scale;
@@ -62,7 +65,7 @@ __device__ __forceinline__ void store_row(const Epilogue& ep, int64_t row, int d
   }
 }
 
-template <int NV, bool D64, bool HAS_VAL, bool MASKED>
+template <int NV, bool D64, bool HAS_VAL, bool MASKED, int UNR>
 __global__ __launch_bounds__(256) void spmm_parts(const int64_t* __restrict__ desc, int64_t n_parts,
                                                   const int64_t* __restrict__ rowptr,
                                                   const int32_t* __restrict__ col,
@@ -233,8 +236,8 @@ int32_t launch_spmm(const int64_t* desc, int64_t n_parts, const int32_t* long_ro
   const unsigned blocks = (unsigned)((n_parts + 3) / 4);
   if (blocks > 0) {
 #define GCR_SPMM_LAUNCH(HV, MK)                                                                             \
-  hipLaunchKernelGGL((spmm_parts<NV, D64, HV, MK>), dim3(blocks), dim3(256), 0, stream, desc, n_parts, rowptr, \
-                     col, val, keep_bits, x, d, ep, partials)
+  hipLaunchKernelGGL((spmm_parts<NV, D64, HV, MK, unroll_for<NV>()>), dim3(blocks), dim3(256), 0, stream, desc, n_parts, \
+                     rowptr, col, val, keep_bits, x, d, ep, partials)
     if (val != nullptr) {
       if (keep_bits != nullptr) GCR_SPMM_LAUNCH(true, true);
       else GCR_SPMM_LAUNCH(true, false);

@@ -20,12 +20,14 @@ n = wl["users"] + wl["items"]
 d = 64
 x = torch.randn(n, d, device=dev)
 y = torch.empty_like(x)
-variants = [64, 128, 256, 512, 1024]
+variants = [512]
+unrs = ["4", "8", "16"]
 graphs = {L: ra.CsrGraph(rp, c, v, n, n, dev, symmetric=True, nnz_per_part=L, validate=False) for L in variants}
-res = {L: [] for L in variants}
+res = {L: [] for L in unrs}
 for rnd in range(7):
-    for L in variants:
-        g = graphs[L]
+    for L in unrs:
+        os.environ["GCR_SPMM_UNR"] = L
+        g = graphs[512]
         if rnd == 0:
             Fn.spmm_into(g, x, y=y)
             torch.cuda.synchronize()
@@ -36,10 +38,9 @@ for rnd in range(7):
         e1.record()
         torch.cuda.synchronize()
         res[L].append(e0.elapsed_time(e1) / 5)
-nnz = graphs[256].nnz
+nnz = graphs[512].nnz
 bytes_alg = nnz * 264 + n * 260
 print(name, "nnz", nnz)
-for L in variants:
+for L in unrs:
     med = statistics.median(res[L])
-    print(f"  nnz_per_part {L:5d}: parts {graphs[L].plan.n_parts:8d} split rows {graphs[L].plan.n_long:6d}  "
-          f"median {med:.4f} ms  min {min(res[L]):.4f} ms  {bytes_alg / med / 1e9:.0f} GB/s alg")
+    print(f"  UNR {L:>3s}: median {med:.4f} ms  min {min(res[L]):.4f} ms  {bytes_alg / med / 1e6:.0f} GB/s alg")

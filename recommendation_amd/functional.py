@@ -99,6 +99,15 @@ class _Propagate(torch.autograd.Function):
     def forward(ctx, x0, graph, n_layers, scale, want_layers):
         ctx.graph, ctx.n_layers, ctx.scale, ctx.want_layers = graph, n_layers, scale, want_layers
         x0 = x0.contiguous()
+        if not want_layers and n_layers > 0:
+            # Horner form  sum_k A^k x0 = x0 + A (x0 + A (x0 + ...)): every layer reads x0 and writes ONE
+            # [N, d] array (no separate layer output + running sum): one N x d write less per layer
+            z = x0
+            for k in range(n_layers):
+                nxt = torch.empty_like(x0)
+                spmm_into(graph, z, acc_in=x0, acc_out=nxt, acc_scale=scale if k == n_layers - 1 else 1.0)
+                z = nxt
+            return z
         cur, acc = x0, x0
         layers = []
         for k in range(n_layers):

@@ -100,32 +100,32 @@ def sharded_propagate_raw(g: ShardedBipartiteGraph, x_user, x_item_shard, n_laye
     world = g.world
     d = x_user.shape[1]
     dev = x_user.device
-    acc_u, acc_i = x_user, x_item_shard.clone()
-    cur_u, cur_i = x_user, x_item_shard
-    x_item_full = torch.empty(g.items_padded, d, dtype=torch.float32, device=dev)
+    if n_layers == 0:
+        return x_user * scale, x_item_shard * scale
+    # Horner form z <- x + A z (z_0 = x): after K steps z = sum_{k<=K} A^k x; both halves of a step
+    # read the OLD z, every step writes one array per side (no separate layer output + running sum)
+    z_u, z_i = x_user, x_item_shard
+    z_item_full = torch.empty(g.items_padded, d, dtype=torch.float32, device=dev) if world > 1 else None
     for k in range(n_layers):
-        last = k == n_layers - 1
+        s = scale if k == n_layers - 1 else 1.0
         if world > 1:
-            h_ag = _all_gather(x_item_full, cur_i.contiguous(), g.group, overlap)
+            h_ag = _all_gather(z_item_full, z_i.contiguous(), g.group, overlap)
         else:
-            x_item_full = cur_i
-            h_ag = None
-        part_i, _ = spmm(g.r_iu, cur_u)                                   # item side: local users only
+            z_item_full, h_ag = z_i, None
+        part_i, _ = spmm(g.r_iu, z_u)                                     # item side: local users only
         if h_ag is not None:
             h_ag.wait()
-        y_i = torch.empty_like(cur_i)
         if world > 1:
+            y_i = torch.empty_like(z_i)
             h_rs = _reduce_scatter(y_i, part_i, g.group, overlap)
         else:
             y_i, h_rs = part_i, None
-        y_u, acc_u = spmm(g.r_ui, x_item_full, acc_in=acc_u, acc_scale=scale if last else 1.0, want_y=not last)
+        _, z_u_next = spmm(g.r_ui, z_item_full, acc_in=x_user, acc_scale=s, want_y=False)
         if h_rs is not None:
             h_rs.wait()
-        acc_i = acc_i + y_i
-        cur_u, cur_i = y_u, y_i
-    if n_layers == 0:
-        acc_u = x_user * scale
-    return acc_u, acc_i * scale
+        z_i = (x_item_shard + y_i) * s if s != 1.0 else x_item_shard + y_i
+        z_u = z_u_next
+    return z_u, z_i
 
 
 class _ShardedPropagate(torch.autograd.Function):

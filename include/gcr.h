@@ -271,6 +271,12 @@ int32_t gcr_csr_sym_norm_f32(const int64_t* rowptr, const int32_t* col, const fl
                              int64_t n_rows, int64_t n_cols, const int64_t* rowptr_t, const float* val_t,
                              float* dinv_row, float* dinv_col, float* val_out, void* stream);
 
+/* val_out[e] = val[e] / (row sum), 1/0 -> 0: the non-square branch of Graph.normalize_graph_mat
+ * (selfcf.py:250-254 = ncl.py:37-41), used for MHCN's row-normalised R / H operators
+ * (univariate/mhcn.py:340-368,401-402).  val == NULL = ones.  rinv [n_rows] is scratch. */
+int32_t gcr_csr_row_norm_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t n_rows,
+                             float* rinv, float* val_out, void* stream);
+
 /*
  * Keep bitmap with EXACTLY n_keep of nnz bits set, a uniformly random subset without replacement
  * (64-bit Philox key per edge, stable radix sort, first n_keep win):

@@ -291,8 +291,29 @@ def gen_eval():
     print("wrote eval.json:", "".join(out[:5]).replace("\n", " | "))
 
 
+def gen_rownorm():
+    """tests/golden/rownorm.npz: selfcf.Graph.normalize_graph_mat on a rectangular matrix
+    (selfcf.py:250-254; the same method body as ncl.py:37-41 and the one MHCN uses for R / H)."""
+    import scipy.sparse as sp
+    import selfcf
+    rng = np.random.default_rng(5)
+    n_rows, n_cols, nnz = 60, 35, 500
+    row, col = rng.integers(0, n_rows, nnz), rng.integers(0, n_cols, nnz)
+    row[row == 7] = 8                                   # an empty row -> 1/0 -> 0
+    val = rng.integers(1, 4, nnz).astype(np.float32)
+    a = sp.csr_matrix((val, (row, col)), shape=(n_rows, n_cols), dtype=np.float32)
+    out = selfcf.Graph.normalize_graph_mat(a).tocsr()
+    out.sort_indices()
+    np.savez_compressed(os.path.join(OUT, "rownorm.npz"), row=row, col=col, val=val, n_rows=n_rows, n_cols=n_cols,
+                        indptr=out.indptr.astype(np.int64), indices=out.indices.astype(np.int64),
+                        data=out.data.astype(np.float32))
+    print("wrote rownorm.npz", out.nnz)
+
+
 if __name__ == "__main__":
-    if "--eval" in sys.argv:
+    if "--rownorm" in sys.argv:
+        gen_rownorm()
+    elif "--eval" in sys.argv:
         gen_eval()
     else:
         main()

@@ -47,6 +47,7 @@ SIGNATURES = {
     "gcr_coo_to_csr_workspace_bytes": (c_int64, [c_int64]),
     "gcr_coo_to_csr": (c_int32, [_P, _P, _P, c_int64, c_int64, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gcr_csr_sym_norm_f32": (c_int32, [_P, _P, _P, c_int64, c_int64, _P, _P, _P, _P, _P, _P]),
+    "gcr_csr_row_norm_f32": (c_int32, [_P, _P, _P, c_int64, _P, _P, _P]),
     "gcr_edge_mask_exact_workspace_bytes": (c_int64, [c_int64]),
     "gcr_edge_mask_exact_bits": (c_int32, [c_int64, c_int64, c_uint64, _P, _P, _P]),
 }

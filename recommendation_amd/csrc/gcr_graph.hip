@@ -103,7 +103,7 @@ __global__ void rowptr_fill_dev_n_kernel(const int64_t* __restrict__ key, const 
 // (one 16-lane group per row with a fixed-shape tree sum: a thread per row spent 3.6 ms on the
 // 50K-entry hub rows of cfg2; row sums of the 0/1/2-valued adjacency are exact in any order)
 __global__ void row_dinv_kernel(const int64_t* __restrict__ rowptr, const float* __restrict__ val, int64_t n_rows,
-                                float* __restrict__ dinv) {
+                                float* __restrict__ dinv, bool inverse_not_rsqrt) {
   const int l16 = threadIdx.x & 15;
   for (int64_t r = (int64_t)blockIdx.x * (blockDim.x / 16) + (threadIdx.x >> 4); r < n_rows;
        r += (int64_t)gridDim.x * (blockDim.x / 16)) {
@@ -117,7 +117,8 @@ __global__ void row_dinv_kernel(const int64_t* __restrict__ rowptr, const float*
     } else {
       s = (float)(rowptr[r + 1] - rowptr[r]);
     }
-    const float d = 1.0f / sqrtf(s);   // s == 0 -> inf -> 0, like np.power(0, -0.5) then isinf -> 0
+    // s == 0 -> inf -> 0, like np.power(0, -0.5 | -1) followed by `d_inv[np.isinf(d_inv)] = 0`
+    const float d = inverse_not_rsqrt ? 1.0f / s : 1.0f / sqrtf(s);
     if (l16 == 0) dinv[r] = isinf(d) ? 0.f : d;
   }
 }
@@ -136,7 +137,7 @@ __global__ void scale_values_kernel(const int64_t* __restrict__ rowptr, const in
       if (rowptr[mid] <= e) lo = mid;
       else hi = mid;
     }
-    val_out[e] = dinv_row[lo] * (val != nullptr ? val[e] : 1.0f) * dinv_col[col[e]];
+    val_out[e] = dinv_row[lo] * (val != nullptr ? val[e] : 1.0f) * (dinv_col != nullptr ? dinv_col[col[e]] : 1.0f);
   }
 }
 
@@ -277,14 +278,26 @@ extern "C" int32_t gcr_csr_sym_norm_f32(const int64_t* rowptr, const int32_t* co
   GCR_CHECK_ARG(rowptr && col && dinv_row && val_out);
   GCR_CHECK_ARG(rowptr_t == nullptr || dinv_col != nullptr);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(row_dinv_kernel, dim3(grid_for(n_rows * 16)), dim3(kBlock), 0, s, rowptr, val, n_rows, dinv_row);
+  hipLaunchKernelGGL(row_dinv_kernel, dim3(grid_for(n_rows * 16)), dim3(kBlock), 0, s, rowptr, val, n_rows, dinv_row, false);
   const float* dcol = dinv_row;   // square symmetric operator: column scale = row scale
   if (rowptr_t != nullptr) {      // rectangular / asymmetric: column sums come from the transposed CSR
-    hipLaunchKernelGGL(row_dinv_kernel, dim3(grid_for(n_cols * 16)), dim3(kBlock), 0, s, rowptr_t, val_t, n_cols, dinv_col);
+    hipLaunchKernelGGL(row_dinv_kernel, dim3(grid_for(n_cols * 16)), dim3(kBlock), 0, s, rowptr_t, val_t, n_cols, dinv_col, false);
     dcol = dinv_col;
   }
   hipLaunchKernelGGL(scale_values_kernel, dim3(16384), dim3(kBlock), 0, s, rowptr, col, val, dinv_row, dcol,
                      n_rows, val_out);
+  return GCR_LAUNCH_STATUS();
+}
+
+extern "C" int32_t gcr_csr_row_norm_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t n_rows,
+                                        float* rinv, float* val_out, void* stream) {
+  GCR_CHECK_ARG(n_rows >= 0);
+  if (n_rows == 0) return GCR_OK;
+  GCR_CHECK_ARG(rowptr && col && rinv && val_out);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(row_dinv_kernel, dim3(grid_for(n_rows * 16)), dim3(kBlock), 0, s, rowptr, val, n_rows, rinv, true);
+  hipLaunchKernelGGL(scale_values_kernel, dim3(16384), dim3(kBlock), 0, s, rowptr, col, val, rinv,
+                     (const float*)nullptr, n_rows, val_out);
   return GCR_LAUNCH_STATUS();
 }
 

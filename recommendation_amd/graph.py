@@ -175,6 +175,18 @@ class CsrGraph:
         return cls(rp, c, (dinv[rows] * v * dinv[c]).astype(np.float32), n, n, device, symmetric=True, **kw)
 
     @classmethod
+    def row_normalised(cls, row, col, val, n_rows, n_cols, device, **kw):
+        """Graph.normalize_graph_mat on a NON-square matrix (selfcf.py:250-254 = ncl.py:37-41):
+        D^-1 A with 1/0 -> 0, duplicates summed first (scipy CSR) — MHCN's R and H operators
+        (univariate/mhcn.py:340-368,401-402).  GPU device only."""
+        rp, c, v, _ = coo_to_csr_device(row, col, val, n_rows, n_cols, device, coalesce=True)
+        rinv = torch.empty(n_rows, dtype=torch.float32, device=rp.device)
+        out = torch.empty_like(v)
+        _lib.check(_lib.lib().gcr_csr_row_norm_f32(_lib.dptr(rp), _lib.dptr(c), _lib.dptr(v), n_rows, _lib.dptr(rinv),
+                                                   _lib.dptr(out), _lib.cur_stream(rp.device)), "gcr_csr_row_norm_f32")
+        return cls(rp, c, out, n_rows, n_cols, device, symmetric=False, **kw)
+
+    @classmethod
     def from_edge_index_gcn_norm(cls, edge_index, num_nodes, device, symmetric=False, **kw):
         """lightgcn.py:25 `LGConv()(x, edge_index)`: deg[v] = #edges with target v; w_e =
         deg^-1/2[src] deg^-1/2[dst] (inf -> 0); out[dst] += w_e x[src]  => CSR over rows = dst."""

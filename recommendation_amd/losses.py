@@ -89,3 +89,16 @@ def bpr_gather_loss(user_tab, item_tab, u_idx, i_idx, j_idx, variant=Fn.BPR_NCL)
     straight into the tables.  Returns (mean bpr loss, sum|u|^2, sum|p|^2, sum|n|^2)."""
     sums = Fn.bpr_sums(user_tab, item_tab, u_idx, i_idx, j_idx, variant)
     return sums[0] / max(len(u_idx), 1), sums[1], sums[2], sums[3]
+
+
+def neighbor_discrimination(positive, emb, aug_emb, temperature=0.1):
+    """univariate/sept_social.py:408-420 on already-selected rows (emb = emb[unique_u], aug_emb =
+    aug_user_embeddings[unique_u]): -sum_i log( sum_k exp(<e_i, a_{p_ik}> / t) / sum_j exp(<e_i, a_j> / t) )
+    on normalised rows; `positive` int64 [B', k] are the pseudo-label indices into aug_emb.  The B' x B'
+    denominator is the fused row logsumexp (gcr_infonce_fwd_f32); the k positives per row stay a
+    [B', k] gather."""
+    import torch.nn.functional as F
+    lse, _ = Fn.infonce_stats(emb, aug_emb, None, temperature, normalize=True)
+    e, a = F.normalize(emb, dim=1), F.normalize(aug_emb, dim=1)
+    pos = (e.unsqueeze(1) * a[positive]).sum(2) / temperature
+    return -(torch.logsumexp(pos, dim=1) - lse).sum()

@@ -111,6 +111,8 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("GCR_BENCH_REHEARSE_ONE_GPU") == "1":
+        local_rank = 0      # rehearsal of the N-rank code path on a one-GPU box: ranks share cuda:0 over gloo
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -207,7 +209,10 @@ def main_sharded(args, rank, world, dev, ra):
     from recommendation_amd import distributed as gdist
 
     if not dist.is_initialized():
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if os.environ.get("GCR_BENCH_REHEARSE_ONE_GPU") == "1":
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
     name = args.workload or "cfg2"
     wl = WORKLOADS[name]
     n_u, n_e, k_layers, d = wl["users"], wl["edges"], wl["layers"], args.dim

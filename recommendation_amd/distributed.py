@@ -26,10 +26,10 @@ from . import functional as Fn
 from .graph import CsrGraph
 
 
-def _hip_spmm(graph, x, acc_in=None, acc_scale=1.0, want_y=True):
+def _hip_spmm(graph, x, acc_in=None, acc_scale=1.0, want_y=True, keep_bits=None, val_scale=1.0):
     y = torch.empty(graph.n_rows, x.shape[1], dtype=torch.float32, device=x.device) if want_y else None
     acc = torch.empty(graph.n_rows, x.shape[1], dtype=torch.float32, device=x.device) if acc_in is not None else None
-    Fn.spmm_into(graph, x, y=y, acc_in=acc_in, acc_out=acc, acc_scale=acc_scale)
+    Fn.spmm_into(graph, x, y=y, acc_in=acc_in, acc_out=acc, acc_scale=acc_scale, keep_bits=keep_bits, val_scale=val_scale)
     return y, acc
 
 
@@ -72,8 +72,38 @@ class ShardedBipartiteGraph:
         di[np.isinf(di)] = 0.0
         val = (du[local_uid] * di[iid]).astype(np.float32)
         r_ui = graph_cls.from_coo(local_uid, iid, val, n_local_users, padded, device, coalesce=True, **kw)
-        r_iu = graph_cls.from_coo(iid, local_uid, val, padded, n_local_users, device, coalesce=True, **kw)
+        if torch.device(device).type == "cuda":
+            r_iu = r_ui.t         # device transpose; keeps the nnz correspondence ShardedEdgeDrop needs
+        else:
+            r_iu = graph_cls.from_coo(iid, local_uid, val, padded, n_local_users, device, coalesce=True, **kw)
         return cls(r_ui, r_iu, n_local_users, num_items, per, rank, world, group)
+
+
+class ShardedEdgeDrop:
+    """One augmented view of a rank's blocks: every stored non-zero of the symmetric operator is
+    dropped independently with probability `pe` (gcl.py:18-25 over the directed edge list,
+    buir.py:300-309 over the non-zeros of the normalised adjacency, which also rescales the kept
+    values by 1/(1-pe): `rescale=True`).  (u,i) and (i,u) are separate non-zeros with separate
+    draws, so the masked operator is no longer symmetric: the backward pass runs on its transpose,
+    i.e. each block's structure with the OTHER block's draws, addressed through the nnz
+    correspondence of the device transpose.  Bitmaps come from gcr_edge_mask_bits (counter RNG:
+    a function of (seed, rank, block, nnz id) only)."""
+
+    def __init__(self, g: ShardedBipartiteGraph, pe: float, seed: int, rescale: bool = False):
+        perm = getattr(g.r_iu, "perm_from_transpose", None)
+        if perm is None:
+            raise ValueError("ShardedEdgeDrop needs blocks built on the GPU (r_iu = r_ui.t)")
+        nnz, dev = g.r_ui.nnz, g.r_ui.device
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(nnz, device=dev, dtype=perm.dtype)
+        s_ui = (int(seed) * 0x9E3779B97F4A7C15 + 2 * g.rank + 1) & (2 ** 64 - 1)
+        s_iu = (int(seed) * 0x9E3779B97F4A7C15 + 2 * g.rank + 2) & (2 ** 64 - 1)
+        self.seeds = (s_ui, s_iu)
+        self.ui_fwd = Fn.edge_mask_bits(nnz, pe, s_ui, dev)
+        self.iu_fwd = Fn.edge_mask_bits(nnz, pe, s_iu, dev)
+        self.ui_bwd = Fn.edge_mask_bits(nnz, pe, s_iu, dev, edge_id=inv)      # (R_iu . m_iu)^T on r_ui's structure
+        self.iu_bwd = Fn.edge_mask_bits(nnz, pe, s_ui, dev, edge_id=perm)     # (R_ui . m_ui)^T on r_iu's structure
+        self.val_scale = 1.0 / (1.0 - pe) if rescale else 1.0
 
 
 def _all_gather(full, shard, group, async_op):
@@ -93,11 +123,16 @@ def _reduce_scatter(shard, full, group, async_op):
 
 
 def sharded_propagate_raw(g: ShardedBipartiteGraph, x_user, x_item_shard, n_layers, scale, spmm=_hip_spmm,
-                          overlap=True):
+                          overlap=True, masks=None, val_scale=1.0):
     """final_u [U_g, d], final_i_shard [I/world, d] = scale * sum_{k=0..K} (A^k x)  on the sharded
     operator; no autograd.  `overlap` issues the collectives asynchronously so that they run
-    beside the other half of the SpMM."""
+    beside the other half of the SpMM.  `masks` = (keep bits of r_iu, keep bits of r_ui) and
+    `val_scale` select an edge-dropped view (ShardedEdgeDrop)."""
     world = g.world
+    kw_iu, kw_ui = {}, {}
+    if masks is not None:
+        kw_iu = dict(keep_bits=masks[0], val_scale=val_scale)
+        kw_ui = dict(keep_bits=masks[1], val_scale=val_scale)
     d = x_user.shape[1]
     dev = x_user.device
     if n_layers == 0:
@@ -112,7 +147,7 @@ def sharded_propagate_raw(g: ShardedBipartiteGraph, x_user, x_item_shard, n_laye
             h_ag = _all_gather(z_item_full, z_i.contiguous(), g.group, overlap)
         else:
             z_item_full, h_ag = z_i, None
-        part_i, _ = spmm(g.r_iu, z_u)                                     # item side: local users only
+        part_i, _ = spmm(g.r_iu, z_u, **kw_iu)                            # item side: local users only
         if h_ag is not None:
             h_ag.wait()
         if world > 1:
@@ -120,7 +155,7 @@ def sharded_propagate_raw(g: ShardedBipartiteGraph, x_user, x_item_shard, n_laye
             h_rs = _reduce_scatter(y_i, part_i, g.group, overlap)
         else:
             y_i, h_rs = part_i, None
-        _, z_u_next = spmm(g.r_ui, z_item_full, acc_in=x_user, acc_scale=s, want_y=False)
+        _, z_u_next = spmm(g.r_ui, z_item_full, acc_in=x_user, acc_scale=s, want_y=False, **kw_ui)
         if h_rs is not None:
             h_rs.wait()
         z_i = (x_item_shard + y_i) * s if s != 1.0 else x_item_shard + y_i
@@ -130,24 +165,30 @@ def sharded_propagate_raw(g: ShardedBipartiteGraph, x_user, x_item_shard, n_laye
 
 class _ShardedPropagate(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x_user, x_item_shard, g, n_layers, scale, spmm, overlap):
-        ctx.g, ctx.n_layers, ctx.scale, ctx.spmm, ctx.overlap = g, n_layers, scale, spmm, overlap
-        return sharded_propagate_raw(g, x_user.contiguous(), x_item_shard.contiguous(), n_layers, scale, spmm, overlap)
+    def forward(ctx, x_user, x_item_shard, g, n_layers, scale, spmm, overlap, view):
+        ctx.g, ctx.n_layers, ctx.scale, ctx.spmm, ctx.overlap, ctx.view = g, n_layers, scale, spmm, overlap, view
+        masks, vs = ((view.iu_fwd, view.ui_fwd), view.val_scale) if view is not None else (None, 1.0)
+        return sharded_propagate_raw(g, x_user.contiguous(), x_item_shard.contiguous(), n_layers, scale, spmm, overlap,
+                                     masks, vs)
 
     @staticmethod
     def backward(ctx, g_user, g_item_shard):
-        # symmetric linear operator: same schedule on the gradients
+        # linear operator: same schedule on the gradients with the transposed operator (itself when
+        # unmasked: symmetric; an edge-dropped view swaps the two blocks' draws)
+        view = ctx.view
+        masks, vs = ((view.iu_bwd, view.ui_bwd), view.val_scale) if view is not None else (None, 1.0)
         gu, gi = sharded_propagate_raw(ctx.g, g_user.contiguous(), g_item_shard.contiguous(), ctx.n_layers,
-                                       ctx.scale, ctx.spmm, ctx.overlap)
-        return gu, gi, None, None, None, None, None
+                                       ctx.scale, ctx.spmm, ctx.overlap, masks, vs)
+        return gu, gi, None, None, None, None, None, None
 
 
 def sharded_lightgcn_propagate(g: ShardedBipartiteGraph, x_user, x_item_shard, n_layers, combine="mean",
-                               spmm=_hip_spmm, overlap=True):
+                               spmm=_hip_spmm, overlap=True, view=None):
     """Differentiable sharded K-layer propagation; returns (user rows of this rank, item shard of
-    this rank).  Use `gather_items` to replicate the item side for the loss."""
+    this rank).  Use `gather_items` to replicate the item side for the loss.  `view`: a
+    ShardedEdgeDrop (one augmented view of the graph)."""
     scale = 1.0 / (n_layers + 1) if combine == "mean" else 1.0
-    return _ShardedPropagate.apply(x_user, x_item_shard, g, int(n_layers), scale, spmm, overlap)
+    return _ShardedPropagate.apply(x_user, x_item_shard, g, int(n_layers), scale, spmm, overlap, view)
 
 
 class _GatherItems(torch.autograd.Function):

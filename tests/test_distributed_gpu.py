@@ -17,6 +17,7 @@ from oracle import oracle_np as O
 pytestmark = pytest.mark.gpu
 
 N_USERS, N_ITEMS, N_EDGES, D, K = 3000, 1111, 60000, 64, 3      # 1111 items: padding shard path
+PE = 0.3
 
 
 def _free_port():
@@ -61,6 +62,14 @@ def _worker(rank, world, port, out):
         ((fu * wu).sum() + (items_full * wi).sum() / world).backward()
         res = dict(fu=fu.detach().cpu().numpy(), fi=fi.detach().cpu().numpy(), gu=xu.grad.cpu().numpy(),
                    gi=xi.grad.cpu().numpy(), lo=lo, hi=hi, ipr=ipr, pad=g.items_padded)
+        # an edge-dropped view (buir-style: independent draws per stored non-zero, kept values / (1 - pe))
+        view = gd.ShardedEdgeDrop(g, PE, seed=11, rescale=True)
+        xu2, xi2 = xu.detach().clone().requires_grad_(True), xi.detach().clone().requires_grad_(True)
+        mu, mi = gd.sharded_lightgcn_propagate(g, xu2, xi2, K, combine="mean", view=view)
+        ((mu * wu).sum() + (gd.gather_items(mi) * wi).sum() / world).backward()
+        host = lambda b: (b.rowptr_host, b.col.cpu().numpy(), b.val.cpu().numpy())
+        res.update(mu=mu.detach().cpu().numpy(), mi=mi.detach().cpu().numpy(), mgu=xu2.grad.cpu().numpy(),
+                   mgi=xi2.grad.cpu().numpy(), seeds=view.seeds, ui=host(g.r_ui), iu=host(g.r_iu))
         # sharded symmetric InfoNCE on this rank's user rows of two noisy views
         gen = torch.Generator().manual_seed(5)
         z1 = torch.randn(N_USERS, D, generator=gen)
@@ -108,6 +117,39 @@ def test_two_ranks_one_gpu_match_single_process():
         np.testing.assert_allclose(res[r]["fi"], ref[N_USERS + r * ipr: N_USERS + (r + 1) * ipr], **tol)
         np.testing.assert_allclose(res[r]["gu"], gref[lo:hi], **gt)
         np.testing.assert_allclose(res[r]["gi"], gref[N_USERS + r * ipr: N_USERS + (r + 1) * ipr], **gt)
+    # the edge-dropped view: assemble the global masked (non-symmetric) operator from every rank's
+    # blocks and the oracle's Philox keep masks, then propagate / back-propagate in float64
+    import scipy.sparse as sp
+    n = N_USERS + pad
+    rows, cols, vals = [], [], []
+    for r in range(world):
+        lo = res[r]["lo"]
+        s_ui, s_iu = res[r]["seeds"]
+        (rp, c, v), (rpt, ct, vt) = res[r]["ui"], res[r]["iu"]
+        keep = O.edge_keep_mask(c.size, PE, seed=s_ui)
+        ru = np.repeat(np.arange(rp.size - 1), np.diff(rp))
+        rows.append(lo + ru[keep]); cols.append(N_USERS + c[keep]); vals.append(v[keep] / (1 - PE))
+        keep_t = O.edge_keep_mask(ct.size, PE, seed=s_iu)
+        ri = np.repeat(np.arange(rpt.size - 1), np.diff(rpt))
+        rows.append(N_USERS + ri[keep_t]); cols.append(lo + ct[keep_t]); vals.append(vt[keep_t] / (1 - PE))
+    a_m = sp.csr_matrix((np.concatenate(vals).astype(np.float64), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n))
+    assert abs(a_m.nnz / (2 * sum(res[r]["ui"][1].size for r in range(world))) - (1 - PE)) < 0.02
+    z = acc = x_all.astype(np.float64)
+    gz = gacc = w_all.astype(np.float64)
+    for _ in range(K):
+        z = a_m @ z
+        acc = acc + z
+        gz = a_m.T @ gz
+        gacc = gacc + gz
+    mref, mgref = acc / (K + 1), gacc / (K + 1)
+    tol = dict(rtol=1e-5, atol=1e-5 * np.abs(mref).max())
+    gt = dict(rtol=1e-5, atol=1e-5 * np.abs(mgref).max())
+    for r in range(world):
+        lo, hi, ipr = res[r]["lo"], res[r]["hi"], res[r]["ipr"]
+        np.testing.assert_allclose(res[r]["mu"], mref[lo:hi], **tol)
+        np.testing.assert_allclose(res[r]["mi"], mref[N_USERS + r * ipr: N_USERS + (r + 1) * ipr], **tol)
+        np.testing.assert_allclose(res[r]["mgu"], mgref[lo:hi], **gt)
+        np.testing.assert_allclose(res[r]["mgi"], mgref[N_USERS + r * ipr: N_USERS + (r + 1) * ipr], **gt)
     gen = torch.Generator().manual_seed(5)
     z1 = torch.randn(N_USERS, D, generator=gen)
     z2 = z1 + 0.4 * torch.randn(N_USERS, D, generator=gen)

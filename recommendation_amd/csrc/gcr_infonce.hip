@@ -234,6 +234,323 @@ __global__ __launch_bounds__(256, (D <= 64 ? 3 : 2)) void infonce_fwd_kernel(con
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Split-operand engine ("b3").  gfx950's bf16 MFMA (v_mfma_f32_32x32x16_bf16) runs at 16x the rate
+// of the f32 MFMA and accumulates in f32.  Every f32 operand x is split ERROR-FREE into three
+// bf16 planes x = x1 + x2 + x3 (+ <= 2^-27 |x|): x1 = bf16_rn(x), x2 = bf16_rn(x - x1),
+// x3 = bf16_rn(x - x1 - x2), the subtractions being exact in f32; bf16 has the exponent range of
+// f32, so this holds for any finite input.  A product x*y is then the six terms
+//   x1y1 + (x1y2 + x2y1) + (x2y2 + x1y3 + x3y1),
+// the dropped ones (x2y3, x3y2, x3y3) being <= 2^-26 |xy|, below the rounding of the f32
+// accumulator that both engines share.  Six bf16 MFMAs of K = 16 replace eight f32 MFMAs of K = 2
+// per 16 features: 2.67x fewer matrix-core cycles at f32 accuracy (the parity tests run on both
+// engines with the same tolerances).  The split happens once per element: anchors when they are
+// loaded, table rows on their way into LDS (three planes, 16-B padded rows, conflict-free b128).
+// ------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){lo, hi}, bf16x2));   // v_cvt_pk_bf16_f32 (RNE)
+}
+__device__ __forceinline__ float bf16_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+
+// two f32 -> three packed bf16 pairs (planes 1..3)
+__device__ __forceinline__ void split3(float a, float b, unsigned& p1, unsigned& p2, unsigned& p3) {
+  p1 = pack_bf16(a, b);
+  a -= bf16_lo(p1);
+  b -= bf16_hi(p1);
+  p2 = pack_bf16(a, b);
+  a -= bf16_lo(p2);
+  b -= bf16_hi(p2);
+  p3 = pack_bf16(a, b);
+}
+
+template <int D>
+struct ShapeB3 {
+  static constexpr int KH = D / 2;                       // features per lane half
+  static constexpr int KC = KH / 8;                      // MFMA k-chunks (8 bf16 per lane) per product term
+  static constexpr int ROWB = 2 * D + 16;                // bytes per LDS row and plane (+16 B pad)
+  static constexpr int PLANE = kTileJ * ROWB;            // bytes per plane
+  static constexpr int NT = D <= 64 ? 2 : 1;             // anchor tiles of 32 per wave
+  static constexpr int NLD = (kTileJ * D / 4) / 256;
+  static constexpr int ANCHORS_PER_BLOCK = 4 * 32 * NT;
+};
+
+template <int D>
+__device__ __forceinline__ void stage_store_b3_one(unsigned char* __restrict__ tile, int tid, const float4& v, int u) {
+  using S = ShapeB3<D>;
+  const int idx = tid + 256 * u;
+  const int row = idx / (D / 4), c4 = idx % (D / 4);
+  unsigned a1, a2, a3, b1, b2, b3;
+  split3(v.x, v.y, a1, a2, a3);
+  split3(v.z, v.w, b1, b2, b3);
+  unsigned char* p = tile + row * S::ROWB + c4 * 8;
+  *reinterpret_cast<uint2*>(p) = make_uint2(a1, b1);
+  *reinterpret_cast<uint2*>(p + S::PLANE) = make_uint2(a2, b2);
+  *reinterpret_cast<uint2*>(p + 2 * S::PLANE) = make_uint2(a3, b3);
+}
+
+template <int D>
+__device__ __forceinline__ void stage_store_b3(unsigned char* __restrict__ tile, int tid,
+                                               const float4 (&regs)[ShapeB3<D>::NLD]) {
+#pragma unroll
+  for (int u = 0; u < ShapeB3<D>::NLD; ++u) stage_store_b3_one<D>(tile, tid, regs[u], u);
+}
+
+// stationary operand planes: frag[p][c] = 8 consecutive features [h*KH + 8c, +8) of plane p
+template <int D>
+__device__ __forceinline__ void load_stationary_b3(const float* __restrict__ a, const float* __restrict__ a_scale,
+                                                   int64_t m_rows, int64_t row, int h, float mult,
+                                                   u32x4 (&frag)[3][ShapeB3<D>::KC]) {
+  using S = ShapeB3<D>;
+  const bool valid = row < m_rows;
+  const float s = valid ? (a_scale != nullptr ? a_scale[row] : 1.0f) * mult : 0.f;
+  const float* p = a + (valid ? row : 0) * D + h * S::KH;
+#pragma unroll
+  for (int c = 0; c < S::KC; ++c) {
+    const float4 v0 = valid ? *reinterpret_cast<const float4*>(p + 8 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 v1 = valid ? *reinterpret_cast<const float4*>(p + 8 * c + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned q[3][4];
+    split3(v0.x * s, v0.y * s, q[0][0], q[1][0], q[2][0]);
+    split3(v0.z * s, v0.w * s, q[0][1], q[1][1], q[2][1]);
+    split3(v1.x * s, v1.y * s, q[0][2], q[1][2], q[2][2]);
+    split3(v1.z * s, v1.w * s, q[0][3], q[1][3], q[2][3]);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) frag[pl][c] = (u32x4){q[pl][0], q[pl][1], q[pl][2], q[pl][3]};
+  }
+}
+
+__device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// S^T tile as in score_tile, six bf16 terms per k-chunk, smallest terms first
+template <int D, int NT>
+__device__ __forceinline__ void score_tile_b3(const unsigned char* __restrict__ tile, int i32, int h,
+                                              const u32x4 (&bq)[NT][3][ShapeB3<D>::KC], f32x16 (&acc)[NT]) {
+  using S = ShapeB3<D>;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const unsigned char* base = tile + i32 * S::ROWB + h * (S::KH * 2);
+#pragma unroll
+  for (int c = 0; c < S::KC; ++c) {
+    const u32x4 a1 = *reinterpret_cast<const u32x4*>(base + 16 * c);
+    const u32x4 a2 = *reinterpret_cast<const u32x4*>(base + S::PLANE + 16 * c);
+    const u32x4 a3 = *reinterpret_cast<const u32x4*>(base + 2 * S::PLANE + 16 * c);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = mfma_bf16(a3, bq[t][0][c], acc[t]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = mfma_bf16(a1, bq[t][2][c], acc[t]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = mfma_bf16(a2, bq[t][1][c], acc[t]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = mfma_bf16(a2, bq[t][0][c], acc[t]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = mfma_bf16(a1, bq[t][1][c], acc[t]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = mfma_bf16(a1, bq[t][0][c], acc[t]);
+  }
+}
+
+template <int D, bool COLSUM, bool PIPE>
+__global__ __launch_bounds__(256, 2) void infonce_fwd_b3_kernel(const float* __restrict__ a,
+                                                                const float* __restrict__ a_scale, int64_t m_rows,
+                                                                const float* __restrict__ b,
+                                                                const float* __restrict__ b_scale, int64_t n_rows,
+                                                                float scale2, int nsplit, int64_t tiles_per_split,
+                                                                float2* __restrict__ part, float* __restrict__ col_sum,
+                                                                float col_bound2) {
+  using S = ShapeB3<D>;
+  __shared__ __align__(16) unsigned char lds[2][3 * S::PLANE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i32 = lane & 31, h = lane >> 5;
+  const int64_t mblk = blockIdx.x / nsplit;
+  const int split = blockIdx.x % nsplit;
+  const int64_t i0 = (mblk * 4 + wave) * (32 * S::NT);
+
+  u32x4 bq[S::NT][3][S::KC];
+#pragma unroll
+  for (int t = 0; t < S::NT; ++t) load_stationary_b3<D>(a, a_scale, m_rows, i0 + 32 * t + i32, h, scale2, bq[t]);
+
+  float m_run[S::NT], l_run[S::NT], a_valid[S::NT];
+#pragma unroll
+  for (int t = 0; t < S::NT; ++t) {
+    m_run[t] = kNegBig;
+    l_run[t] = 0.f;
+    a_valid[t] = (i0 + 32 * t + i32 < m_rows) ? 1.0f : 0.f;
+  }
+
+  const int64_t total_tiles = (n_rows + kTileJ - 1) / kTileJ;
+  const int64_t tile0 = (int64_t)split * tiles_per_split;
+  const int64_t tile1 = min(total_tiles, tile0 + tiles_per_split);
+  float4 regs[S::NLD];
+  auto colsum = [&](const f32x16 (&acc)[S::NT], int64_t tt) {
+    const int64_t j0 = tt * kTileJ;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float e = 0.f;
+#pragma unroll
+      for (int t = 0; t < S::NT; ++t) e += a_valid[t] * __builtin_amdgcn_exp2f(acc[t][r] - col_bound2);
+      e = half_wave_sum_to_last_lane(e);
+      const int64_t j = j0 + acc_row(r, h);
+      if (i32 == 31 && j < n_rows) atomicAdd(col_sum + j, e);
+    }
+  };
+  // the table's last tile is the only one that can be ragged
+  auto epilogue_any = [&](const f32x16 (&acc)[S::NT], int64_t tt) {
+    if ((tt + 1) * kTileJ > n_rows)
+      lse_update<S::NT, true>(acc, rows_left(n_rows, tt * kTileJ, h), m_run, l_run);
+    else
+      lse_update<S::NT, false>(acc, 64, m_run, l_run);
+    if (COLSUM) colsum(acc, tt);
+  };
+  if (tile0 >= tile1) {
+    // empty split (plan_fwd never makes one): fall through to the (kNegBig, 0) partial
+  } else if (PIPE) {
+    // Software pipeline, interleaved by hand: the MFMAs of tile tt+1 alternate in program order with
+    // the softmax VALU work of tile tt (branch-free: every tile before the split's last one is full)
+    // and with the operand split of tile tt+2, one share of VALU "units" per MFMA slot, pinned by
+    // sched_barrier.  A wave issues in order, so this is what lets ONE wave keep the matrix pipe busy
+    // under its own exp2 / max / add stream (two waves of a SIMD otherwise fall into lock-step and
+    // serialise: measured 48 % MFMA utilisation before, scripts/perf_infonce_engine_ab.py).
+    constexpr int NS = 6 * S::KC * S::NT;                         // MFMA slots per step
+    constexpr int NU = 22 * S::NT + S::NLD + (COLSUM ? 16 : 0);   // VALU micro-units per step
+    constexpr int TA[6] = {2, 0, 1, 1, 0, 0};                     // table plane / anchor plane of the six terms,
+    constexpr int TB[6] = {0, 2, 1, 0, 1, 0};                     // smallest products first
+    const int64_t last = tile1 - 1;
+    f32x16 acc_a[S::NT], acc_b[S::NT];
+    stage_load<D>(b, b_scale, n_rows, tile0 * kTileJ, tid, regs);
+    stage_store_b3<D>(lds[0], tid, regs);
+    stage_load<D>(b, b_scale, n_rows, min(tile0 + 1, last) * kTileJ, tid, regs);
+    __syncthreads();
+    score_tile_b3<D, S::NT>(lds[0], i32, h, bq, acc_a);
+    stage_store_b3<D>(lds[1], tid, regs);
+    __syncthreads();
+    auto step = [&](const f32x16 (&cur)[S::NT], f32x16 (&nxt)[S::NT], int64_t tt, int nb) {
+      stage_load<D>(b, b_scale, n_rows, min(tt + 2, last) * kTileJ, tid, regs);
+      const unsigned char* base = lds[nb] + i32 * S::ROWB + h * (S::KH * 2);
+      unsigned char* out = lds[nb ^ 1];
+      float tmax[S::NT], m_new[S::NT], sum[S::NT];
+      // micro-unit m of the step's VALU work: m < 22*NT -> softmax unit m / NT of anchor tile m % NT
+      // (0-3 partial max, 4 new max, 5-20 exp2-add of one register, 21 fold into the running sum);
+      // then the operand split + LDS store of one staged float4; then (COLSUM) one register's column sums
+      auto micro = [&](int m) {
+        const int u = m / S::NT, t = m % S::NT;
+        if (m >= 22 * S::NT + S::NLD) {
+          if (COLSUM) {
+            const int r = m - 22 * S::NT - S::NLD;
+            float e = 0.f;
+#pragma unroll
+            for (int q = 0; q < S::NT; ++q) e += a_valid[q] * __builtin_amdgcn_exp2f(cur[q][r] - col_bound2);
+            e = half_wave_sum_to_last_lane(e);
+            const int64_t j = tt * kTileJ + acc_row(r, h);
+            if (i32 == 31 && j < n_rows) atomicAdd(col_sum + j, e);
+          }
+        } else if (m >= 22 * S::NT) {
+          stage_store_b3_one<D>(out, tid, regs[m - 22 * S::NT], m - 22 * S::NT);
+        } else if (u < 4) {
+          const float x = fmaxf(fmaxf(cur[t][4 * u], cur[t][4 * u + 1]), fmaxf(cur[t][4 * u + 2], cur[t][4 * u + 3]));
+          tmax[t] = u == 0 ? x : fmaxf(tmax[t], x);
+        } else if (u == 4) {
+          m_new[t] = fmaxf(m_run[t], tmax[t]);
+          sum[t] = 0.f;
+        } else if (u < 21) {
+          sum[t] += __builtin_amdgcn_exp2f(cur[t][u - 5] - m_new[t]);
+        } else {
+          l_run[t] = l_run[t] * __builtin_amdgcn_exp2f(m_run[t] - m_new[t]) + sum[t];
+          m_run[t] = m_new[t];
+        }
+      };
+      u32x4 ap[2][3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) ap[0][pl] = *reinterpret_cast<const u32x4*>(base + pl * S::PLANE);
+#pragma unroll
+      for (int c = 0; c < S::KC; ++c) {
+        if (c + 1 < S::KC) {
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl)
+            ap[(c + 1) & 1][pl] = *reinterpret_cast<const u32x4*>(base + pl * S::PLANE + 16 * (c + 1));
+        }
+#pragma unroll
+        for (int term = 0; term < 6; ++term) {
+#pragma unroll
+          for (int t = 0; t < S::NT; ++t) {
+            const int slot = (c * 6 + term) * S::NT + t;
+            f32x16 cin = nxt[t];
+            if (c == 0 && term == 0) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) cin[r] = 0.f;
+            }
+            nxt[t] = mfma_bf16(ap[c & 1][TA[term]], bq[t][TB[term]][c], cin);
+#pragma unroll
+            for (int u = slot * NU / NS; u < (slot + 1) * NU / NS; ++u) micro(u);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+      // pin the running statistics here: without it the compiler sinks this step's softmax work past
+      // the barrier into the next step, in front of its MFMAs
+#pragma unroll
+      for (int t = 0; t < S::NT; ++t) asm volatile("" : "+v"(m_run[t]), "+v"(l_run[t]));
+      __syncthreads();
+    };
+    int64_t tt = tile0;
+    for (; tt + 2 <= last; tt += 2) {
+      step(acc_a, acc_b, tt, 1);
+      step(acc_b, acc_a, tt + 1, 0);
+    }
+    if (tt < last) {
+      step(acc_a, acc_b, tt, 1);
+      epilogue_any(acc_b, last);
+    } else {
+      epilogue_any(acc_a, last);
+    }
+  } else {
+    stage_load<D>(b, b_scale, n_rows, tile0 * kTileJ, tid, regs);
+    stage_store_b3<D>(lds[0], tid, regs);
+    __syncthreads();
+    for (int64_t tt = tile0; tt < tile1; ++tt) {
+      const int cur = (int)((tt - tile0) & 1);
+      const int64_t nxt = tt + 1 < tile1 ? tt + 1 : tt;
+      stage_load<D>(b, b_scale, n_rows, nxt * kTileJ, tid, regs);
+      f32x16 acc[S::NT];
+      score_tile_b3<D, S::NT>(lds[cur], i32, h, bq, acc);
+      epilogue_any(acc, tt);
+      stage_store_b3<D>(lds[cur ^ 1], tid, regs);
+      __syncthreads();
+    }
+  }
+
+#pragma unroll
+  for (int t = 0; t < S::NT; ++t) {
+    const float m_o = __shfl_xor(m_run[t], 32, 64), l_o = __shfl_xor(l_run[t], 32, 64);
+    const float m = fmaxf(m_run[t], m_o);
+    const float l = l_run[t] * __builtin_amdgcn_exp2f(m_run[t] - m) + l_o * __builtin_amdgcn_exp2f(m_o - m);
+    const int64_t row = i0 + 32 * t + i32;
+    if (h == 0 && row < m_rows) part[(int64_t)split * m_rows + row] = make_float2(m, l);
+  }
+}
+
+// engine selection: GCR_INFONCE_ENGINE = f32 | b3 (read per call so that A/B rounds interleave
+// in-process); d = 256 stays on the f32 engine (its three operand planes would not fit the registers)
+// Default: b3 for d <= 64, where forward AND backward have it (the backward must recompute the
+// forward's logits with the forward's engine, or sum_j P_ij = 1 only holds to ~1e-6 and
+// near-cancelling gradients lose digits).  GCR_INFONCE_ENGINE=b3all (measurement only) also takes
+// the forward-only kernels (row LSE, k-means assignment) at d = 128.
+bool use_b3(int d) {
+  if (d > 128) return false;
+  const char* e = getenv("GCR_INFONCE_ENGINE");
+  if (e != nullptr && e[0] == 'f') return false;
+  if (e != nullptr && e[0] == 'b' && e[1] == '3' && e[2] == 'a') return true;
+  return d <= 64;
+}
+
 // natural-log LSE of the scaled logits from the per-split (max2, sum2) partials
 __global__ void infonce_merge_kernel(const float2* __restrict__ part, int nsplit, int64_t m_rows,
                                      float* __restrict__ lse) {
@@ -508,6 +825,179 @@ __global__ __launch_bounds__(256, 2) void infonce_bwd_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Backward on the split-operand engine (d <= 64).  Same structure as infonce_bwd_kernel; the score
+// tile is recomputed with exactly the forward's sequence of bf16 MFMAs (bitwise the forward's
+// logits when the roles are the forward's, so sum_j P_ij = 1 to rounding), P is split into three
+// bf16 planes in registers (an accumulator register pair -> one packed dword of each plane: the
+// accumulator layout is already the B-operand layout of the 32x32x16 MFMA, k = the 8 + 8 streamed
+// rows a lane holds per 16-row chunk), and the second product reads its A operand
+// yhat[rows][feature] from a TRANSPOSED copy of the three planes in LDS ([feature][row] bf16,
+// 72-B rows: conflict-free ds_read_b64), staged together with the row-major planes.
+// ------------------------------------------------------------------------------------------
+template <int D>
+struct BwdB3 {
+  static constexpr int CT = D / 32;                    // feature tiles of 32, all in one launch
+  static constexpr int RT = 72;                        // bytes per feature of a transposed plane
+  static constexpr int TPLANE = D * RT;
+  static constexpr int ROWS_PER_BLOCK = 128;           // one tile of 32 stationary rows per wave
+  static constexpr int TILE_BYTES = 3 * ShapeB3<D>::PLANE + 3 * TPLANE;
+};
+
+template <int D>
+__device__ __forceinline__ void stage_store_b3t_one(unsigned char* __restrict__ tile, int tid, const float4& v, int u) {
+  using S = ShapeB3<D>;
+  using B = BwdB3<D>;
+  const int idx = tid + 256 * u;
+  const int row = idx / (D / 4), c4 = idx % (D / 4);
+  unsigned a1, a2, a3, b1, b2, b3;
+  split3(v.x, v.y, a1, a2, a3);
+  split3(v.z, v.w, b1, b2, b3);
+  unsigned char* p = tile + row * S::ROWB + c4 * 8;
+  *reinterpret_cast<uint2*>(p) = make_uint2(a1, b1);
+  *reinterpret_cast<uint2*>(p + S::PLANE) = make_uint2(a2, b2);
+  *reinterpret_cast<uint2*>(p + 2 * S::PLANE) = make_uint2(a3, b3);
+  unsigned short* q = reinterpret_cast<unsigned short*>(tile + 3 * S::PLANE + (4 * c4) * B::RT + row * 2);
+  const unsigned pa[3] = {a1, a2, a3}, pb[3] = {b1, b2, b3};
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) {
+    unsigned short* qq = q + pl * (B::TPLANE / 2);
+    qq[0] = (unsigned short)(pa[pl] & 0xffffu);
+    qq[B::RT / 2] = (unsigned short)(pa[pl] >> 16);
+    qq[2 * (B::RT / 2)] = (unsigned short)(pb[pl] & 0xffffu);
+    qq[3 * (B::RT / 2)] = (unsigned short)(pb[pl] >> 16);
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void infonce_bwd_b3_kernel(
+    const float* __restrict__ x, const float* __restrict__ x_scale, int64_t mx, const float* __restrict__ y,
+    const float* __restrict__ y_scale, int64_t ny, float scale2, float out_scale, const float* __restrict__ lse_x,
+    const float* __restrict__ w_x, const float* __restrict__ lse_y, const float* __restrict__ w_y, int nsplit,
+    int64_t tiles_per_split, float* __restrict__ gpart) {
+  using S = ShapeB3<D>;
+  using B = BwdB3<D>;
+  __shared__ __align__(16) unsigned char lds[2][B::TILE_BYTES];
+  __shared__ __align__(16) float st_lse[2][kTileJ];
+  __shared__ __align__(16) float st_w[2][kTileJ];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i32 = lane & 31, h = lane >> 5;
+  const int64_t mblk = blockIdx.x / nsplit;
+  const int split = blockIdx.x % nsplit;
+  const int64_t row_i = (mblk * 4 + wave) * 32 + i32;
+
+  u32x4 bq[1][3][S::KC];
+  load_stationary_b3<D>(x, x_scale, mx, row_i, h, scale2, bq[0]);
+  const bool on_x = row_i < mx && w_x != nullptr;
+  const float wl = on_x ? w_x[row_i] : 0.f;
+  const float lse2l = on_x ? lse_x[row_i] * kLog2e : 1.0e30f;    // disabled term: exp2(-huge) = 0, never 0 * inf
+  f32x16 gacc[B::CT];
+#pragma unroll
+  for (int c = 0; c < B::CT; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gacc[c][r] = 0.f;
+
+  const int64_t total_tiles = (ny + kTileJ - 1) / kTileJ;
+  const int64_t tile0 = (int64_t)split * tiles_per_split;
+  const int64_t tile1 = min(total_tiles, tile0 + tiles_per_split);
+  float4 regs[S::NLD];
+  float s_lse = 0.f, s_w = 0.f;
+  auto load_stats = [&](int64_t j0) {
+    if (tid < kTileJ) {
+      const int64_t j = j0 + tid;
+      const bool on = j < ny && w_y != nullptr;
+      s_w = on ? w_y[j] : 0.f;
+      s_lse = on ? lse_y[j] * kLog2e : 1.0e30f;
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < S::NLD; ++u) stage_store_b3t_one<D>(lds[buf], tid, regs[u], u);
+    if (tid < kTileJ) {
+      st_lse[buf][tid] = s_lse;
+      st_w[buf][tid] = s_w;
+    }
+  };
+  if (tile0 < tile1) {
+    stage_load<D>(y, y_scale, ny, tile0 * kTileJ, tid, regs);
+    load_stats(tile0 * kTileJ);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int64_t tt = tile0; tt < tile1; ++tt) {
+    const int cur = (int)((tt - tile0) & 1);
+    const bool more = tt + 1 < tile1;
+    if (more) {
+      stage_load<D>(y, y_scale, ny, (tt + 1) * kTileJ, tid, regs);
+      load_stats((tt + 1) * kTileJ);
+    }
+    f32x16 acc[1];
+    score_tile_b3<D, 1>(lds[cur], i32, h, bq, acc);
+    const int64_t j0 = tt * kTileJ;
+    const bool ragged = j0 + kTileJ > ny;
+    // P in place of the scores
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 lr = *reinterpret_cast<const float4*>(&st_lse[cur][8 * g + 4 * h]);
+      const float4 wr = *reinterpret_cast<const float4*>(&st_w[cur][8 * g + 4 * h]);
+      const float lre[4] = {lr.x, lr.y, lr.z, lr.w};
+      const float wre[4] = {wr.x, wr.y, wr.z, wr.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g + e;
+        const bool dead = ragged && (j0 + acc_row(r, h) >= ny);
+        const float sc = dead ? -INFINITY : acc[0][r];
+        acc[0][r] = wl * __builtin_amdgcn_exp2f(sc - lse2l) + wre[e] * __builtin_amdgcn_exp2f(sc - lre[e]);
+      }
+    }
+    // G^T[c][i] += yhat[j][c] * P[j][i], 16 streamed rows per k-chunk, six bf16 terms
+    const unsigned char* tbase = lds[cur] + 3 * S::PLANE + i32 * B::RT + 8 * h;
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+      u32x4 pp[3];
+      {
+        unsigned q[3][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split3(acc[0][8 * kc + 2 * e], acc[0][8 * kc + 2 * e + 1], q[0][e], q[1][e], q[2][e]);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) pp[pl] = (u32x4){q[pl][0], q[pl][1], q[pl][2], q[pl][3]};
+      }
+#pragma unroll
+      for (int c = 0; c < B::CT; ++c) {
+        u32x4 ya[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          const unsigned char* p = tbase + pl * B::TPLANE + (32 * c) * B::RT + 32 * kc;
+          const uint2 lo = *reinterpret_cast<const uint2*>(p);
+          const uint2 hi = *reinterpret_cast<const uint2*>(p + 16);
+          ya[pl] = (u32x4){lo.x, lo.y, hi.x, hi.y};
+        }
+        gacc[c] = mfma_bf16(ya[2], pp[0], gacc[c]);
+        gacc[c] = mfma_bf16(ya[0], pp[2], gacc[c]);
+        gacc[c] = mfma_bf16(ya[1], pp[1], gacc[c]);
+        gacc[c] = mfma_bf16(ya[1], pp[0], gacc[c]);
+        gacc[c] = mfma_bf16(ya[0], pp[1], gacc[c]);
+        gacc[c] = mfma_bf16(ya[0], pp[0], gacc[c]);
+      }
+    }
+    if (more) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  // gacc[c] register rr of lane (i, h) is column 32*c + acc_row(rr, h) of row i
+  float* gout = gpart + (int64_t)split * mx * D;
+  if (row_i < mx) {
+#pragma unroll
+    for (int c = 0; c < B::CT; ++c)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 v = make_float4(gacc[c][4 * g + 0] * out_scale, gacc[c][4 * g + 1] * out_scale,
+                               gacc[c][4 * g + 2] * out_scale, gacc[c][4 * g + 3] * out_scale);
+        *reinterpret_cast<float4*>(gout + row_i * D + 32 * c + 8 * g + 4 * h) = v;
+      }
+  }
+}
+
 // g[i, :] = sum over splits (fixed order) of the partial gradients
 __global__ __launch_bounds__(256) void bwd_reduce_kernel(const float* __restrict__ gpart, int nsplit, int64_t n4,
                                                          float* __restrict__ g) {
@@ -554,13 +1044,12 @@ __global__ __launch_bounds__(256) void normalize_bwd_kernel(const float* __restr
   }
 }
 
-template <int D>
-FwdPlan plan_bwd(int64_t mx, int64_t ny) {
-  FwdPlan p = plan_fwd(mx, ny, BwdShape<D>::ROWS_PER_BLOCK, 512);
+FwdPlan plan_bwd_rows(int64_t mx, int64_t ny, int d, int rows_per_block) {
+  FwdPlan p = plan_fwd(mx, ny, rows_per_block, 512);
   // every split keeps an [mx, D] fp32 partial: with many stationary rows the row blocks alone fill
   // the chip, and the partials must stay small (cap 1 GiB)
   const int64_t total_tiles = (ny + kTileJ - 1) / kTileJ;
-  while (p.nsplit > 1 && (p.m_blocks >= 1536 || (int64_t)p.nsplit * mx * D * 4 > (1ll << 30))) {
+  while (p.nsplit > 1 && (p.m_blocks >= 1536 || (int64_t)p.nsplit * mx * d * 4 > (1ll << 30))) {
     p.tiles_per_split *= 2;
     p.nsplit = (int)((total_tiles + p.tiles_per_split - 1) / p.tiles_per_split);
   }
@@ -568,9 +1057,33 @@ FwdPlan plan_bwd(int64_t mx, int64_t ny) {
 }
 
 template <int D>
+FwdPlan plan_bwd(int64_t mx, int64_t ny) {
+  return plan_bwd_rows(mx, ny, D, BwdShape<D>::ROWS_PER_BLOCK);
+}
+
+template <int D>
 int32_t launch_bwd(const float* x, const float* x_scale, int64_t mx, const float* y, const float* y_scale, int64_t ny,
                    float inv_tau, const float* lse_x, const float* w_x, const float* lse_y, const float* w_y, float* g,
                    void* workspace, hipStream_t s) {
+  if constexpr (D <= 64) {
+    if (use_b3(D)) {
+      const FwdPlan p = plan_bwd_rows(mx, ny, D, BwdB3<D>::ROWS_PER_BLOCK);
+      float* gpart = p.nsplit == 1 ? g : reinterpret_cast<float*>(workspace);
+      hipLaunchKernelGGL((infonce_bwd_b3_kernel<D>), dim3((unsigned)(p.m_blocks * p.nsplit)), dim3(256), 0, s, x,
+                         x_scale, mx, y, y_scale, ny, inv_tau * kLog2e, inv_tau, lse_x, w_x, lse_y, w_y, p.nsplit,
+                         p.tiles_per_split, gpart);
+      int32_t st = GCR_LAUNCH_STATUS();
+      if (st != GCR_OK) return st;
+      if (p.nsplit > 1) {
+        const int64_t n4 = mx * D / 4;
+        const int64_t want = (n4 + 255) / 256;
+        hipLaunchKernelGGL(bwd_reduce_kernel, dim3((unsigned)(want > 4096 ? 4096 : want)), dim3(256), 0, s, gpart,
+                           p.nsplit, n4, g);
+        return GCR_LAUNCH_STATUS();
+      }
+      return GCR_OK;
+    }
+  }
   const FwdPlan p = plan_bwd<D>(mx, ny);
   float* gpart = p.nsplit == 1 ? g : reinterpret_cast<float*>(workspace);
   for (int pass = 0; pass < BwdShape<D>::PASSES; ++pass) {
@@ -595,8 +1108,34 @@ int anchors_per_block_for(int d) { return d <= 128 ? 256 : 128; }
 template <int D>
 int32_t launch_fwd(const float* a, const float* a_scale, int64_t m, const float* b, const float* b_scale, int64_t n,
                    float inv_tau, float* lse, float* col_sum, float col_bound, void* workspace, hipStream_t s) {
-  const FwdPlan p = plan_fwd(m, n, Shape<D>::ANCHORS_PER_BLOCK, D <= 64 ? 768 : 512);
   float2* part = reinterpret_cast<float2*>(workspace);
+  if constexpr (D <= 128) {
+    if (use_b3(D)) {
+      const FwdPlan p = plan_fwd(m, n, ShapeB3<D>::ANCHORS_PER_BLOCK, 512);
+      const dim3 grid((unsigned)(p.m_blocks * p.nsplit));
+      const char* pe = getenv("GCR_INFONCE_PIPE");   // A/B knob
+      const bool pipe = !(pe != nullptr && pe[0] == '0');
+      const float cb2 = col_sum != nullptr ? col_bound * kLog2e : 0.f;
+      if (col_sum != nullptr) {
+        hipError_t err = hipMemsetAsync(col_sum, 0, sizeof(float) * (size_t)n, s);
+        if (err != hipSuccess) return gcr_hip_status(err);
+      }
+#define GCR_B3(CS, PP)                                                                                              \
+  hipLaunchKernelGGL((infonce_fwd_b3_kernel<D, CS, PP>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale, n,       \
+                     inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part, col_sum, cb2)
+      if (col_sum != nullptr) {
+        if (pipe) GCR_B3(true, true); else GCR_B3(true, false);
+      } else {
+        if (pipe) GCR_B3(false, true); else GCR_B3(false, false);
+      }
+#undef GCR_B3
+      int32_t st = GCR_LAUNCH_STATUS();
+      if (st != GCR_OK) return st;
+      hipLaunchKernelGGL(infonce_merge_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, part, p.nsplit, m, lse);
+      return GCR_LAUNCH_STATUS();
+    }
+  }
+  const FwdPlan p = plan_fwd(m, n, Shape<D>::ANCHORS_PER_BLOCK, D <= 64 ? 768 : 512);
   const dim3 grid((unsigned)(p.m_blocks * p.nsplit));
   const char* fm = getenv("GCR_INFONCE_FORCE_MASK");   // A/B knob
   const int force_mask = fm != nullptr && fm[0] == '1';
@@ -699,6 +1238,82 @@ __global__ __launch_bounds__(256, (D <= 64 ? 3 : 2)) void kmeans_assign_kernel(
   }
 }
 
+// the same on the split-operand engine (d <= 128)
+template <int D>
+__global__ __launch_bounds__(256, 2) void kmeans_assign_b3_kernel(
+    const float* __restrict__ x, int64_t n, const float* __restrict__ cent, const float* __restrict__ half_sq,
+    int64_t k, int64_t* __restrict__ assign, float* __restrict__ best_out) {
+  using S = ShapeB3<D>;
+  __shared__ __align__(16) unsigned char lds[2][3 * S::PLANE];
+  __shared__ __align__(16) float st_bias[2][kTileJ];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i32 = lane & 31, h = lane >> 5;
+  const int64_t i0 = ((int64_t)blockIdx.x * 4 + wave) * (32 * S::NT);
+  u32x4 bfrag[S::NT][3][S::KC];
+#pragma unroll
+  for (int t = 0; t < S::NT; ++t) load_stationary_b3<D>(x, nullptr, n, i0 + 32 * t + i32, h, 1.0f, bfrag[t]);
+  float best[S::NT];
+  int bidx[S::NT];
+#pragma unroll
+  for (int t = 0; t < S::NT; ++t) {
+    best[t] = -INFINITY;
+    bidx[t] = 0x7fffffff;
+  }
+  const int64_t tiles = (k + kTileJ - 1) / kTileJ;
+  float4 regs[S::NLD];
+  float bias = 0.f;
+  auto load_bias = [&](int64_t j0) {
+    if (tid < kTileJ) bias = (j0 + tid < k) ? -half_sq[j0 + tid] : -INFINITY;  // rows past k never win
+  };
+  stage_load<D>(cent, nullptr, k, 0, tid, regs);
+  load_bias(0);
+  stage_store_b3<D>(lds[0], tid, regs);
+  if (tid < kTileJ) st_bias[0][tid] = bias;
+  __syncthreads();
+  for (int64_t tt = 0; tt < tiles; ++tt) {
+    const int cur = (int)(tt & 1);
+    const int64_t nxt = tt + 1 < tiles ? tt + 1 : tt;
+    stage_load<D>(cent, nullptr, k, nxt * kTileJ, tid, regs);
+    load_bias(nxt * kTileJ);
+    f32x16 acc[S::NT];
+    score_tile_b3<D, S::NT>(lds[cur], i32, h, bfrag, acc);
+    const int j0 = (int)(tt * kTileJ);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 bb = *reinterpret_cast<const float4*>(&st_bias[cur][8 * g + 4 * h]);
+      const float be[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g + e;
+        const int j = j0 + acc_row(r, h);
+#pragma unroll
+        for (int t = 0; t < S::NT; ++t) {
+          const float v = acc[t][r] + be[e];
+          const bool better = v > best[t] || (v == best[t] && j < bidx[t]);
+          best[t] = better ? v : best[t];
+          bidx[t] = better ? j : bidx[t];
+        }
+      }
+    }
+    stage_store_b3<D>(lds[cur ^ 1], tid, regs);
+    if (tid < kTileJ) st_bias[cur ^ 1][tid] = bias;
+    __syncthreads();
+  }
+#pragma unroll
+  for (int t = 0; t < S::NT; ++t) {
+    const float v_o = __shfl_xor(best[t], 32, 64);
+    const int j_o = __shfl_xor(bidx[t], 32, 64);
+    const bool other = v_o > best[t] || (v_o == best[t] && j_o < bidx[t]);
+    const float v = other ? v_o : best[t];
+    const int j = other ? j_o : bidx[t];
+    const int64_t row = i0 + 32 * t + i32;
+    if (h == 0 && row < n) {
+      assign[row] = j;
+      if (best_out != nullptr) best_out[row] = v;
+    }
+  }
+}
+
 // sums[c] += x_i (256-B float-atomic rows), counts[c] += 1, one wave per point
 __global__ __launch_bounds__(256) void kmeans_accumulate_kernel(const float* __restrict__ x, int64_t n, int d,
                                                                 const int64_t* __restrict__ assign, int64_t k,
@@ -746,13 +1361,19 @@ extern "C" int32_t gcr_kmeans_assign_f32(const float* x, int64_t n, const float*
   hipLaunchKernelGGL((kmeans_assign_kernel<DD>), dim3((unsigned)((n + Shape<DD>::ANCHORS_PER_BLOCK - 1) /      \
                                                                  Shape<DD>::ANCHORS_PER_BLOCK)),               \
                      dim3(256), 0, s, x, n, centroids, half_sqnorm, k, assign, best_score)
+#define GCR_KM3(DD)                                                                                            \
+  hipLaunchKernelGGL((kmeans_assign_b3_kernel<DD>), dim3((unsigned)((n + ShapeB3<DD>::ANCHORS_PER_BLOCK - 1) / \
+                                                                    ShapeB3<DD>::ANCHORS_PER_BLOCK)),          \
+                     dim3(256), 0, s, x, n, centroids, half_sqnorm, k, assign, best_score)
+  const bool b3 = use_b3(d);
   switch (d) {
-    case 32: GCR_KM(32); break;
-    case 64: GCR_KM(64); break;
-    case 128: GCR_KM(128); break;
+    case 32: if (b3) GCR_KM3(32); else GCR_KM(32); break;
+    case 64: if (b3) GCR_KM3(64); else GCR_KM(64); break;
+    case 128: if (b3) GCR_KM3(128); else GCR_KM(128); break;
     default: GCR_KM(256); break;
   }
 #undef GCR_KM
+#undef GCR_KM3
   return GCR_LAUNCH_STATUS();
 }
 
@@ -779,8 +1400,14 @@ extern "C" int32_t gcr_kmeans_update_f32(const float* x, int64_t n, int32_t d, c
 
 extern "C" int64_t gcr_infonce_fwd_workspace_bytes(int64_t m, int64_t n, int32_t d) {
   if (m <= 0 || n <= 0 || !dim_supported(d)) return 0;
+  // large enough for either engine (the choice is made per call)
   const FwdPlan p = plan_fwd(m, n, anchors_per_block_for(d), d <= 64 ? 768 : 512);
-  return (int64_t)p.nsplit * m * (int64_t)sizeof(float2);
+  int64_t nsplit = p.nsplit;
+  if (d <= 128) {
+    const FwdPlan q = plan_fwd(m, n, d <= 64 ? 256 : 128, 512);
+    if (q.nsplit > nsplit) nsplit = q.nsplit;
+  }
+  return nsplit * m * (int64_t)sizeof(float2);
 }
 
 extern "C" int32_t gcr_infonce_fwd_f32(const float* a, const float* a_scale, int64_t m, const float* b,
@@ -831,7 +1458,12 @@ extern "C" int64_t gcr_infonce_bwd_workspace_bytes(int64_t mx, int64_t ny, int32
     case 128: p = plan_bwd<128>(mx, ny); break;
     default: p = plan_bwd<256>(mx, ny); break;
   }
-  return p.nsplit > 1 ? (int64_t)p.nsplit * mx * d * (int64_t)sizeof(float) : 0;
+  int64_t nsplit = p.nsplit;
+  if (d <= 64) {   // either engine (chosen per call)
+    const FwdPlan q = plan_bwd_rows(mx, ny, d, 128);
+    if (q.nsplit > nsplit) nsplit = q.nsplit;
+  }
+  return nsplit > 1 ? nsplit * mx * d * (int64_t)sizeof(float) : 0;
 }
 
 extern "C" int32_t gcr_infonce_bwd_f32(const float* x, const float* x_scale, int64_t mx, const float* y,

@@ -16,6 +16,14 @@ def Fn():
     return functional
 
 
+@pytest.fixture(autouse=True, params=["b3", "f32"])
+def engine(request, monkeypatch):
+    """Every test of this module runs on both MFMA engines (csrc/gcr_infonce.hip): the split-operand
+    bf16 engine (default for d <= 128) and the f32 MFMA engine, with the same tolerances."""
+    monkeypatch.setenv("GCR_INFONCE_ENGINE", request.param)
+    return request.param
+
+
 def _lse(Fn, a, b, inv_tau, normalize):
     at, bt = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
     sa = Fn.row_inv_norm(at) if normalize else None

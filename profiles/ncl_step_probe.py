@@ -18,7 +18,7 @@ n_u, n_i = wl["users"], wl["items"]
 graph = ra.CsrGraph.bipartite_sym_norm(users, items, n_u, n_i, dev)
 xp = torch.nn.Parameter(torch.empty(n_u + n_i, 64, device=dev))
 torch.nn.init.xavier_uniform_(xp)
-opt = torch.optim.Adam([xp], lr=1e-3)
+opt = torch.optim.Adam([xp], lr=1e-3, fused=True)
 gen = torch.Generator(device=dev).manual_seed(1)
 bsz = 2048
 uidx = torch.randint(0, n_u, (bsz,), device=dev, generator=gen)
@@ -31,7 +31,7 @@ u2c = torch.randint(0, 1000, (n_u,), device=dev, generator=gen)
 i2c = torch.randint(0, 1000, (n_i,), device=dev, generator=gen)
 for _ in range(6):
     final, layers = Fn.lightgcn_propagate(graph, xp, 3, "mean", return_layers=True)
-    ue, ie = final[:n_u], final[n_u:]
+    ue, ie = Fn.split_rows(final, n_u)
     loss = Ls.bpr_loss(ue[uidx], ie[iidx], ie[jn]) + \
         Ls.ssl_layer_loss(layers[2], layers[0], uidx, iidx, n_u, 0.1, 1e-6, 1.0) + \
         Ls.ProtoNCE_loss(layers[0], uidx, iidx, n_u, cent, u2c, cent, i2c, 0.1, 1e-7, bsz)

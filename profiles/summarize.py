@@ -20,7 +20,7 @@ here = os.path.dirname(os.path.abspath(__file__))
 
 
 def one(pattern):
-    hits = glob.glob(os.path.join(src, pattern))
+    hits = glob.glob(os.path.join(src, pattern)) or glob.glob(os.path.join(src, pattern.replace("/*/", "/")))
     return hits[0] if hits else None
 
 
@@ -76,8 +76,9 @@ if pmc:
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(pmc)):
         k = r["Kernel_Name"]
-        if "infonce_fwd_kernel" in k or "infonce_bwd_kernel" in k:
-            agg["infonce_fwd_kernel<64>" if "fwd" in k else "infonce_bwd_kernel<64>"][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if "infonce_fwd" in k or "infonce_bwd" in k:
+            name = k.split("::")[-1].split("(")[0]          # infonce_fwd_b3_kernel<64, false, true> ...
+            agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
     with open(os.path.join(here, f"{tag}_infonce_pmc_mfma.csv"), "w") as f:
         w = csv.writer(f)
         w.writerow(["kernel", "dispatches", "counter", "avg_value", "note"])

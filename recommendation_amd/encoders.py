@@ -92,7 +92,8 @@ class LGCNEncoder(nn.Module):
     def forward(self):
         emb = torch.cat([self.embedding_dict["user_emb"], self.embedding_dict["item_emb"]], 0)
         final, all_emb = Fn.lightgcn_propagate(self.norm_adj, emb, self.layers, combine="mean", return_layers=True)
-        return final[: self.data.user_num], final[self.data.user_num:], all_emb
+        user_all, item_all = Fn.split_rows(final, self.data.user_num)
+        return user_all, item_all, all_emb
 
 
 class LightGCN(nn.Module):
@@ -128,7 +129,7 @@ class LightGCN(nn.Module):
         x = torch.cat([self.user_embedding.weight, self.item_embedding.weight], dim=0)
         x = Fn.lightgcn_propagate(graph, x, self.num_layers, combine="sum")
         nu = self.user_embedding.num_embeddings
-        return x[:nu], x[nu:]
+        return Fn.split_rows(x, nu)
 
 
 def sept_encoder(emb, adj: CsrGraph, n_layers: int):

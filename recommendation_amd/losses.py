@@ -37,13 +37,13 @@ def batch_softmax_loss(user_emb, item_emb, temperature):
 def ssl_layer_loss(context, initial, user, item, user_num, ssl_temp, ssl_reg, alpha):
     """ncl.py:358-367 (NCLModel.ssl_layer_loss): structure contrast of the batch's context-layer rows
     against ALL layer-0 rows of the same side; positives = the row's own layer-0 embedding; summed."""
-    cu, ci = context[:user_num], context[user_num:]
-    iu, ii = initial[:user_num], initial[user_num:]
+    iu, ii = Fn.split_rows(initial, user_num)
     dev = context.device
     user = torch.as_tensor(user, device=dev, dtype=torch.int64)
     item = torch.as_tensor(item, device=dev, dtype=torch.int64)
-    lse_u, pos_u = Fn.infonce_stats(cu[user], iu, user, ssl_temp, normalize=True)
-    lse_i, pos_i = Fn.infonce_stats(ci[item], ii, item, ssl_temp, normalize=True)
+    # batch rows gathered straight from the stacked table (one sparse backward instead of slice + gather)
+    lse_u, pos_u = Fn.infonce_stats(context[user], iu, user, ssl_temp, normalize=True)
+    lse_i, pos_i = Fn.infonce_stats(context[item + user_num], ii, item, ssl_temp, normalize=True)
     return ssl_reg * ((lse_u - pos_u).sum() + alpha * (lse_i - pos_i).sum())
 
 
@@ -53,11 +53,10 @@ def ProtoNCE_loss(initial_emb, user_idx, item_idx, user_num, user_centroids, use
     dev = initial_emb.device
     user_idx = torch.as_tensor(user_idx, device=dev, dtype=torch.int64)
     item_idx = torch.as_tensor(item_idx, device=dev, dtype=torch.int64)
-    user_emb, item_emb = initial_emb[:user_num], initial_emb[user_num:]
     u2c = user_centroids.to(dev)[user_2cluster.to(dev)[user_idx]]
     i2c = item_centroids.to(dev)[item_2cluster.to(dev)[item_idx]]
-    loss_user = InfoNCE(user_emb[user_idx], u2c, ssl_temp) * batch_size
-    loss_item = InfoNCE(item_emb[item_idx], i2c, ssl_temp) * batch_size
+    loss_user = InfoNCE(initial_emb[user_idx], u2c, ssl_temp) * batch_size
+    loss_item = InfoNCE(initial_emb[item_idx + user_num], i2c, ssl_temp) * batch_size
     return proto_reg * (loss_user + loss_item)
 
 

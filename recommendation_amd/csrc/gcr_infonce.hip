@@ -869,7 +869,7 @@ __device__ __forceinline__ void stage_store_b3t_one(unsigned char* __restrict__ 
   }
 }
 
-template <int D>
+template <int D, bool ILV>
 __global__ __launch_bounds__(256, 2) void infonce_bwd_b3_kernel(
     const float* __restrict__ x, const float* __restrict__ x_scale, int64_t mx, const float* __restrict__ y,
     const float* __restrict__ y_scale, int64_t ny, float scale2, float out_scale, const float* __restrict__ lse_x,
@@ -918,53 +918,113 @@ __global__ __launch_bounds__(256, 2) void infonce_bwd_b3_kernel(
       st_w[buf][tid] = s_w;
     }
   };
-  if (tile0 < tile1) {
-    stage_load<D>(y, y_scale, ny, tile0 * kTileJ, tid, regs);
-    load_stats(tile0 * kTileJ);
-    store_tile(0);
-  }
-  __syncthreads();
-  for (int64_t tt = tile0; tt < tile1; ++tt) {
-    const int cur = (int)((tt - tile0) & 1);
-    const bool more = tt + 1 < tile1;
-    if (more) {
-      stage_load<D>(y, y_scale, ny, (tt + 1) * kTileJ, tid, regs);
-      load_stats((tt + 1) * kTileJ);
-    }
-    f32x16 acc[1];
-    score_tile_b3<D, 1>(lds[cur], i32, h, bq, acc);
-    const int64_t j0 = tt * kTileJ;
-    const bool ragged = j0 + kTileJ > ny;
-    // P in place of the scores
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float4 lr = *reinterpret_cast<const float4*>(&st_lse[cur][8 * g + 4 * h]);
-      const float4 wr = *reinterpret_cast<const float4*>(&st_w[cur][8 * g + 4 * h]);
-      const float lre[4] = {lr.x, lr.y, lr.z, lr.w};
-      const float wre[4] = {wr.x, wr.y, wr.z, wr.w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int r = 4 * g + e;
-        const bool dead = ragged && (j0 + acc_row(r, h) >= ny);
-        const float sc = dead ? -INFINITY : acc[0][r];
-        acc[0][r] = wl * __builtin_amdgcn_exp2f(sc - lse2l) + wre[e] * __builtin_amdgcn_exp2f(sc - lre[e]);
+  if (ILV) {
+    // Interleaved by hand (a wave issues in order, see the forward): phase 1 alternates the 6*KC score
+    // MFMAs with the operand split + LDS stores of the NEXT tile (loaded one iteration earlier: two
+    // staging register sets); phase 2 (exposed) forms P and splits its first 16 rows; phase 3
+    // alternates the G MFMAs of rows 0-15 with the split of rows 16-31, then issues those of rows 16-31.
+    constexpr int NP = 4 * S::NLD, NS1 = 6 * S::KC, NG = B::CT * 6;
+    constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+    float4 ra[S::NLD], rb[S::NLD];
+    float lse_a = 0.f, w_a = 0.f, lse_b = 0.f, w_b = 0.f;
+    const int64_t last = tile1 - 1;
+    auto load_tile = [&](int64_t t, float4 (&r)[S::NLD], float& sl, float& sw) {
+      const int64_t j0 = min(t, last) * kTileJ;
+      stage_load<D>(y, y_scale, ny, j0, tid, r);
+      if (tid < kTileJ) {
+        const int64_t j = j0 + tid;
+        const bool on = j < ny && w_y != nullptr;
+        sw = on ? w_y[j] : 0.f;
+        sl = on ? lse_y[j] * kLog2e : 1.0e30f;
       }
-    }
-    // G^T[c][i] += yhat[j][c] * P[j][i], 16 streamed rows per k-chunk, six bf16 terms
-    const unsigned char* tbase = lds[cur] + 3 * S::PLANE + i32 * B::RT + 8 * h;
+    };
+    auto step = [&](int64_t tt, int cur, const float4 (&st)[S::NLD], float st_l, float st_w_v, float4 (&ld)[S::NLD],
+                    float& ld_l, float& ld_w) {
+      load_tile(tt + 2, ld, ld_l, ld_w);
+      unsigned char* out = lds[cur ^ 1];
+      unsigned sa[S::NLD][3], sb[S::NLD][3];
+      auto part = [&](int pi) {
+        const int u = pi / 4, k = pi % 4;
+        const int idx = tid + 256 * u;
+        const int row = idx / (D / 4), c4 = idx % (D / 4);
+        if (k == 0) {
+          split3(st[u].x, st[u].y, sa[u][0], sa[u][1], sa[u][2]);
+        } else if (k == 1) {
+          split3(st[u].z, st[u].w, sb[u][0], sb[u][1], sb[u][2]);
+        } else if (k == 2) {
+          unsigned char* p = out + row * S::ROWB + c4 * 8;
 #pragma unroll
-    for (int kc = 0; kc < 2; ++kc) {
-      u32x4 pp[3];
+          for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint2*>(p + pl * S::PLANE) = make_uint2(sa[u][pl], sb[u][pl]);
+          if (u == 0 && tid < kTileJ) {
+            st_lse[cur ^ 1][tid] = st_l;
+            st_w[cur ^ 1][tid] = st_w_v;
+          }
+        } else {
+          unsigned short* q = reinterpret_cast<unsigned short*>(out + 3 * S::PLANE + (4 * c4) * B::RT + row * 2);
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {
+            unsigned short* qq = q + pl * (B::TPLANE / 2);
+            qq[0] = (unsigned short)(sa[u][pl] & 0xffffu);
+            qq[B::RT / 2] = (unsigned short)(sa[u][pl] >> 16);
+            qq[2 * (B::RT / 2)] = (unsigned short)(sb[u][pl] & 0xffffu);
+            qq[3 * (B::RT / 2)] = (unsigned short)(sb[u][pl] >> 16);
+          }
+        }
+      };
+      // phase 1: S^T tile (the forward's MFMA order) + staging of the next tile
+      f32x16 acc;
       {
-        unsigned q[3][4];
+        const unsigned char* base = lds[cur] + i32 * S::ROWB + h * (S::KH * 2);
+        u32x4 ap[2][3];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) split3(acc[0][8 * kc + 2 * e], acc[0][8 * kc + 2 * e + 1], q[0][e], q[1][e], q[2][e]);
+        for (int pl = 0; pl < 3; ++pl) ap[0][pl] = *reinterpret_cast<const u32x4*>(base + pl * S::PLANE);
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) pp[pl] = (u32x4){q[pl][0], q[pl][1], q[pl][2], q[pl][3]};
+        for (int c = 0; c < S::KC; ++c) {
+          if (c + 1 < S::KC) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+              ap[(c + 1) & 1][pl] = *reinterpret_cast<const u32x4*>(base + pl * S::PLANE + 16 * (c + 1));
+          }
+#pragma unroll
+          for (int term = 0; term < 6; ++term) {
+            const int slot = c * 6 + term;
+            f32x16 cin = acc;
+            if (slot == 0) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) cin[r] = 0.f;
+            }
+            acc = mfma_bf16(ap[c & 1][TA[term]], bq[0][TB[term]][c], cin);
+#pragma unroll
+            for (int pi = slot * NP / NS1; pi < (slot + 1) * NP / NS1; ++pi) part(pi);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
       }
+      // phase 2: P in place of the scores, first half split
+      const int64_t j0 = tt * kTileJ;
+      const bool ragged = j0 + kTileJ > ny;
 #pragma unroll
-      for (int c = 0; c < B::CT; ++c) {
-        u32x4 ya[3];
+      for (int g = 0; g < 4; ++g) {
+        const float4 lr = *reinterpret_cast<const float4*>(&st_lse[cur][8 * g + 4 * h]);
+        const float4 wr = *reinterpret_cast<const float4*>(&st_w[cur][8 * g + 4 * h]);
+        const float lre[4] = {lr.x, lr.y, lr.z, lr.w};
+        const float wre[4] = {wr.x, wr.y, wr.z, wr.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          const bool dead = ragged && (j0 + acc_row(r, h) >= ny);
+          const float sc = dead ? -INFINITY : acc[r];
+          acc[r] = wl * __builtin_amdgcn_exp2f(sc - lse2l) + wre[e] * __builtin_amdgcn_exp2f(sc - lre[e]);
+        }
+      }
+      unsigned pq[2][3][4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) split3(acc[2 * e], acc[2 * e + 1], pq[0][0][e], pq[0][1][e], pq[0][2][e]);
+      __builtin_amdgcn_sched_barrier(0);
+      // phase 3: G^T[c][i] += yhat[j][c] * P[j][i]
+      const unsigned char* tbase = lds[cur] + 3 * S::PLANE + i32 * B::RT + 8 * h;
+      auto load_ya = [&](int grp, u32x4 (&ya)[3]) {     // grp = kc * CT + c
+        const int kc = grp / B::CT, c = grp % B::CT;
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
           const unsigned char* p = tbase + pl * B::TPLANE + (32 * c) * B::RT + 32 * kc;
@@ -972,16 +1032,111 @@ __global__ __launch_bounds__(256, 2) void infonce_bwd_b3_kernel(
           const uint2 hi = *reinterpret_cast<const uint2*>(p + 16);
           ya[pl] = (u32x4){lo.x, lo.y, hi.x, hi.y};
         }
-        gacc[c] = mfma_bf16(ya[2], pp[0], gacc[c]);
-        gacc[c] = mfma_bf16(ya[0], pp[2], gacc[c]);
-        gacc[c] = mfma_bf16(ya[1], pp[1], gacc[c]);
-        gacc[c] = mfma_bf16(ya[1], pp[0], gacc[c]);
-        gacc[c] = mfma_bf16(ya[0], pp[1], gacc[c]);
-        gacc[c] = mfma_bf16(ya[0], pp[0], gacc[c]);
+      };
+      u32x4 ya[2][3];
+      load_ya(0, ya[0]);
+#pragma unroll
+      for (int grp = 0; grp < 2 * B::CT; ++grp) {
+        const int kc = grp / B::CT, c = grp % B::CT;
+        if (grp + 1 < 2 * B::CT) load_ya(grp + 1, ya[(grp + 1) & 1]);
+        u32x4 pp[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) pp[pl] = (u32x4){pq[kc][pl][0], pq[kc][pl][1], pq[kc][pl][2], pq[kc][pl][3]};
+#pragma unroll
+        for (int term = 0; term < 6; ++term) {
+          gacc[c] = mfma_bf16(ya[grp & 1][TA[term]], pp[TB[term]], gacc[c]);
+          if (kc == 0) {                                   // split of rows 16-31 under the MFMAs of rows 0-15
+            const int slot = c * 6 + term;
+#pragma unroll
+            for (int e = slot * 4 / NG; e < (slot + 1) * 4 / NG; ++e)
+              split3(acc[8 + 2 * e], acc[8 + 2 * e + 1], pq[1][0][e], pq[1][1][e], pq[1][2][e]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
+      __syncthreads();
+    };
+    if (tile0 < tile1) {
+      load_tile(tile0, ra, lse_a, w_a);
+#pragma unroll
+      for (int u = 0; u < S::NLD; ++u) stage_store_b3t_one<D>(lds[0], tid, ra[u], u);
+      if (tid < kTileJ) {
+        st_lse[0][tid] = lse_a;
+        st_w[0][tid] = w_a;
+      }
+      load_tile(tile0 + 1, ra, lse_a, w_a);
     }
-    if (more) store_tile(cur ^ 1);
     __syncthreads();
+    for (int64_t tt = tile0; tt < tile1; tt += 2) {
+      step(tt, 0, ra, lse_a, w_a, rb, lse_b, w_b);
+      if (tt + 1 < tile1) step(tt + 1, 1, rb, lse_b, w_b, ra, lse_a, w_a);
+    }
+  } else {
+    if (tile0 < tile1) {
+      stage_load<D>(y, y_scale, ny, tile0 * kTileJ, tid, regs);
+      load_stats(tile0 * kTileJ);
+      store_tile(0);
+    }
+    __syncthreads();
+    for (int64_t tt = tile0; tt < tile1; ++tt) {
+      const int cur = (int)((tt - tile0) & 1);
+      const bool more = tt + 1 < tile1;
+      if (more) {
+        stage_load<D>(y, y_scale, ny, (tt + 1) * kTileJ, tid, regs);
+        load_stats((tt + 1) * kTileJ);
+      }
+      f32x16 acc[1];
+      score_tile_b3<D, 1>(lds[cur], i32, h, bq, acc);
+      const int64_t j0 = tt * kTileJ;
+      const bool ragged = j0 + kTileJ > ny;
+      // P in place of the scores
+  #pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 lr = *reinterpret_cast<const float4*>(&st_lse[cur][8 * g + 4 * h]);
+        const float4 wr = *reinterpret_cast<const float4*>(&st_w[cur][8 * g + 4 * h]);
+        const float lre[4] = {lr.x, lr.y, lr.z, lr.w};
+        const float wre[4] = {wr.x, wr.y, wr.z, wr.w};
+  #pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          const bool dead = ragged && (j0 + acc_row(r, h) >= ny);
+          const float sc = dead ? -INFINITY : acc[0][r];
+          acc[0][r] = wl * __builtin_amdgcn_exp2f(sc - lse2l) + wre[e] * __builtin_amdgcn_exp2f(sc - lre[e]);
+        }
+      }
+      // G^T[c][i] += yhat[j][c] * P[j][i], 16 streamed rows per k-chunk, six bf16 terms
+      const unsigned char* tbase = lds[cur] + 3 * S::PLANE + i32 * B::RT + 8 * h;
+  #pragma unroll
+      for (int kc = 0; kc < 2; ++kc) {
+        u32x4 pp[3];
+        {
+          unsigned q[3][4];
+  #pragma unroll
+          for (int e = 0; e < 4; ++e) split3(acc[0][8 * kc + 2 * e], acc[0][8 * kc + 2 * e + 1], q[0][e], q[1][e], q[2][e]);
+  #pragma unroll
+          for (int pl = 0; pl < 3; ++pl) pp[pl] = (u32x4){q[pl][0], q[pl][1], q[pl][2], q[pl][3]};
+        }
+  #pragma unroll
+        for (int c = 0; c < B::CT; ++c) {
+          u32x4 ya[3];
+  #pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {
+            const unsigned char* p = tbase + pl * B::TPLANE + (32 * c) * B::RT + 32 * kc;
+            const uint2 lo = *reinterpret_cast<const uint2*>(p);
+            const uint2 hi = *reinterpret_cast<const uint2*>(p + 16);
+            ya[pl] = (u32x4){lo.x, lo.y, hi.x, hi.y};
+          }
+          gacc[c] = mfma_bf16(ya[2], pp[0], gacc[c]);
+          gacc[c] = mfma_bf16(ya[0], pp[2], gacc[c]);
+          gacc[c] = mfma_bf16(ya[1], pp[1], gacc[c]);
+          gacc[c] = mfma_bf16(ya[1], pp[0], gacc[c]);
+          gacc[c] = mfma_bf16(ya[0], pp[1], gacc[c]);
+          gacc[c] = mfma_bf16(ya[0], pp[0], gacc[c]);
+        }
+      }
+      if (more) store_tile(cur ^ 1);
+      __syncthreads();
+    }
   }
 
   // gacc[c] register rr of lane (i, h) is column 32*c + acc_row(rr, h) of row i
@@ -1069,9 +1224,15 @@ int32_t launch_bwd(const float* x, const float* x_scale, int64_t mx, const float
     if (use_b3(D)) {
       const FwdPlan p = plan_bwd_rows(mx, ny, D, BwdB3<D>::ROWS_PER_BLOCK);
       float* gpart = p.nsplit == 1 ? g : reinterpret_cast<float*>(workspace);
-      hipLaunchKernelGGL((infonce_bwd_b3_kernel<D>), dim3((unsigned)(p.m_blocks * p.nsplit)), dim3(256), 0, s, x,
-                         x_scale, mx, y, y_scale, ny, inv_tau * kLog2e, inv_tau, lse_x, w_x, lse_y, w_y, p.nsplit,
-                         p.tiles_per_split, gpart);
+      const char* ie = getenv("GCR_INFONCE_BWD_ILV");   // A/B knob
+      if (ie != nullptr && ie[0] == '0')
+        hipLaunchKernelGGL((infonce_bwd_b3_kernel<D, false>), dim3((unsigned)(p.m_blocks * p.nsplit)), dim3(256), 0, s,
+                           x, x_scale, mx, y, y_scale, ny, inv_tau * kLog2e, inv_tau, lse_x, w_x, lse_y, w_y, p.nsplit,
+                           p.tiles_per_split, gpart);
+      else
+        hipLaunchKernelGGL((infonce_bwd_b3_kernel<D, true>), dim3((unsigned)(p.m_blocks * p.nsplit)), dim3(256), 0, s,
+                           x, x_scale, mx, y, y_scale, ny, inv_tau * kLog2e, inv_tau, lse_x, w_x, lse_y, w_y, p.nsplit,
+                           p.tiles_per_split, gpart);
       int32_t st = GCR_LAUNCH_STATUS();
       if (st != GCR_OK) return st;
       if (p.nsplit > 1) {

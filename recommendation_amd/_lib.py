@@ -33,6 +33,7 @@ SIGNATURES = {
     "gcr_neg_sample": (c_int32, [_P, _P, _P, c_int64, c_int32, c_int64, c_int64, c_uint64, c_uint64, c_int32, _P, _P]),
     "gcr_edge_mask_bits": (c_int32, [c_int64, c_float, c_uint64, _P, _P, _P]),
     "gcr_row_inv_norm_f32": (c_int32, [_P, c_int64, c_int32, c_float, _P, _P]),
+    "gcr_infonce_engine": (c_int32, [c_int32]),
     "gcr_infonce_fwd_workspace_bytes": (c_int64, [c_int64, c_int64, c_int32]),
     "gcr_infonce_fwd_f32": (c_int32, [_P, _P, c_int64, _P, _P, c_int64, c_int32, c_float, _P, _P, c_float, _P, _P]),
     "gcr_pos_logit_f32": (c_int32, [_P, _P, _P, _P, _P, c_int64, c_int64, c_int32, c_float, _P, _P]),

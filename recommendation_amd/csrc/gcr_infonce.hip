@@ -1559,6 +1559,8 @@ extern "C" int32_t gcr_kmeans_update_f32(const float* x, int64_t n, int32_t d, c
   return GCR_LAUNCH_STATUS();
 }
 
+extern "C" int32_t gcr_infonce_engine(int32_t d) { return dim_supported(d) && use_b3(d) ? 1 : 0; }
+
 extern "C" int64_t gcr_infonce_fwd_workspace_bytes(int64_t m, int64_t n, int32_t d) {
   if (m <= 0 || n <= 0 || !dim_supported(d)) return 0;
   // large enough for either engine (the choice is made per call)

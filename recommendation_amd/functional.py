@@ -392,10 +392,14 @@ class _InfoNCEStats(torch.autograd.Function):
         a_p, b_p = _pad_dim(a).contiguous(), _pad_dim(b).contiguous()
         sa = row_inv_norm(a_p) if normalize else None
         sb = row_inv_norm(b_p) if normalize else None
-        # unit-norm rows bound every logit by 1/tau: row and column LSE come out of ONE pass (the
-        # column sums by float atomics); COL_DETERMINISTIC forces the bitwise-reproducible second
-        # pass with the roles swapped, which is also the path for un-normalised inputs
-        one_pass = want_col and normalize and inv_tau <= 40.0 and not COL_DETERMINISTIC
+        # unit-norm rows bound every logit by 1/tau: on the f32-MFMA engine row and column LSE come out
+        # of ONE pass (the column sums by float atomics: 15.9 vs 21.0 ms at 100K x 100K);
+        # COL_DETERMINISTIC forces the bitwise-reproducible second pass with the roles swapped, which
+        # is also the path for un-normalised inputs — and for the split-operand engine, whose MFMA
+        # work is cheap enough that the second pass costs no more than the column-sum epilogue
+        # (11.6 vs 11.6 ms at 100K x 100K, 0.49 vs 0.65 ms at 20K x 20K; scripts/perf_infonce_sym.py)
+        one_pass = want_col and normalize and inv_tau <= 40.0 and not COL_DETERMINISTIC and \
+            _lib.lib().gcr_infonce_engine(a_p.shape[1]) == 0
         if one_pass:
             lse, col = infonce_lse_raw(a_p, sa, b_p, sb, inv_tau, col_bound=inv_tau * 1.0001)
         else:

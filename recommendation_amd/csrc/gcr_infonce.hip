@@ -21,6 +21,8 @@
 // Grid = anchor blocks x column splits; split partials (max, sum) are merged by a second kernel.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "gcr_common.h"
 
 namespace {
@@ -1399,74 +1401,154 @@ __global__ __launch_bounds__(256, (D <= 64 ? 3 : 2)) void kmeans_assign_kernel(
   }
 }
 
-// the same on the split-operand engine (d <= 128)
+// The same on the split-operand engine (d <= 128), software-pipelined by hand like the InfoNCE forward.
+// -0.5 ||c||^2 rides in as the MFMA C operand of the tile's first product; the running arg-max costs
+// three VALU instructions per score (compare, select the register number, max) plus one tile-number
+// select per tile: a lane walks its rows in increasing centroid id, so a strict `>` keeps the smallest
+// id among equal scores; the two lane halves are merged with an explicit id comparison at the end.
 template <int D>
 __global__ __launch_bounds__(256, 2) void kmeans_assign_b3_kernel(
     const float* __restrict__ x, int64_t n, const float* __restrict__ cent, const float* __restrict__ half_sq,
     int64_t k, int64_t* __restrict__ assign, float* __restrict__ best_out) {
   using S = ShapeB3<D>;
+  constexpr int NS = 6 * S::KC * S::NT, NU = 16 * S::NT + S::NLD;
+  constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
   __shared__ __align__(16) unsigned char lds[2][3 * S::PLANE];
   __shared__ __align__(16) float st_bias[2][kTileJ];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i32 = lane & 31, h = lane >> 5;
   const int64_t i0 = ((int64_t)blockIdx.x * 4 + wave) * (32 * S::NT);
-  u32x4 bfrag[S::NT][3][S::KC];
+  u32x4 bq[S::NT][3][S::KC];
 #pragma unroll
-  for (int t = 0; t < S::NT; ++t) load_stationary_b3<D>(x, nullptr, n, i0 + 32 * t + i32, h, 1.0f, bfrag[t]);
+  for (int t = 0; t < S::NT; ++t) load_stationary_b3<D>(x, nullptr, n, i0 + 32 * t + i32, h, 1.0f, bq[t]);
   float best[S::NT];
-  int bidx[S::NT];
+  int btile[S::NT], breg[S::NT];
 #pragma unroll
   for (int t = 0; t < S::NT; ++t) {
     best[t] = -INFINITY;
-    bidx[t] = 0x7fffffff;
+    btile[t] = 0;
+    breg[t] = 0;
   }
   const int64_t tiles = (k + kTileJ - 1) / kTileJ;
+  const int64_t last = tiles - 1;
   float4 regs[S::NLD];
   float bias = 0.f;
-  auto load_bias = [&](int64_t j0) {
-    if (tid < kTileJ) bias = (j0 + tid < k) ? -half_sq[j0 + tid] : -INFINITY;  // rows past k never win
+  auto load_tile = [&](int64_t t) {
+    const int64_t j0 = min(t, last) * kTileJ;
+    stage_load<D>(cent, nullptr, k, j0, tid, regs);
+    if (tid < kTileJ) bias = (j0 + tid < k) ? -half_sq[j0 + tid] : -INFINITY;   // rows past k never win
   };
-  stage_load<D>(cent, nullptr, k, 0, tid, regs);
-  load_bias(0);
-  stage_store_b3<D>(lds[0], tid, regs);
-  if (tid < kTileJ) st_bias[0][tid] = bias;
-  __syncthreads();
-  for (int64_t tt = 0; tt < tiles; ++tt) {
-    const int cur = (int)(tt & 1);
-    const int64_t nxt = tt + 1 < tiles ? tt + 1 : tt;
-    stage_load<D>(cent, nullptr, k, nxt * kTileJ, tid, regs);
-    load_bias(nxt * kTileJ);
-    f32x16 acc[S::NT];
-    score_tile_b3<D, S::NT>(lds[cur], i32, h, bfrag, acc);
-    const int j0 = (int)(tt * kTileJ);
+  // one tile: scores of the tile in lds[buf] into `nxt` (C = bias), optionally interleaved with the
+  // arg-max over `cur` (the previous tile, number tt) and the staging of the tile held in `regs`
+  auto tile = [&](auto with_cur, const f32x16 (&cur)[S::NT], f32x16 (&nxt)[S::NT], int64_t tt, int buf) {
+    constexpr bool CUR = decltype(with_cur)::value;
+    const unsigned char* base = lds[buf] + i32 * S::ROWB + h * (S::KH * 2);
+    unsigned char* out = lds[buf ^ 1];
+    float binit[16];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const float4 bb = *reinterpret_cast<const float4*>(&st_bias[cur][8 * g + 4 * h]);
-      const float be[4] = {bb.x, bb.y, bb.z, bb.w};
+      const float4 bb = *reinterpret_cast<const float4*>(&st_bias[buf][8 * g + 4 * h]);
+      binit[4 * g + 0] = bb.x; binit[4 * g + 1] = bb.y; binit[4 * g + 2] = bb.z; binit[4 * g + 3] = bb.w;
+    }
+    float bprev[S::NT];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int r = 4 * g + e;
-        const int j = j0 + acc_row(r, h);
+    for (int t = 0; t < S::NT; ++t) bprev[t] = best[t];
+    auto micro = [&](int m) {
+      if (m < 16 * S::NT) {
+        const int r = m / S::NT, t = m % S::NT;
+        const float v = cur[t][r];
+        breg[t] = v > best[t] ? r : breg[t];
+        best[t] = fmaxf(best[t], v);
+      } else {
+        const int u = m - 16 * S::NT;
+        stage_store_b3_one<D>(out, tid, regs[u], u);
+        if (u == 0 && tid < kTileJ) st_bias[buf ^ 1][tid] = bias;
+      }
+    };
+    u32x4 ap[2][3];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) ap[0][pl] = *reinterpret_cast<const u32x4*>(base + pl * S::PLANE);
+#pragma unroll
+    for (int c = 0; c < S::KC; ++c) {
+      if (c + 1 < S::KC) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          ap[(c + 1) & 1][pl] = *reinterpret_cast<const u32x4*>(base + pl * S::PLANE + 16 * (c + 1));
+      }
+#pragma unroll
+      for (int term = 0; term < 6; ++term) {
 #pragma unroll
         for (int t = 0; t < S::NT; ++t) {
-          const float v = acc[t][r] + be[e];
-          const bool better = v > best[t] || (v == best[t] && j < bidx[t]);
-          best[t] = better ? v : best[t];
-          bidx[t] = better ? j : bidx[t];
+          const int slot = (c * 6 + term) * S::NT + t;
+          f32x16 cin = nxt[t];
+          if (c == 0 && term == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cin[r] = binit[r];
+          }
+          nxt[t] = mfma_bf16(ap[c & 1][TA[term]], bq[t][TB[term]][c], cin);
+          if (CUR) {
+#pragma unroll
+            for (int u = slot * NU / NS; u < (slot + 1) * NU / NS; ++u) micro(u);
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
-    stage_store_b3<D>(lds[cur ^ 1], tid, regs);
-    if (tid < kTileJ) st_bias[cur ^ 1][tid] = bias;
+    if (CUR) {
+#pragma unroll
+      for (int t = 0; t < S::NT; ++t) {
+        btile[t] = best[t] > bprev[t] ? (int)tt : btile[t];
+        asm volatile("" : "+v"(best[t]), "+v"(breg[t]), "+v"(btile[t]));
+      }
+    }
+  };
+  auto argmax_only = [&](const f32x16 (&cur)[S::NT], int64_t tt) {
+#pragma unroll
+    for (int t = 0; t < S::NT; ++t) {
+      const float bp = best[t];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        breg[t] = cur[t][r] > best[t] ? r : breg[t];
+        best[t] = fmaxf(best[t], cur[t][r]);
+      }
+      btile[t] = best[t] > bp ? (int)tt : btile[t];
+    }
+  };
+  f32x16 acc_a[S::NT], acc_b[S::NT];
+  load_tile(0);
+  stage_store_b3<D>(lds[0], tid, regs);
+  if (tid < kTileJ) st_bias[0][tid] = bias;
+  load_tile(1);
+  __syncthreads();
+  tile(std::false_type{}, acc_b, acc_a, 0, 0);          // scores of tile 0; nothing to reduce yet
+  stage_store_b3<D>(lds[1], tid, regs);
+  if (tid < kTileJ) st_bias[1][tid] = bias;
+  __syncthreads();
+  int64_t tt = 0;
+  for (; tt + 2 <= last; tt += 2) {
+    load_tile(tt + 2);
+    tile(std::true_type{}, acc_a, acc_b, tt, 1);
     __syncthreads();
+    load_tile(tt + 3);
+    tile(std::true_type{}, acc_b, acc_a, tt + 1, 0);
+    __syncthreads();
+  }
+  if (tt < last) {
+    load_tile(tt + 2);
+    tile(std::true_type{}, acc_a, acc_b, tt, 1);
+    __syncthreads();
+    argmax_only(acc_b, last);
+  } else {
+    argmax_only(acc_a, last);
   }
 #pragma unroll
   for (int t = 0; t < S::NT; ++t) {
+    const int jl = best[t] > -INFINITY ? btile[t] * kTileJ + (breg[t] & 3) + 8 * (breg[t] >> 2) + 4 * h : 0x7fffffff;
     const float v_o = __shfl_xor(best[t], 32, 64);
-    const int j_o = __shfl_xor(bidx[t], 32, 64);
-    const bool other = v_o > best[t] || (v_o == best[t] && j_o < bidx[t]);
+    const int j_o = __shfl_xor(jl, 32, 64);
+    const bool other = v_o > best[t] || (v_o == best[t] && j_o < jl);
     const float v = other ? v_o : best[t];
-    const int j = other ? j_o : bidx[t];
+    const int j = other ? j_o : jl;
     const int64_t row = i0 + 32 * t + i32;
     if (h == 0 && row < n) {
       assign[row] = j;

@@ -2,10 +2,13 @@
 
 The reference delegates to `faiss.Kmeans(d, k, gpu=False).train(x)` + `kmeans.index.search(x, 1)`;
 faiss is an un-vendored dependency that is not installed here, so parity with it is UNPINNED.  What
-is implemented is plain Lloyd iteration with faiss' defaults that matter for the result shape
-(niter = 20, initial centroids = a random sample of k points, L2 nearest centroid); an empty
-cluster keeps its previous centroid (faiss re-splits a big cluster instead).  The assignment runs on
-the fp32 MFMA tile engine (gcr_kmeans_assign_f32), the update is float-atomic row adds.
+is implemented is faiss' published `Clustering::train` with its defaults: if n > 256 k the
+centroids are trained on a random subsample of 256 k points (max_points_per_centroid), initial
+centroids = a random sample of k training points, niter = 20 Lloyd iterations with L2 nearest
+centroid, then EVERY point is assigned against the final centroids (the `index.search`).  Differences:
+the random draws are torch's, not faiss' generator, and an empty cluster keeps its previous centroid
+(faiss re-splits a big cluster instead).  The assignment runs on the MFMA tile engine
+(gcr_kmeans_assign_f32), the update is float-atomic row adds.
 """
 from __future__ import annotations
 
@@ -24,7 +27,7 @@ def kmeans_assign(x, centroids, half_sq):
     return assign
 
 
-def run_kmeans(x, k, niter=20, seed=1234, init_centroids=None):
+def run_kmeans(x, k, niter=20, seed=1234, init_centroids=None, max_points_per_centroid=256):
     """ncl.py:347-356.  x: float32 [n, d] on the GPU.  Returns (centroids [k', d], assignment int64 [n])
     with k' = min(k, max(2, n // 39)) exactly as ncl.py:350-351 clamps it."""
     _lib.require_cuda(x)
@@ -32,11 +35,16 @@ def run_kmeans(x, k, niter=20, seed=1234, init_centroids=None):
         raise ValueError("x must be float32 [n, d]")
     n, d_orig = x.shape
     k = min(int(k), max(2, n // 39))
-    if init_centroids is None:
-        g = torch.Generator(device=x.device).manual_seed(int(seed))
-        init_centroids = x[torch.randperm(n, device=x.device, generator=g)[:k]]
     xp = Fn._pad_dim(x.detach()).contiguous()
-    cent = Fn._pad_dim(init_centroids.detach().to(torch.float32)).contiguous().clone()
+    g = torch.Generator(device=x.device).manual_seed(int(seed))
+    xt = xp                                            # training set
+    if max_points_per_centroid and n > k * max_points_per_centroid:
+        xt = xp[torch.randperm(n, device=x.device, generator=g)[:k * max_points_per_centroid]]
+    n_train = xt.shape[0]
+    if init_centroids is None:
+        cent = xt[torch.randperm(n_train, device=x.device, generator=g)[:k]].clone()
+    else:
+        cent = Fn._pad_dim(init_centroids.detach().to(torch.float32)).contiguous().clone()
     k = cent.shape[0]
     d = xp.shape[1]
     L = _lib.lib()
@@ -46,12 +54,12 @@ def run_kmeans(x, k, niter=20, seed=1234, init_centroids=None):
     stream = _lib.cur_stream(x.device)
 
     def update(assign, n_rows):
-        _lib.check(L.gcr_kmeans_update_f32(_lib.dptr(xp), n_rows, d, _lib.dptr(assign), k, _lib.dptr(cent),
+        _lib.check(L.gcr_kmeans_update_f32(_lib.dptr(xt), n_rows, d, _lib.dptr(assign), k, _lib.dptr(cent),
                                            _lib.dptr(half_sq), _lib.dptr(sums), _lib.dptr(counts), stream),
                    "gcr_kmeans_update_f32")
 
     update(None, 0)                      # half_sq of the initial centroids
     for _ in range(niter):
-        update(kmeans_assign(xp, cent, half_sq), n)
+        update(kmeans_assign(xt, cent, half_sq), n_train)
     assign = kmeans_assign(xp, cent, half_sq)       # kmeans.index.search(x, 1) against the final centroids
     return cent[:, :d_orig].contiguous(), assign

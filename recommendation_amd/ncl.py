@@ -49,9 +49,14 @@ class NCLModel:
         self.bestPerformance = []
 
     # ncl.py:340-356
-    def e_step(self):
+    def e_step(self, user_emb=None, item_emb=None):
+        """`user_emb` / `item_emb`: the encoder outputs when the caller has just computed them with the
+        current parameters (the training step has: the reference runs the same forward a second time,
+        ncl.py:341, with identical results)."""
         with torch.no_grad():
-            user_emb, item_emb, _ = self.model()
+            if user_emb is None or item_emb is None:
+                user_emb, item_emb, _ = self.model()
+            user_emb, item_emb = user_emb.detach(), item_emb.detach()
             self.user_centroids, self.user_2cluster = run_kmeans(user_emb.contiguous(), self.k, seed=self.seed)
             self.item_centroids, self.item_2cluster = run_kmeans(item_emb.contiguous(), self.k, seed=self.seed + 1)
 
@@ -74,7 +79,7 @@ class NCLModel:
         initial_emb = emb_list[0]
         context_emb = emb_list[-1] if self.hyper_layers * 2 >= len(emb_list) else emb_list[self.hyper_layers * 2]
         ssl_loss = self.ssl_layer_loss(context_emb, initial_emb, user_idx, pos_idx)
-        self.e_step()                                                       # ncl.py:324 (every batch, Q8)
+        self.e_step(rec_user_emb, rec_item_emb)                             # ncl.py:324 (every batch, Q8)
         proto_loss = self.ProtoNCE_loss(initial_emb, user_idx, pos_idx)
         total = rec_loss + Ls.l2_reg_loss(self.reg, user_emb, pos_emb, neg_emb) / self.batch_size + ssl_loss + proto_loss
         optimizer.zero_grad()

@@ -45,7 +45,7 @@ def test_lloyd_iterations_match_restatement():
     a0 = kmeans_assign(xt, it, 0.5 * (it * it).sum(1)).cpu().numpy()
     ref_a0 = O.kmeans_lloyd(x, init, niter=0)[1]
     assert (a0 == ref_a0).mean() > 0.999
-    cent, assign = run_kmeans(xt, k, niter=1, init_centroids=it)
+    cent, assign = run_kmeans(xt, k, niter=1, init_centroids=it, max_points_per_centroid=0)   # all 8000 points train
     sums = np.zeros((k, d))
     np.add.at(sums, a0, x.astype(np.float64))
     cnt = np.bincount(a0, minlength=k)
@@ -55,7 +55,7 @@ def test_lloyd_iterations_match_restatement():
     assert (assign.cpu().numpy() == d2.argmin(1)).mean() > 0.999
     # 20 steps: the trajectory is chaotic at cluster boundaries (a flipped near-tie moves centroids),
     # so compare what k-means optimises: the within-cluster sum of squares
-    cent, assign = run_kmeans(xt, k, niter=20, init_centroids=it)
+    cent, assign = run_kmeans(xt, k, niter=20, init_centroids=it, max_points_per_centroid=0)
     ref_c, ref_a = O.kmeans_lloyd(x, init, niter=20)
     wss = float(((xt - cent[assign]) ** 2).sum())
     ref_wss = float(((x.astype(np.float64) - ref_c[ref_a]) ** 2).sum())
@@ -78,3 +78,25 @@ def test_kmeans_at_ncl_scale():
     sub = torch.arange(0, 1_000_000, 997, device="cuda")
     d2 = torch.cdist(x[sub].double(), c3.double()) ** 2
     assert bool((d2.gather(1, a3[sub, None]).squeeze(1) <= d2.min(1).values * (1 + 1e-5) + 1e-6).all())
+
+
+def test_training_subsample_like_faiss():
+    """faiss.Clustering trains on at most 256 points per centroid and then assigns every point
+    (index.search): with n = 40 x 256 k the subsample path runs; well-separated blobs must still be
+    recovered, every point must sit with its nearest centroid, and switching the cap off must give the
+    same partition quality."""
+    from recommendation_amd.kmeans import run_kmeans
+    rng = np.random.default_rng(3)
+    k, d, n = 8, 64, 8 * 256 * 40
+    centers = rng.standard_normal((k, d)) * 6
+    lab = rng.integers(0, k, n)
+    x = torch.from_numpy((centers[lab] + rng.standard_normal((n, d))).astype(np.float32)).cuda()
+    init = x[torch.from_numpy(np.array([np.flatnonzero(lab == c)[0] for c in range(k)])).cuda()]
+    c_sub, a_sub = run_kmeans(x, k, niter=20, init_centroids=init)
+    c_all, a_all = run_kmeans(x, k, niter=20, init_centroids=init, max_points_per_centroid=0)
+    assert a_sub.shape == (n,)
+    assert float((a_sub.cpu() == torch.from_numpy(lab)).float().mean()) > 0.999     # init[c] came from blob c
+    assert float((a_sub == a_all).float().mean()) > 0.999
+    np.testing.assert_allclose(c_sub.cpu().numpy(), centers, atol=0.35)            # means of ~256 samples each
+    d2 = torch.cdist(x[::97].double(), c_sub.double()) ** 2
+    assert bool((d2.gather(1, a_sub[::97, None]).squeeze(1) <= d2.min(1).values * (1 + 1e-5) + 1e-6).all())

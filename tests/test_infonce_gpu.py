@@ -187,6 +187,51 @@ def test_stats_grads_match_oracle(Fn, m, n, d, normalize, sym):
     _gclose(bt.grad, g2 + d_bn, rel=2e-4)
 
 
+@pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 63, 64, 65, 95, 96, 97, 127, 129, 161, 1023, 1025])
+def test_every_tile_count_parity_forward_and_backward(Fn, n):
+    """The software-pipelined kernels treat the first, the odd / even and the (ragged) last 32-row tile
+    of a column split differently: sweep the table length across those boundaries, values and both
+    gradients against the float64 oracle."""
+    rng = np.random.default_rng(n)
+    m, d = 45, 64
+    a = (rng.standard_normal((m, d)) * 0.4).astype(np.float32)
+    b = (rng.standard_normal((n, d)) * 0.4).astype(np.float32)
+    pos = rng.integers(0, n, m)
+    w = rng.standard_normal(m)
+    at, bt = _t(a, True), _t(b, True)
+    lse, pl = Fn.infonce_stats(at, bt, pos, 0.2, True)
+    ref_lse, s = O.row_lse_scores(a, b, 5.0, True)
+    np.testing.assert_allclose(lse.detach().cpu().numpy(), ref_lse, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(pl.detach().cpu().numpy(), s[np.arange(m), pos], rtol=1e-5, atol=1e-5)
+    ((lse - pl) * _t(w.astype(np.float32))).sum().backward()
+    g1, g2 = O.infonce_grads(a, b, pos, 5.0, True, w)
+    # n = 1: the exact gradient is 0 (softmax over one row), what is left is f32 cancellation noise of
+    # terms of size |w| / tau * |xhat| ~ 1 summed over the 45 anchors
+    floor = 1e-5 if n == 1 else 1e-8
+    _gclose(at.grad, g1, rel=2e-4, floor=floor)
+    _gclose(bt.grad, g2, rel=2e-4, floor=floor)
+
+
+@pytest.mark.parametrize("blocks", [64, 4096])
+def test_short_column_splits(Fn, monkeypatch, blocks):
+    """Column splits of one, two and three tiles (forced through the grid knob): the pipeline's
+    prologue / tail paths and the merge of many partials."""
+    monkeypatch.setenv("GCR_INFONCE_BLOCKS", str(blocks))
+    rng = np.random.default_rng(blocks)
+    m, n, d = 70, 2049, 64
+    a = (rng.standard_normal((m, d)) * 0.4).astype(np.float32)
+    b = (rng.standard_normal((n, d)) * 0.4).astype(np.float32)
+    w = rng.standard_normal(m)
+    at, bt = _t(a, True), _t(b, True)
+    lse, pl = Fn.infonce_stats(at, bt, None, 0.1, True)
+    ref_lse, s = O.row_lse_scores(a, b, 10.0, True)
+    np.testing.assert_allclose(lse.detach().cpu().numpy(), ref_lse, rtol=1e-5, atol=1e-5)
+    ((lse - pl) * _t(w.astype(np.float32))).sum().backward()
+    g1, g2 = O.infonce_grads(a, b, np.arange(m), 10.0, True, w)
+    _gclose(at.grad, g1, rel=2e-4)
+    _gclose(bt.grad, g2, rel=2e-4)
+
+
 @pytest.mark.parametrize("m,n,d,temp", [(300, 300, 64, 0.2), (1000, 257, 64, 0.05), (97, 4100, 128, 0.5), (64, 64, 32, 0.1)])
 def test_one_pass_column_lse_matches_two_pass_and_oracle(Fn, m, n, d, temp):
     """gcl.py:34 `cross_entropy(sim.T)`: column LSE from the same pass (atomics) vs the swapped-role

@@ -174,6 +174,18 @@ int32_t gcr_infonce_fwd_f32(const float* a, const float* a_scale, int64_t m,
                             void* workspace, void* stream);
 
 /*
+ * Same with flags.  GCR_INFONCE_EXCLUDE_DIAGONAL: the pair (i, j = i) is left out of every sum, i.e.
+ * lse[i] = log sum_{j != i} exp(s_ij) — the intra-view negatives of PyGCL's DualBranchContrast
+ * (univariate/grace.py:396-404: `neg_mask = 1 - eye` over the anchors themselves), a and b then being the
+ * same view.  Not combinable with col_sum.
+ */
+#define GCR_INFONCE_EXCLUDE_DIAGONAL 1u
+int32_t gcr_infonce_fwd_ex_f32(const float* a, const float* a_scale, int64_t m,
+                               const float* b, const float* b_scale, int64_t n, int32_t d,
+                               float inv_tau, float* lse, float* col_sum, float col_bound,
+                               void* workspace, uint32_t flags, void* stream);
+
+/*
  * out[i] = scale * a_scale[i] * b_scale[p] * <a_i, b_p>, p = pos[i] (pos == NULL: p = i) — the
  * positive logit (the diagonal of ncl.py:129 / gcl.py:32-34, `(norm_cu * norm_iu).sum(1) / t`
  * ncl.py:363).  An out-of-range pos yields NaN for that row.  Any d.
@@ -199,6 +211,11 @@ int32_t gcr_infonce_bwd_f32(const float* x, const float* x_scale, int64_t mx,
                             const float* y, const float* y_scale, int64_t ny, int32_t d, float inv_tau,
                             const float* lse_x, const float* w_x, const float* lse_y, const float* w_y,
                             float* g, void* workspace, void* stream);
+/* Same with flags: GCR_INFONCE_EXCLUDE_DIAGONAL gives P_ii = 0 (backward of gcr_infonce_fwd_ex_f32). */
+int32_t gcr_infonce_bwd_ex_f32(const float* x, const float* x_scale, int64_t mx,
+                               const float* y, const float* y_scale, int64_t ny, int32_t d, float inv_tau,
+                               const float* lse_x, const float* w_x, const float* lse_y, const float* w_y,
+                               float* g, void* workspace, uint32_t flags, void* stream);
 
 /*
  * Positive-logit term: gx[i,:] += coef[i] * inv_tau * yhat[p_i,:]  (plain add, row i is exclusive)

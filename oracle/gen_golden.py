@@ -310,8 +310,50 @@ def gen_rownorm():
     print("wrote rownorm.npz", out.nnz)
 
 
+def gen_grace():
+    """tests/golden/grace.npz: univariate/grace.py's DualBranchContrast(InfoNCE(tau), 'L2L', intraview_negs)
+    (:196-224, :380-419, :448-502) run as-is on seeded views.  grace.py imports torch_geometric at module
+    level (not installed), so the pure-torch classes are lifted out of its AST and executed unchanged.
+    Two variants per case: extra_neg_mask=None — the call the model makes; add_extra_mask then REPLACES the
+    sampler's negative mask by 1 - pos_mask, so the anchor's own row counts as a negative — and
+    extra_neg_mask=ones, which keeps the sampler's mask (diagonal of the intra-view block excluded)."""
+    import torch
+    import torch.nn.functional as F
+    from abc import ABC, abstractmethod
+    tree = ast.parse(open(os.path.join(REF, "univariate", "grace.py")).read())
+    names = {"_similarity", "Loss", "InfoNCE", "Sampler", "SameScaleSampler", "CrossScaleSampler", "get_sampler",
+             "add_extra_mask", "DualBranchContrast"}
+    wanted = [n for n in tree.body if isinstance(n, (ast.ClassDef, ast.FunctionDef)) and n.name in names]
+    assert {n.name for n in wanted} == names
+    ns = {"torch": torch, "F": F, "ABC": ABC, "abstractmethod": abstractmethod}
+    exec(compile(ast.Module(body=wanted, type_ignores=[]), "grace.py", "exec"), ns)
+    rng = np.random.default_rng(21)
+    out = {}
+    for m in (7, 257):
+        h1 = rng.standard_normal((m, 64)).astype(np.float32)
+        h2 = (h1 + 0.5 * rng.standard_normal((m, 64))).astype(np.float32)
+        out[f"h1_{m}"], out[f"h2_{m}"] = h1, h2
+        for tau in (0.2, 0.5):
+            for intra in (0, 1):
+                for keep_sampler_mask in (0, 1):
+                    if keep_sampler_mask and not intra:
+                        continue
+                    t1, t2 = torch.from_numpy(h1).requires_grad_(True), torch.from_numpy(h2).requires_grad_(True)
+                    model = ns["DualBranchContrast"](loss=ns["InfoNCE"](tau=tau), mode="L2L", intraview_negs=bool(intra))
+                    extra = torch.ones(m, 2 * m) if keep_sampler_mask else None
+                    loss = model(h1=t1, h2=t2, extra_neg_mask=extra)
+                    loss.backward()
+                    key = f"{m}_{tau}_{intra}_{keep_sampler_mask}"
+                    out[f"loss_{key}"] = np.float32(loss.item())
+                    out[f"g1_{key}"], out[f"g2_{key}"] = t1.grad.numpy(), t2.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "grace.npz"), **out)
+    print("wrote grace.npz", {k: float(v) for k, v in out.items() if k.startswith("loss_257_0.2")})
+
+
 if __name__ == "__main__":
-    if "--rownorm" in sys.argv:
+    if "--grace" in sys.argv:
+        gen_grace()
+    elif "--rownorm" in sys.argv:
         gen_rownorm()
     elif "--eval" in sys.argv:
         gen_eval()

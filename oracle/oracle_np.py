@@ -280,6 +280,28 @@ def proto_nce_loss(initial, user_idx, item_idx, num_users, user_centroids, user_
     return proto_reg * (lu + li)
 
 
+def grace_infonce(h1, h2, tau, intraview_negs=True, exclude_self=False):
+    """univariate/grace.py:218-224 + 396-419 + 448-502 (DualBranchContrast, L2L): dense float64.  sample =
+    [other view; own view]; pos_mask = [eye | 0]; the denominator runs over pos + neg masks.
+    exclude_self=False restates what add_extra_mask leaves when extra_neg_mask is None (neg = 1 - pos: the
+    anchor's own row is a negative), True the sampler's mask (`1 - eye` on the intra-view block)."""
+    a, b = row_l2_normalize(h1), row_l2_normalize(h2)
+    m = a.shape[0]
+
+    def one(x, y):
+        s_inter = x @ y.T / tau
+        mask = [np.ones((m, m), bool)]
+        blocks = [s_inter]
+        if intraview_negs:
+            blocks.append(x @ x.T / tau)
+            mask.append(~np.eye(m, dtype=bool) if exclude_self else np.ones((m, m), bool))
+        s, k = np.concatenate(blocks, 1), np.concatenate(mask, 1)
+        s_m = np.where(k, s, -np.inf)
+        return float(np.mean(_logsumexp(s_m, 1) - np.diag(s_inter)))
+
+    return 0.5 * (one(a, b) + one(b, a))
+
+
 def batch_softmax_loss(user_emb, item_emb, temperature):
     """ssl4rec.py:25-30: mean(-log(exp(pos/t) / sum_j exp(<u,i_j>/t) + 1e-6)) on normalised rows."""
     lse, s = row_lse_scores(user_emb, item_emb, 1.0 / temperature, normalize=True)

@@ -117,13 +117,20 @@ __device__ __forceinline__ void score_tile(const float* __restrict__ tile, int i
 
 // online-softmax update with one finished score tile; `rem` = table rows left from this lane's
 // first accumulator row (n_rows - j0 - 4h): rows at or past it are masked out (ragged last tile).
-template <int NT, bool MASK>
-__device__ __forceinline__ void lse_update(const f32x16 (&acc)[NT], int rem, float (&m_run)[NT], float (&l_run)[NT]) {
+// EXD: additionally the row whose in-tile offset (acc_row without the 4h) equals xr[t] is left out of
+// anchor tile t's sums (the excluded diagonal pair; xr[t] < 0: none in this tile).
+template <int NT, bool MASK, bool EXD = false>
+__device__ __forceinline__ void lse_update(const f32x16 (&acc)[NT], int rem, float (&m_run)[NT], float (&l_run)[NT],
+                                           const int* xr = nullptr) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     float v[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = (!MASK || (r & 3) + 8 * (r >> 2) < rem) ? acc[t][r] : -INFINITY;
+    for (int r = 0; r < 16; ++r) {
+      const int rc = (r & 3) + 8 * (r >> 2);
+      const bool keep = (!MASK || rc < rem) && !(EXD && rc == xr[t]);
+      v[r] = keep ? acc[t][r] : -INFINITY;
+    }
     float tmax = v[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, v[r]);
@@ -134,6 +141,13 @@ __device__ __forceinline__ void lse_update(const f32x16 (&acc)[NT], int rem, flo
     l_run[t] = l_run[t] * __builtin_amdgcn_exp2f(m_run[t] - m_new) + sum;
     m_run[t] = m_new;
   }
+}
+
+// in-tile offset of table row `i` for lane half h of the tile starting at j0 (matches (r&3)+8(r>>2) of
+// the register that holds it), or -1 when the row is not one of this lane's 16
+__device__ __forceinline__ int diag_offset(int64_t i, int64_t j0, int h) {
+  const int64_t d = i - j0 - 4 * h;
+  return (d >= 0 && d < 28) ? (int)d : -1;
 }
 
 __device__ __forceinline__ int rows_left(int64_t n_rows, int64_t j0, int h) {
@@ -162,7 +176,7 @@ __device__ __forceinline__ float half_wave_sum_to_last_lane(float v) {
   return v;
 }
 
-template <int D, bool COLSUM>
+template <int D, bool COLSUM, bool EXD = false>
 __global__ __launch_bounds__(256, (D <= 64 ? 3 : 2)) void infonce_fwd_kernel(const float* __restrict__ a,
                                                              const float* __restrict__ a_scale, int64_t m_rows,
                                                              const float* __restrict__ b,
@@ -206,7 +220,12 @@ __global__ __launch_bounds__(256, (D <= 64 ? 3 : 2)) void infonce_fwd_kernel(con
     stage_load<D>(b, b_scale, n_rows, nxt * kTileJ, tid, regs);
     f32x16 acc[S::NT];
     score_tile<D>(lds[cur], i32, h, bfrag, acc);
-    if (force_mask || (tt + 1) * kTileJ > n_rows)   // only the table's ragged last tile pays for the row mask
+    if (EXD) {                                      // diagonal pair (i, j = i) left out of the sums
+      int xr[S::NT];
+#pragma unroll
+      for (int t = 0; t < S::NT; ++t) xr[t] = diag_offset(i0 + 32 * t + i32, tt * kTileJ, h);
+      lse_update<S::NT, true, true>(acc, rows_left(n_rows, tt * kTileJ, h), m_run, l_run, xr);
+    } else if (force_mask || (tt + 1) * kTileJ > n_rows)   // only the table's ragged last tile pays for the row mask
       lse_update<S::NT, true>(acc, rows_left(n_rows, tt * kTileJ, h), m_run, l_run);
     else
       lse_update<S::NT, false>(acc, 64, m_run, l_run);
@@ -360,7 +379,7 @@ __device__ __forceinline__ void score_tile_b3(const unsigned char* __restrict__ 
   }
 }
 
-template <int D, bool COLSUM, bool PIPE>
+template <int D, bool COLSUM, bool PIPE, bool EXD = false>
 __global__ __launch_bounds__(256, 2) void infonce_fwd_b3_kernel(const float* __restrict__ a,
                                                                 const float* __restrict__ a_scale, int64_t m_rows,
                                                                 const float* __restrict__ b,
@@ -406,7 +425,12 @@ __global__ __launch_bounds__(256, 2) void infonce_fwd_b3_kernel(const float* __r
   };
   // the table's last tile is the only one that can be ragged
   auto epilogue_any = [&](const f32x16 (&acc)[S::NT], int64_t tt) {
-    if ((tt + 1) * kTileJ > n_rows)
+    if (EXD) {
+      int xr[S::NT];
+#pragma unroll
+      for (int t = 0; t < S::NT; ++t) xr[t] = diag_offset(i0 + 32 * t + i32, tt * kTileJ, h);
+      lse_update<S::NT, true, true>(acc, rows_left(n_rows, tt * kTileJ, h), m_run, l_run, xr);
+    } else if ((tt + 1) * kTileJ > n_rows)
       lse_update<S::NT, true>(acc, rows_left(n_rows, tt * kTileJ, h), m_run, l_run);
     else
       lse_update<S::NT, false>(acc, 64, m_run, l_run);
@@ -434,11 +458,16 @@ __global__ __launch_bounds__(256, 2) void infonce_fwd_b3_kernel(const float* __r
     score_tile_b3<D, S::NT>(lds[0], i32, h, bq, acc_a);
     stage_store_b3<D>(lds[1], tid, regs);
     __syncthreads();
-    auto step = [&](const f32x16 (&cur)[S::NT], f32x16 (&nxt)[S::NT], int64_t tt, int nb) {
+    auto step = [&](f32x16 (&cur)[S::NT], f32x16 (&nxt)[S::NT], int64_t tt, int nb) {
       stage_load<D>(b, b_scale, n_rows, min(tt + 2, last) * kTileJ, tid, regs);
       const unsigned char* base = lds[nb] + i32 * S::ROWB + h * (S::KH * 2);
       unsigned char* out = lds[nb ^ 1];
       float tmax[S::NT], m_new[S::NT], sum[S::NT];
+      int xr[S::NT];
+      if (EXD) {
+#pragma unroll
+        for (int t = 0; t < S::NT; ++t) xr[t] = diag_offset(i0 + 32 * t + i32, tt * kTileJ, h);
+      }
       // micro-unit m of the step's VALU work: m < 22*NT -> softmax unit m / NT of anchor tile m % NT
       // (0-3 partial max, 4 new max, 5-20 exp2-add of one register, 21 fold into the running sum);
       // then the operand split + LDS store of one staged float4; then (COLSUM) one register's column sums
@@ -457,6 +486,10 @@ __global__ __launch_bounds__(256, 2) void infonce_fwd_b3_kernel(const float* __r
         } else if (m >= 22 * S::NT) {
           stage_store_b3_one<D>(out, tid, regs[m - 22 * S::NT], m - 22 * S::NT);
         } else if (u < 4) {
+          if (EXD) {                                    // excluded diagonal pair: -inf before it is seen by max / exp2
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cur[t][4 * u + e] = (xr[t] == e + 8 * u) ? -INFINITY : cur[t][4 * u + e];
+          }
           const float x = fmaxf(fmaxf(cur[t][4 * u], cur[t][4 * u + 1]), fmaxf(cur[t][4 * u + 2], cur[t][4 * u + 3]));
           tmax[t] = u == 0 ? x : fmaxf(tmax[t], x);
         } else if (u == 4) {
@@ -684,7 +717,7 @@ struct BwdShape {
   static constexpr int ROWS_PER_BLOCK = 4 * 32 * NT;
 };
 
-template <int D>
+template <int D, bool EXD = false>
 __global__ __launch_bounds__(256, 2) void infonce_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ x_scale, int64_t mx, const float* __restrict__ y,
     const float* __restrict__ y_scale, int64_t ny, float scale2, float out_scale, const float* __restrict__ lse_x,
@@ -782,9 +815,11 @@ __global__ __launch_bounds__(256, 2) void infonce_bwd_kernel(
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int r = 4 * g + e;
-        const bool dead = ragged && (j0 + acc_row(r, h) >= ny);
+        const bool dead_j = ragged && (j0 + acc_row(r, h) >= ny);
 #pragma unroll
         for (int t = 0; t < B::NT; ++t) {
+          // EXD: the diagonal pair (stationary row i, streamed row j = i) carries no probability
+          const bool dead = dead_j || (EXD && diag_offset(i0 + 32 * t + i32, j0, h) == e + 8 * g);
           const float sc = dead ? -INFINITY : acc[t][r];
           acc[t][r] = wl[t] * __builtin_amdgcn_exp2f(sc - lse2l[t]) + wre[e] * __builtin_amdgcn_exp2f(sc - lre[e]);
         }
@@ -871,7 +906,7 @@ __device__ __forceinline__ void stage_store_b3t_one(unsigned char* __restrict__ 
   }
 }
 
-template <int D, bool ILV>
+template <int D, bool ILV, bool EXD = false>
 __global__ __launch_bounds__(256, 2) void infonce_bwd_b3_kernel(
     const float* __restrict__ x, const float* __restrict__ x_scale, int64_t mx, const float* __restrict__ y,
     const float* __restrict__ y_scale, int64_t ny, float scale2, float out_scale, const float* __restrict__ lse_x,
@@ -1005,6 +1040,7 @@ __global__ __launch_bounds__(256, 2) void infonce_bwd_b3_kernel(
       // phase 2: P in place of the scores, first half split
       const int64_t j0 = tt * kTileJ;
       const bool ragged = j0 + kTileJ > ny;
+      const int xr = EXD ? diag_offset(row_i, j0, h) : -1;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float4 lr = *reinterpret_cast<const float4*>(&st_lse[cur][8 * g + 4 * h]);
@@ -1014,7 +1050,7 @@ __global__ __launch_bounds__(256, 2) void infonce_bwd_b3_kernel(
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * g + e;
-          const bool dead = ragged && (j0 + acc_row(r, h) >= ny);
+          const bool dead = (ragged && (j0 + acc_row(r, h) >= ny)) || (EXD && xr == e + 8 * g);
           const float sc = dead ? -INFINITY : acc[r];
           acc[r] = wl * __builtin_amdgcn_exp2f(sc - lse2l) + wre[e] * __builtin_amdgcn_exp2f(sc - lre[e]);
         }
@@ -1091,6 +1127,7 @@ __global__ __launch_bounds__(256, 2) void infonce_bwd_b3_kernel(
       score_tile_b3<D, 1>(lds[cur], i32, h, bq, acc);
       const int64_t j0 = tt * kTileJ;
       const bool ragged = j0 + kTileJ > ny;
+      const int xr = EXD ? diag_offset(row_i, j0, h) : -1;
       // P in place of the scores
   #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -1101,7 +1138,7 @@ __global__ __launch_bounds__(256, 2) void infonce_bwd_b3_kernel(
   #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * g + e;
-          const bool dead = ragged && (j0 + acc_row(r, h) >= ny);
+          const bool dead = (ragged && (j0 + acc_row(r, h) >= ny)) || (EXD && xr == e + 8 * g);
           const float sc = dead ? -INFINITY : acc[0][r];
           acc[0][r] = wl * __builtin_amdgcn_exp2f(sc - lse2l) + wre[e] * __builtin_amdgcn_exp2f(sc - lre[e]);
         }
@@ -1221,13 +1258,17 @@ FwdPlan plan_bwd(int64_t mx, int64_t ny) {
 template <int D>
 int32_t launch_bwd(const float* x, const float* x_scale, int64_t mx, const float* y, const float* y_scale, int64_t ny,
                    float inv_tau, const float* lse_x, const float* w_x, const float* lse_y, const float* w_y, float* g,
-                   void* workspace, hipStream_t s) {
+                   void* workspace, bool exd, hipStream_t s) {
   if constexpr (D <= 64) {
     if (use_b3(D)) {
       const FwdPlan p = plan_bwd_rows(mx, ny, D, BwdB3<D>::ROWS_PER_BLOCK);
       float* gpart = p.nsplit == 1 ? g : reinterpret_cast<float*>(workspace);
       const char* ie = getenv("GCR_INFONCE_BWD_ILV");   // A/B knob
-      if (ie != nullptr && ie[0] == '0')
+      if (exd)
+        hipLaunchKernelGGL((infonce_bwd_b3_kernel<D, true, true>), dim3((unsigned)(p.m_blocks * p.nsplit)), dim3(256), 0,
+                           s, x, x_scale, mx, y, y_scale, ny, inv_tau * kLog2e, inv_tau, lse_x, w_x, lse_y, w_y, p.nsplit,
+                           p.tiles_per_split, gpart);
+      else if (ie != nullptr && ie[0] == '0')
         hipLaunchKernelGGL((infonce_bwd_b3_kernel<D, false>), dim3((unsigned)(p.m_blocks * p.nsplit)), dim3(256), 0, s,
                            x, x_scale, mx, y, y_scale, ny, inv_tau * kLog2e, inv_tau, lse_x, w_x, lse_y, w_y, p.nsplit,
                            p.tiles_per_split, gpart);
@@ -1250,9 +1291,14 @@ int32_t launch_bwd(const float* x, const float* x_scale, int64_t mx, const float
   const FwdPlan p = plan_bwd<D>(mx, ny);
   float* gpart = p.nsplit == 1 ? g : reinterpret_cast<float*>(workspace);
   for (int pass = 0; pass < BwdShape<D>::PASSES; ++pass) {
-    hipLaunchKernelGGL((infonce_bwd_kernel<D>), dim3((unsigned)(p.m_blocks * p.nsplit)), dim3(256), 0, s, x, x_scale,
-                       mx, y, y_scale, ny, inv_tau * kLog2e, inv_tau, lse_x, w_x, lse_y, w_y, pass * BwdShape<D>::CT,
-                       p.nsplit, p.tiles_per_split, gpart);
+    if (exd)
+      hipLaunchKernelGGL((infonce_bwd_kernel<D, true>), dim3((unsigned)(p.m_blocks * p.nsplit)), dim3(256), 0, s, x,
+                         x_scale, mx, y, y_scale, ny, inv_tau * kLog2e, inv_tau, lse_x, w_x, lse_y, w_y,
+                         pass * BwdShape<D>::CT, p.nsplit, p.tiles_per_split, gpart);
+    else
+      hipLaunchKernelGGL((infonce_bwd_kernel<D>), dim3((unsigned)(p.m_blocks * p.nsplit)), dim3(256), 0, s, x, x_scale,
+                         mx, y, y_scale, ny, inv_tau * kLog2e, inv_tau, lse_x, w_x, lse_y, w_y, pass * BwdShape<D>::CT,
+                         p.nsplit, p.tiles_per_split, gpart);
     int32_t st = GCR_LAUNCH_STATUS();
     if (st != GCR_OK) return st;
   }
@@ -1270,7 +1316,7 @@ int anchors_per_block_for(int d) { return d <= 128 ? 256 : 128; }
 
 template <int D>
 int32_t launch_fwd(const float* a, const float* a_scale, int64_t m, const float* b, const float* b_scale, int64_t n,
-                   float inv_tau, float* lse, float* col_sum, float col_bound, void* workspace, hipStream_t s) {
+                   float inv_tau, float* lse, float* col_sum, float col_bound, void* workspace, bool exd, hipStream_t s) {
   float2* part = reinterpret_cast<float2*>(workspace);
   if constexpr (D <= 128) {
     if (use_b3(D)) {
@@ -1286,7 +1332,10 @@ int32_t launch_fwd(const float* a, const float* a_scale, int64_t m, const float*
 #define GCR_B3(CS, PP)                                                                                              \
   hipLaunchKernelGGL((infonce_fwd_b3_kernel<D, CS, PP>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale, n,       \
                      inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part, col_sum, cb2)
-      if (col_sum != nullptr) {
+      if (exd) {
+        hipLaunchKernelGGL((infonce_fwd_b3_kernel<D, false, true, true>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale,
+                           n, inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part, col_sum, cb2);
+      } else if (col_sum != nullptr) {
         if (pipe) GCR_B3(true, true); else GCR_B3(true, false);
       } else {
         if (pipe) GCR_B3(false, true); else GCR_B3(false, false);
@@ -1302,7 +1351,10 @@ int32_t launch_fwd(const float* a, const float* a_scale, int64_t m, const float*
   const dim3 grid((unsigned)(p.m_blocks * p.nsplit));
   const char* fm = getenv("GCR_INFONCE_FORCE_MASK");   // A/B knob
   const int force_mask = fm != nullptr && fm[0] == '1';
-  if (col_sum != nullptr) {
+  if (exd) {
+    hipLaunchKernelGGL((infonce_fwd_kernel<D, false, true>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale, n,
+                       inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part, col_sum, 0.f, force_mask);
+  } else if (col_sum != nullptr) {
     hipError_t err = hipMemsetAsync(col_sum, 0, sizeof(float) * (size_t)n, s);
     if (err != hipSuccess) return gcr_hip_status(err);
     hipLaunchKernelGGL((infonce_fwd_kernel<D, true>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale, n,
@@ -1655,21 +1707,31 @@ extern "C" int64_t gcr_infonce_fwd_workspace_bytes(int64_t m, int64_t n, int32_t
   return nsplit * m * (int64_t)sizeof(float2);
 }
 
-extern "C" int32_t gcr_infonce_fwd_f32(const float* a, const float* a_scale, int64_t m, const float* b,
-                                       const float* b_scale, int64_t n, int32_t d, float inv_tau, float* lse,
-                                       float* col_sum, float col_bound, void* workspace, void* stream) {
+extern "C" int32_t gcr_infonce_fwd_ex_f32(const float* a, const float* a_scale, int64_t m, const float* b,
+                                          const float* b_scale, int64_t n, int32_t d, float inv_tau, float* lse,
+                                          float* col_sum, float col_bound, void* workspace, uint32_t flags,
+                                          void* stream) {
   GCR_CHECK_ARG(m >= 0 && n >= 1);
+  GCR_CHECK_ARG((flags & ~(uint32_t)GCR_INFONCE_EXCLUDE_DIAGONAL) == 0);
+  const bool exd = (flags & GCR_INFONCE_EXCLUDE_DIAGONAL) != 0;
+  GCR_CHECK_ARG(!(exd && col_sum != nullptr));
   if (!dim_supported(d)) return GCR_EUNSUPPORTED;
   if (m == 0) return GCR_OK;
   GCR_CHECK_ARG(a != nullptr && b != nullptr && lse != nullptr && workspace != nullptr);
   GCR_CHECK_ARG(m < (1ll << 40) && n < (1ll << 40));
   hipStream_t s = (hipStream_t)stream;
   switch (d) {
-    case 32: return launch_fwd<32>(a, a_scale, m, b, b_scale, n, inv_tau, lse, col_sum, col_bound, workspace, s);
-    case 64: return launch_fwd<64>(a, a_scale, m, b, b_scale, n, inv_tau, lse, col_sum, col_bound, workspace, s);
-    case 128: return launch_fwd<128>(a, a_scale, m, b, b_scale, n, inv_tau, lse, col_sum, col_bound, workspace, s);
-    default: return launch_fwd<256>(a, a_scale, m, b, b_scale, n, inv_tau, lse, col_sum, col_bound, workspace, s);
+    case 32: return launch_fwd<32>(a, a_scale, m, b, b_scale, n, inv_tau, lse, col_sum, col_bound, workspace, exd, s);
+    case 64: return launch_fwd<64>(a, a_scale, m, b, b_scale, n, inv_tau, lse, col_sum, col_bound, workspace, exd, s);
+    case 128: return launch_fwd<128>(a, a_scale, m, b, b_scale, n, inv_tau, lse, col_sum, col_bound, workspace, exd, s);
+    default: return launch_fwd<256>(a, a_scale, m, b, b_scale, n, inv_tau, lse, col_sum, col_bound, workspace, exd, s);
   }
+}
+
+extern "C" int32_t gcr_infonce_fwd_f32(const float* a, const float* a_scale, int64_t m, const float* b,
+                                       const float* b_scale, int64_t n, int32_t d, float inv_tau, float* lse,
+                                       float* col_sum, float col_bound, void* workspace, void* stream) {
+  return gcr_infonce_fwd_ex_f32(a, a_scale, m, b, b_scale, n, d, inv_tau, lse, col_sum, col_bound, workspace, 0u, stream);
 }
 
 extern "C" int32_t gcr_row_inv_norm_f32(const float* x, int64_t n, int32_t d, float eps, float* out, void* stream) {
@@ -1711,11 +1773,13 @@ extern "C" int64_t gcr_infonce_bwd_workspace_bytes(int64_t mx, int64_t ny, int32
   return nsplit > 1 ? nsplit * mx * d * (int64_t)sizeof(float) : 0;
 }
 
-extern "C" int32_t gcr_infonce_bwd_f32(const float* x, const float* x_scale, int64_t mx, const float* y,
-                                       const float* y_scale, int64_t ny, int32_t d, float inv_tau, const float* lse_x,
-                                       const float* w_x, const float* lse_y, const float* w_y, float* g,
-                                       void* workspace, void* stream) {
+extern "C" int32_t gcr_infonce_bwd_ex_f32(const float* x, const float* x_scale, int64_t mx, const float* y,
+                                          const float* y_scale, int64_t ny, int32_t d, float inv_tau,
+                                          const float* lse_x, const float* w_x, const float* lse_y, const float* w_y,
+                                          float* g, void* workspace, uint32_t flags, void* stream) {
   GCR_CHECK_ARG(mx >= 0 && ny >= 1);
+  GCR_CHECK_ARG((flags & ~(uint32_t)GCR_INFONCE_EXCLUDE_DIAGONAL) == 0);
+  const bool exd = (flags & GCR_INFONCE_EXCLUDE_DIAGONAL) != 0;
   if (!dim_supported(d)) return GCR_EUNSUPPORTED;
   if (mx == 0) return GCR_OK;
   GCR_CHECK_ARG(x != nullptr && y != nullptr && g != nullptr);
@@ -1723,11 +1787,19 @@ extern "C" int32_t gcr_infonce_bwd_f32(const float* x, const float* x_scale, int
   GCR_CHECK_ARG(workspace != nullptr || gcr_infonce_bwd_workspace_bytes(mx, ny, d) == 0);
   hipStream_t s = (hipStream_t)stream;
   switch (d) {
-    case 32: return launch_bwd<32>(x, x_scale, mx, y, y_scale, ny, inv_tau, lse_x, w_x, lse_y, w_y, g, workspace, s);
-    case 64: return launch_bwd<64>(x, x_scale, mx, y, y_scale, ny, inv_tau, lse_x, w_x, lse_y, w_y, g, workspace, s);
-    case 128: return launch_bwd<128>(x, x_scale, mx, y, y_scale, ny, inv_tau, lse_x, w_x, lse_y, w_y, g, workspace, s);
-    default: return launch_bwd<256>(x, x_scale, mx, y, y_scale, ny, inv_tau, lse_x, w_x, lse_y, w_y, g, workspace, s);
+    case 32: return launch_bwd<32>(x, x_scale, mx, y, y_scale, ny, inv_tau, lse_x, w_x, lse_y, w_y, g, workspace, exd, s);
+    case 64: return launch_bwd<64>(x, x_scale, mx, y, y_scale, ny, inv_tau, lse_x, w_x, lse_y, w_y, g, workspace, exd, s);
+    case 128: return launch_bwd<128>(x, x_scale, mx, y, y_scale, ny, inv_tau, lse_x, w_x, lse_y, w_y, g, workspace, exd, s);
+    default: return launch_bwd<256>(x, x_scale, mx, y, y_scale, ny, inv_tau, lse_x, w_x, lse_y, w_y, g, workspace, exd, s);
   }
+}
+
+extern "C" int32_t gcr_infonce_bwd_f32(const float* x, const float* x_scale, int64_t mx, const float* y,
+                                       const float* y_scale, int64_t ny, int32_t d, float inv_tau, const float* lse_x,
+                                       const float* w_x, const float* lse_y, const float* w_y, float* g,
+                                       void* workspace, void* stream) {
+  return gcr_infonce_bwd_ex_f32(x, x_scale, mx, y, y_scale, ny, d, inv_tau, lse_x, w_x, lse_y, w_y, g, workspace, 0u,
+                                stream);
 }
 
 extern "C" int32_t gcr_infonce_pos_bwd_f32(const float* x, const float* x_scale, const float* y, const float* y_scale,

@@ -341,20 +341,25 @@ def row_inv_norm(x, eps=1e-12):
     return out
 
 
-def infonce_lse_raw(a, a_scale, b, b_scale, inv_tau, col_bound=None):
+INFONCE_EXCLUDE_DIAGONAL = 1
+
+
+def infonce_lse_raw(a, a_scale, b, b_scale, inv_tau, col_bound=None, exclude_diagonal=False):
     """lse[i] = log sum_j exp(inv_tau * a_scale[i] b_scale[j] <a_i, b_j>) (no autograd).
     col_bound (an upper bound of every logit, e.g. inv_tau for unit rows): also return the column
-    logsumexp over the anchors [N] from the same pass (float atomics) as a second value."""
+    logsumexp over the anchors [N] from the same pass (float atomics) as a second value.
+    exclude_diagonal: the sum runs over j != i (grace.py:396-404, intra-view negatives)."""
     L = _lib.lib()
     m, d = a.shape
     n = b.shape[0]
     lse = torch.empty(m, dtype=torch.float32, device=a.device)
     col_sum = torch.empty(n, dtype=torch.float32, device=a.device) if col_bound is not None else None
     ws = torch.empty(max(int(L.gcr_infonce_fwd_workspace_bytes(m, n, d)), 8) // 4, dtype=torch.float32, device=a.device)
-    _lib.check(L.gcr_infonce_fwd_f32(_lib.dptr(a), _lib.dptr(a_scale), m, _lib.dptr(b), _lib.dptr(b_scale), n, d,
-                                     float(inv_tau), _lib.dptr(lse), _lib.dptr(col_sum),
-                                     float(col_bound) if col_bound is not None else 0.0, _lib.dptr(ws),
-                                     _lib.cur_stream(a.device)), "gcr_infonce_fwd_f32")
+    _lib.check(L.gcr_infonce_fwd_ex_f32(_lib.dptr(a), _lib.dptr(a_scale), m, _lib.dptr(b), _lib.dptr(b_scale), n, d,
+                                        float(inv_tau), _lib.dptr(lse), _lib.dptr(col_sum),
+                                        float(col_bound) if col_bound is not None else 0.0, _lib.dptr(ws),
+                                        INFONCE_EXCLUDE_DIAGONAL if exclude_diagonal else 0,
+                                        _lib.cur_stream(a.device)), "gcr_infonce_fwd_ex_f32")
     if col_bound is None:
         return lse
     return lse, torch.log(col_sum) + float(col_bound)
@@ -369,17 +374,18 @@ def pos_logit_raw(a, a_scale, b, b_scale, pos, scale):
     return out
 
 
-def _infonce_bwd_raw(x, x_scale, y, y_scale, inv_tau, lse_x, w_x, lse_y, w_y):
+def _infonce_bwd_raw(x, x_scale, y, y_scale, inv_tau, lse_x, w_x, lse_y, w_y, exclude_diagonal=False):
     """g = inv_tau * sum_j P_ij yhat_j (see gcr_infonce_bwd_f32): gradient w.r.t. the scaled rows of x."""
     L = _lib.lib()
     mx, d = x.shape
     g = torch.empty_like(x)
     nbytes = int(L.gcr_infonce_bwd_workspace_bytes(mx, y.shape[0], d))
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device) if nbytes else None
-    _lib.check(L.gcr_infonce_bwd_f32(_lib.dptr(x), _lib.dptr(x_scale), mx, _lib.dptr(y), _lib.dptr(y_scale), y.shape[0],
-                                     d, float(inv_tau), _lib.dptr(lse_x), _lib.dptr(w_x), _lib.dptr(lse_y),
-                                     _lib.dptr(w_y), _lib.dptr(g), _lib.dptr(ws), _lib.cur_stream(x.device)),
-               "gcr_infonce_bwd_f32")
+    _lib.check(L.gcr_infonce_bwd_ex_f32(_lib.dptr(x), _lib.dptr(x_scale), mx, _lib.dptr(y), _lib.dptr(y_scale), y.shape[0],
+                                        d, float(inv_tau), _lib.dptr(lse_x), _lib.dptr(w_x), _lib.dptr(lse_y),
+                                        _lib.dptr(w_y), _lib.dptr(g), _lib.dptr(ws),
+                                        INFONCE_EXCLUDE_DIAGONAL if exclude_diagonal else 0, _lib.cur_stream(x.device)),
+               "gcr_infonce_bwd_ex_f32")
     return g
 
 
@@ -388,7 +394,7 @@ class _InfoNCEStats(torch.autograd.Function):
     flash-style HIP backward.  Every loss of the InfoNCE family is a few [M]-vector ops on top."""
 
     @staticmethod
-    def forward(ctx, a, b, pos, inv_tau, normalize, want_col):
+    def forward(ctx, a, b, pos, inv_tau, normalize, want_col, exd=False):
         a_p, b_p = _pad_dim(a).contiguous(), _pad_dim(b).contiguous()
         sa = row_inv_norm(a_p) if normalize else None
         sb = row_inv_norm(b_p) if normalize else None
@@ -398,16 +404,16 @@ class _InfoNCEStats(torch.autograd.Function):
         # is also the path for un-normalised inputs — and for the split-operand engine, whose MFMA
         # work is cheap enough that the second pass costs no more than the column-sum epilogue
         # (11.6 vs 11.6 ms at 100K x 100K, 0.49 vs 0.65 ms at 20K x 20K; scripts/perf_infonce_sym.py)
-        one_pass = want_col and normalize and inv_tau <= 40.0 and not COL_DETERMINISTIC and \
+        one_pass = want_col and normalize and inv_tau <= 40.0 and not COL_DETERMINISTIC and not exd and \
             _lib.lib().gcr_infonce_engine(a_p.shape[1]) == 0
         if one_pass:
             lse, col = infonce_lse_raw(a_p, sa, b_p, sb, inv_tau, col_bound=inv_tau * 1.0001)
         else:
-            lse = infonce_lse_raw(a_p, sa, b_p, sb, inv_tau)
-            col = infonce_lse_raw(b_p, sb, a_p, sa, inv_tau) if want_col else None
+            lse = infonce_lse_raw(a_p, sa, b_p, sb, inv_tau, exclude_diagonal=exd)
+            col = infonce_lse_raw(b_p, sb, a_p, sa, inv_tau, exclude_diagonal=exd) if want_col else None
         pl = pos_logit_raw(a_p, sa, b_p, sb, pos, inv_tau)
         ctx.save_for_backward(a_p, b_p, pos, sa, sb, lse, col)
-        ctx.inv_tau, ctx.d = inv_tau, a.shape[1]
+        ctx.inv_tau, ctx.d, ctx.exd = inv_tau, a.shape[1], exd
         if want_col:
             return lse, pl, col
         return lse, pl
@@ -425,9 +431,9 @@ class _InfoNCEStats(torch.autograd.Function):
         ga = gb = None
         stream = _lib.cur_stream(a.device)
         if need_a:
-            ga = _infonce_bwd_raw(a, sa, b, sb, inv_tau, lse_r, g_lse, col_r, g_col)
+            ga = _infonce_bwd_raw(a, sa, b, sb, inv_tau, lse_r, g_lse, col_r, g_col, ctx.exd)
         if need_b:
-            gb = _infonce_bwd_raw(b, sb, a, sa, inv_tau, col_r, g_col, lse_r, g_lse)
+            gb = _infonce_bwd_raw(b, sb, a, sa, inv_tau, col_r, g_col, lse_r, g_lse, ctx.exd)
         if g_pos is not None and (need_a or need_b):
             _lib.check(L.gcr_infonce_pos_bwd_f32(_lib.dptr(a), _lib.dptr(sa), _lib.dptr(b), _lib.dptr(sb), _lib.dptr(pos),
                                                  _lib.dptr(g_pos.contiguous().float()), a.shape[0], b.shape[0], a.shape[1],
@@ -443,15 +449,15 @@ class _InfoNCEStats(torch.autograd.Function):
             ga = ga[:, :d].contiguous()
         if gb is not None and gb.shape[1] != d:
             gb = gb[:, :d].contiguous()
-        return ga, gb, None, None, None, None
+        return ga, gb, None, None, None, None, None
 
 
-def infonce_stats(a, b, pos=None, temperature=0.2, normalize=True, want_col=False):
+def infonce_stats(a, b, pos=None, temperature=0.2, normalize=True, want_col=False, exclude_diagonal=False):
     """Row logsumexp and positive logit of S = (ahat @ bhat.T) / temperature without materialising S.
     a: [M, d] anchors, b: [N, d] candidates, pos: int64 [M] index of each anchor's positive row in b
     (None: the diagonal, requires N >= M).  Returns (lse [M], pos_logit [M]) and, with want_col,
-    also the column logsumexp [N] (gcl.py:34 `cross_entropy(sim.T, labels)`).  Differentiable
-    w.r.t. a and b."""
+    also the column logsumexp [N] (gcl.py:34 `cross_entropy(sim.T, labels)`).  exclude_diagonal: the
+    sums leave out the pair (i, j = i) (grace.py:396-404).  Differentiable w.r.t. a and b."""
     _lib.require_cuda(a, b)
     if a.dim() != 2 or b.dim() != 2 or a.shape[1] != b.shape[1] or a.dtype != torch.float32 or b.dtype != torch.float32:
         raise ValueError("a [M, d] and b [N, d] must be float32 with the same d")
@@ -464,7 +470,7 @@ def infonce_stats(a, b, pos=None, temperature=0.2, normalize=True, want_col=Fals
         pos = _as_index(pos, a.device)
         if pos.shape != (a.shape[0],):
             raise ValueError("pos must be [M]")
-    return _InfoNCEStats.apply(a, b, pos, 1.0 / float(temperature), bool(normalize), bool(want_col))
+    return _InfoNCEStats.apply(a, b, pos, 1.0 / float(temperature), bool(normalize), bool(want_col), bool(exclude_diagonal))
 
 
 def edge_mask_exact_bits(nnz, n_keep, seed, device):

@@ -104,3 +104,29 @@ def neighbor_discrimination(positive, emb, aug_emb, temperature=0.1):
     e, a = F.normalize(emb, dim=1), F.normalize(aug_emb, dim=1)
     pos = (e.unsqueeze(1) * a[positive]).sum(2) / temperature
     return -(torch.logsumexp(pos, dim=1) - lse).sum()
+
+
+def grace_infonce_loss(h1, h2, tau, intraview_negs=True, exclude_self=False):
+    """univariate/grace.py: `DualBranchContrast(loss=InfoNCE(tau), mode='L2L', intraview_negs=...)(h1, h2)`
+    (:462-502 with SameScaleSampler :396-419 and InfoNCE.compute :218-224): for anchor h1_i the positive is
+    h2_i, the negatives every other h2_j and — with intra-view negatives — the rows of h1 itself;
+    symmetric in the two views, averaged.  The [N, 2N] masked similarity matrix of the reference becomes
+    two fused row logsumexps per direction (over the other view, over the own view) joined by logaddexp.
+
+    exclude_self=False is what the reference computes when the model calls it: `add_extra_mask` (:448-455)
+    replaces the sampler's negative mask by `1 - pos_mask` whenever extra_neg_mask is None, so the anchor's
+    own row h1_i (similarity 1/tau) stays in the denominator.  exclude_self=True is the sampler's own mask
+    (`1 - eye` on the intra-view block, :399-404; what the reference gives with extra_neg_mask = ones): the
+    diagonal is left out inside the kernel (GCR_INFONCE_EXCLUDE_DIAGONAL).  Both are pinned by
+    tests/golden/grace.npz."""
+    if h1.shape != h2.shape:
+        raise ValueError("grace_infonce_loss needs two views of the same nodes")
+
+    def one_direction(a, b):
+        lse_inter, pos = Fn.infonce_stats(a, b, None, tau, normalize=True)
+        if not intraview_negs:
+            return (lse_inter - pos).mean()
+        lse_intra, _ = Fn.infonce_stats(a, a, None, tau, normalize=True, exclude_diagonal=exclude_self)
+        return (torch.logaddexp(lse_inter, lse_intra) - pos).mean()
+
+    return (one_direction(h1, h2) + one_direction(h2, h1)) * 0.5

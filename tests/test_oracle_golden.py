@@ -213,3 +213,15 @@ def test_synthetic_graph_contract():
     assert u.size == 80000 and np.unique(u * 1682 + i).size == 80000
     assert np.unique(u).size == 943 and i.max() < 1682
     assert np.bincount(i).max() <= 0.006 * 80000 + 50
+
+
+def test_grace_dual_branch_infonce(golden):
+    """univariate/grace.py DualBranchContrast(InfoNCE, 'L2L') run as-is (oracle/gen_golden.py --grace):
+    without intra-view negatives, with them as the model calls it (the anchor's own row stays a negative,
+    grace.py:448-455) and with the sampler's mask kept (diagonal excluded, grace.py:399-404)."""
+    g = golden("grace.npz")
+    for m in (7, 257):
+        for tau in (0.2, 0.5):
+            for intra, keep in ((0, 0), (1, 0), (1, 1)):
+                got = O.grace_infonce(g[f"h1_{m}"], g[f"h2_{m}"], tau, bool(intra), bool(keep))
+                assert got == pytest.approx(float(g[f"loss_{m}_{tau}_{intra}_{keep}"]), rel=RT, abs=2e-6)

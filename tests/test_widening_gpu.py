@@ -60,3 +60,50 @@ def test_neighbor_discrimination_matches_dense(b, k, d):
     for got, want in ((et.grad, e64.grad), (at.grad, a64.grad)):
         want = want.numpy()
         np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=1e-5 * np.abs(want).max())
+
+
+@pytest.mark.parametrize("engine", ["b3", "f32"])
+@pytest.mark.parametrize("m", [7, 257])
+def test_grace_dual_branch_infonce_matches_reference(golden, monkeypatch, engine, m):
+    """losses.grace_infonce_loss against the reference's own DualBranchContrast outputs (values and both
+    gradients), all three mask variants, both MFMA engines."""
+    from recommendation_amd.losses import grace_infonce_loss
+    monkeypatch.setenv("GCR_INFONCE_ENGINE", engine)
+    g = golden("grace.npz")
+    for tau in (0.2, 0.5):
+        for intra, keep in ((0, 0), (1, 0), (1, 1)):
+            h1 = torch.from_numpy(g[f"h1_{m}"]).cuda().requires_grad_(True)
+            h2 = torch.from_numpy(g[f"h2_{m}"]).cuda().requires_grad_(True)
+            loss = grace_infonce_loss(h1, h2, tau, intraview_negs=bool(intra), exclude_self=bool(keep))
+            key = f"{m}_{tau}_{intra}_{keep}"
+            assert float(loss) == pytest.approx(float(g[f"loss_{key}"]), rel=1e-5, abs=2e-6)
+            loss.backward()
+            for got, want in ((h1.grad, g[f"g1_{key}"]), (h2.grad, g[f"g2_{key}"])):
+                np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=1e-5 * np.abs(want).max() + 1e-9)
+
+
+@pytest.mark.parametrize("engine", ["b3", "f32"])
+@pytest.mark.parametrize("m,d", [(1, 64), (31, 64), (33, 64), (64, 64), (65, 32), (129, 64), (300, 128), (1000, 64), (2100, 64)])
+def test_exclude_diagonal_lse_and_grads(monkeypatch, engine, m, d):
+    """GCR_INFONCE_EXCLUDE_DIAGONAL on square self-similarity problems across tile boundaries: row LSE
+    over j != i and its gradient against dense float64 torch."""
+    from recommendation_amd import functional as Fn
+    monkeypatch.setenv("GCR_INFONCE_ENGINE", engine)
+    rng = np.random.default_rng(m + d)
+    x = (rng.standard_normal((m, d)) * 0.5).astype(np.float32)
+    w = rng.standard_normal(m)
+    xt = torch.from_numpy(x).cuda().requires_grad_(True)
+    lse, _ = Fn.infonce_stats(xt, xt, None, 0.25, normalize=True, exclude_diagonal=True)
+    x64 = torch.from_numpy(x).double().requires_grad_(True)
+    xn = torch.nn.functional.normalize(x64, dim=1)
+    s = (xn @ xn.T) * 4.0
+    s = s.masked_fill(torch.eye(m, dtype=torch.bool), float("-inf"))
+    ref = torch.logsumexp(s, 1) if m > 1 else torch.full((1,), float("-inf"), dtype=torch.float64)
+    if m == 1:
+        assert float(lse[0]) == float("-inf")
+        return
+    np.testing.assert_allclose(lse.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-5)
+    (lse * torch.from_numpy(w.astype(np.float32)).cuda()).sum().backward()
+    (ref * torch.from_numpy(w)).sum().backward()
+    want = x64.grad.numpy()
+    np.testing.assert_allclose(xt.grad.cpu().numpy(), want, rtol=2e-4, atol=1e-5 * np.abs(want).max())

@@ -7,6 +7,7 @@ directory.  Usage: python profiles/summarize.py gpurun_out/prof5 r01
                                 profiles/pmc_probe.py: 3 calibration launches, then 2 x 3 cfg2 layers)
   pmc_traffic.json              per-launch HBM bytes bench.py reports as roofline.traffic
   <tag>_infonce_kernel_stats.csv, <tag>_infonce_pmc_mfma.csv   profiles/infonce_probe.py
+  <tag>_ncl_step_kernel_stats.csv, <tag>_kmeans_kernel_stats.csv  profiles/ncl_step_probe.py, kmeans_probe.py
 """
 import collections
 import csv
@@ -39,6 +40,8 @@ def stats(pattern, out, top=12):
 
 stats("kt/*/*_kernel_stats.csv", f"{tag}_cfg2_kernel_stats.csv")
 stats("kt_nce/*/*_kernel_stats.csv", f"{tag}_infonce_kernel_stats.csv", top=10)
+stats("kt_ncl/*/*_kernel_stats.csv", f"{tag}_ncl_step_kernel_stats.csv", top=16)      # profiles/ncl_step_probe.py
+stats("kt_km/*/*_kernel_stats.csv", f"{tag}_kmeans_kernel_stats.csv", top=6)           # profiles/kmeans_probe.py
 
 fetch, write = one("pmc_fetch/*/*_counter_collection.csv"), one("pmc_write/*/*_counter_collection.csv")
 if fetch and write:

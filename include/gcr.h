@@ -112,6 +112,26 @@ int32_t gcr_bpr_bwd_f32(const float* user_tab, const float* item_tab, int32_t d,
                         const float* dloss_dx, const float* grad_sums,
                         float* grad_user, float* grad_item, void* stream);
 
+/*
+ * Backward for large batches (lightgcn.py:95-118 trains on all E edges at once): the same gradients from
+ * three SORTED orders of the samples instead of three row atomics per sample.  gcr_sort_index produces an
+ * order: keys_sorted[k] = idx[perm[k]] ascending (stable), ids outside [0, n_keys) get key 0xFFFFFFFF and
+ * sort last; n and n_keys < 2^31.  (keys_u, perm_u) = order of u_idx, (keys_i, perm_i) of i_idx,
+ * (keys_j, perm_j) of the flattened j_idx [batch * n_neg]; orders of index arrays that do not change
+ * between steps can be reused.  One row atomic per run of equal keys and 64-entry chunk.
+ */
+int64_t gcr_sort_index_workspace_bytes(int64_t n);
+int32_t gcr_sort_index(const int64_t* idx, int64_t n, int64_t n_keys, uint32_t* keys_sorted, int32_t* perm,
+                       void* workspace, void* stream);
+int32_t gcr_bpr_bwd_sorted_f32(const float* user_tab, const float* item_tab, int32_t d,
+                               const int64_t* u_idx, const int64_t* i_idx, const int64_t* j_idx,
+                               int64_t batch, int32_t n_neg, int64_t n_users, int64_t n_items,
+                               const float* dloss_dx, const float* grad_sums,
+                               const uint32_t* keys_u, const int32_t* perm_u,
+                               const uint32_t* keys_i, const int32_t* perm_i,
+                               const uint32_t* keys_j, const int32_t* perm_j,
+                               float* grad_user, float* grad_item, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Counter-based RNG (Philox-4x32-10): negative sampler and edge-dropout bitmaps.
  * --------------------------------------------------------------------------------------------- */

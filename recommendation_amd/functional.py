@@ -230,6 +230,33 @@ def _as_index(t, device):
     return t.contiguous()
 
 
+# batches at least this large take the sorted backward (gcr_bpr_bwd_sorted_f32); below it the three
+# row atomics per sample are cheaper than the sorts
+BPR_SORTED_MIN_BATCH = 1 << 18
+_ORDER_CACHE = {}
+
+
+def _sorted_order(idx, n_keys, cache=False):
+    """(keys_sorted uint32 as int32 tensor, perm int32) of a flat int64 index vector (gcr_sort_index).
+    cache=True keeps the order of an index tensor that is reused step after step (lightgcn.py trains
+    on the same edge arrays every step), keyed by storage pointer / length / version."""
+    key = (idx.data_ptr(), idx.numel(), idx._version, int(n_keys))
+    if cache and key in _ORDER_CACHE:
+        return _ORDER_CACHE[key]
+    L = _lib.lib()
+    n = idx.numel()
+    keys = torch.empty(n, dtype=torch.int32, device=idx.device)
+    perm = torch.empty(n, dtype=torch.int32, device=idx.device)
+    ws = torch.empty(int(L.gcr_sort_index_workspace_bytes(n)), dtype=torch.uint8, device=idx.device)
+    _lib.check(L.gcr_sort_index(_lib.dptr(idx), n, int(n_keys), _lib.dptr(keys), _lib.dptr(perm), _lib.dptr(ws),
+                                _lib.cur_stream(idx.device)), "gcr_sort_index")
+    if cache:
+        if len(_ORDER_CACHE) >= 8:
+            _ORDER_CACHE.pop(next(iter(_ORDER_CACHE)))
+        _ORDER_CACHE[key] = (keys, perm, idx)       # holding idx keeps the pointer from being recycled
+    return keys, perm, idx
+
+
 class _BprSums(torch.autograd.Function):
     """sums = [sum_b loss_b, sum|U[u]|^2, sum|I[i]|^2, sum|I[j]|^2] through gcr_bpr_fwd/bwd_f32."""
 
@@ -259,6 +286,17 @@ class _BprSums(torch.autograd.Function):
         gs = g_sums.contiguous().to(torch.float32)
         gu = torch.zeros_like(user_tab)
         gi = torch.zeros_like(item_tab)
+        batch = u_idx.numel()
+        if batch >= BPR_SORTED_MIN_BATCH and batch * ctx.n_neg < 2 ** 31:
+            ku, pu, _ = _sorted_order(u_idx, user_tab.shape[0], cache=True)
+            ki, pi, _ = _sorted_order(i_idx, item_tab.shape[0], cache=True)
+            kj, pj, _ = _sorted_order(j_idx.reshape(-1), item_tab.shape[0])       # fresh negatives every step
+            _lib.check(_lib.lib().gcr_bpr_bwd_sorted_f32(
+                _lib.dptr(user_tab), _lib.dptr(item_tab), user_tab.shape[1], _lib.dptr(u_idx), _lib.dptr(i_idx),
+                _lib.dptr(j_idx), batch, ctx.n_neg, user_tab.shape[0], item_tab.shape[0], _lib.dptr(dldx),
+                _lib.dptr(gs), _lib.dptr(ku), _lib.dptr(pu), _lib.dptr(ki), _lib.dptr(pi), _lib.dptr(kj), _lib.dptr(pj),
+                _lib.dptr(gu), _lib.dptr(gi), _lib.cur_stream(user_tab.device)), "gcr_bpr_bwd_sorted_f32")
+            return gu, gi, None, None, None, None
         _lib.check(_lib.lib().gcr_bpr_bwd_f32(
             _lib.dptr(user_tab), _lib.dptr(item_tab), user_tab.shape[1], _lib.dptr(u_idx), _lib.dptr(i_idx),
             _lib.dptr(j_idx), u_idx.numel(), ctx.n_neg, user_tab.shape[0], item_tab.shape[0], _lib.dptr(dldx),

@@ -168,3 +168,60 @@ def test_edge_mask_bit_exact(Fn, nnz):
         pb = Fn.edge_mask_bits(nnz, 0.3, 1234567, "cuda", edge_id=torch.from_numpy(perm).cuda()).cpu().numpy()
         assert np.array_equal(np.unpackbits(pb.view(np.uint8), bitorder="little")[:nnz].astype(bool), ref[perm])
         assert abs(ref.mean() - 0.7) < 0.01
+
+
+@pytest.mark.parametrize("jkey,name,variant", [("j_idx", "ncl_bpr", 0), ("j_idx", "lgcn_block_n1", 2), ("j_idx3", "lgcn_block_n3", 2)])
+def test_sorted_backward_matches_goldens(Fn, golden, monkeypatch, jkey, name, variant):
+    """The large-batch backward (three sorted orders, one row atomic per run) on the reference-generated
+    gradients: forced on at golden size through the batch threshold."""
+    monkeypatch.setattr(Fn, "BPR_SORTED_MIN_BATCH", 1)
+    b, ut, it = _load(golden)
+    sums = Fn.bpr_sums(ut, it, b["u_idx"], b["i_idx"], b[jkey], variant)
+    loss = sums[0] / len(b["u_idx"]) + (1e-4 * (sums[1] + sums[2]) if variant == 2 else 0.0)
+    assert float(loss) == pytest.approx(float(b[f"{name}_loss"]), rel=1e-5)
+    loss.backward()
+    _close(ut.grad, b[f"{name}_gu"])
+    _close(it.grad, b[f"{name}_gi"])
+
+
+@pytest.mark.parametrize("d,n_neg", [(64, 1), (64, 2), (100, 1), (200, 3)])
+def test_sorted_backward_equals_atomic_backward(Fn, monkeypatch, d, n_neg):
+    """Random large-ish batch with heavy key repetition, bad ids in every index vector and all four
+    upstream gradients: the sorted and the atomic backward must agree to summation-order noise."""
+    rng = np.random.default_rng(d + n_neg)
+    n_u, n_i, bsz = 3000, 700, 50_000
+    ut0 = rng.standard_normal((n_u, d)).astype(np.float32) * 0.3
+    it0 = rng.standard_normal((n_i, d)).astype(np.float32) * 0.3
+    u = rng.integers(0, n_u, bsz)
+    i = (rng.pareto(1.2, bsz) * 5).astype(np.int64) % n_i            # popular items: long runs
+    j = rng.integers(0, n_i, (bsz, n_neg)) if n_neg > 1 else rng.integers(0, n_i, bsz)
+    u[17], i[99] = -1, n_i + 5
+    if n_neg > 1:
+        j[123, 1] = n_i
+    else:
+        j[123] = -7
+    w = torch.tensor([1.0 / bsz, 3e-4, 2e-4, 1e-4, 0.0], device="cuda")
+    grads = {}
+    for mode, thr in (("atomic", 1 << 40), ("sorted", 1)):
+        monkeypatch.setattr(Fn, "BPR_SORTED_MIN_BATCH", thr)
+        ut = torch.from_numpy(ut0).cuda().requires_grad_(True)
+        it = torch.from_numpy(it0).cuda().requires_grad_(True)
+        sums = Fn.bpr_sums(ut, it, u, i, j, Fn.BPR_LOGSIGMOID)
+        assert float(sums[4]) == 3.0
+        (sums * w).sum().backward()
+        grads[mode] = (ut.grad.cpu().numpy(), it.grad.cpu().numpy())
+    for a, s in zip(grads["atomic"], grads["sorted"]):
+        np.testing.assert_allclose(s, a, rtol=2e-4, atol=2e-6 * np.abs(a).max())
+    # and against the float64 oracle on the valid samples
+    ok = np.ones(bsz, bool)
+    ok[[17, 99, 123]] = False
+    jo = j[ok] if n_neg == 1 else j[ok]
+    gu, gi = O.bpr_grads(ut0, it0, u[ok], i[ok], jo, variant=1) if n_neg == 1 else (None, None)
+    if gu is not None:
+        # oracle gradient of sum_b loss_b / |valid|: rescale to the weights used above (loss term only)
+        ut = torch.from_numpy(ut0).cuda().requires_grad_(True)
+        it = torch.from_numpy(it0).cuda().requires_grad_(True)
+        monkeypatch.setattr(Fn, "BPR_SORTED_MIN_BATCH", 1)
+        (Fn.bpr_sums(ut, it, u, i, j, Fn.BPR_LOGSIGMOID)[0] / ok.sum()).backward()
+        _close(ut.grad, gu, rel=5e-5)
+        _close(it.grad, gi, rel=5e-5)

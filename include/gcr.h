@@ -90,7 +90,7 @@ int64_t gcr_bpr_workspace_floats(int64_t batch);
  * x_b = <U[u_b], I[i_b]> - mean_k <U[u_b], I[j_{b,k}]>          (n_neg negatives per sample)
  * replaces  rec_user_emb[user_idx] / rec_item_emb[pos_idx] / [neg_idx] + bpr_loss  ncl.py:314-317,
  *           lightgcn.py:95-108, gcl.py:216-221, sept.py:236-240, mhcn.py:527-530.
- * Outputs: dloss_dx[b] = d loss_b / d x_b (saved for backward); sums[5] =
+ * Outputs: dloss_dx[b] = d loss_b / d x_b (saved for backward; NaN for a skipped sample); sums[5] =
  *   { sum_b loss_b, sum_b |U[u_b]|^2, sum_b |I[i_b]|^2, sum_{b,k} |I[j_bk]|^2, #samples skipped
  *     because an id was out of range } — the caller forms mean / regulariser variants
  *   (lightgcn.py:118, gcl.py:222, ncl.py:122-123, sept.py:241) from these.

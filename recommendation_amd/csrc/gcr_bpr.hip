@@ -73,7 +73,7 @@ __global__ __launch_bounds__(kFwdThreads) void bpr_fwd_kernel(const float* __res
     }
     if (!ok) {  // never dereference a bad id; reported through sums[4]
       t_err += 1.f;
-      if (l16 == 0) dloss_dx[b] = 0.f;
+      if (l16 == 0) dloss_dx[b] = __builtin_nanf("");   // marks the sample for the sorted backward
       continue;
     }
     const float* ur = user_tab + u * d;
@@ -244,23 +244,20 @@ __global__ __launch_bounds__(256) void bpr_bwd_sorted_kernel(
       my_key = keys[c0 + lane];
       const int64_t slot = perm[c0 + lane];
       const int64_t b = SIDE == 2 ? slot / n_neg : slot;
-      const int64_t u = u_idx[b], i = i_idx[b];
-      bool ok = my_key != kBadKey && u >= 0 && u < n_users && i >= 0 && i < n_items;
-      for (int k = 0; k < n_neg; ++k) {
-        const int64_t j = j_idx[b * n_neg + k];
-        ok = ok && j >= 0 && j < n_items;
-      }
-      const float g = g_loss * dloss_dx[b];
+      // the forward left NaN in dloss_dx for a sample with any id out of range: it contributes nothing
+      const float dl = dloss_dx[b];
+      const bool ok = my_key != kBadKey && dl == dl;
+      const float g = g_loss * dl;
       my_coef = SIDE == 2 ? -g / (float)n_neg : g;
-      my_u = u;
-      my_i = i;
+      if (SIDE == 0) my_i = ok ? i_idx[b] : 0;
+      else my_u = ok ? u_idx[b] : 0;
       my_b = b;
-      if (!ok) my_key = kBadKey;      // a sample with any bad id contributes nothing (as in the forward)
+      if (!ok) my_key = kBadKey;
     }
     uint32_t cur = kBadKey;
-    float acc[NV], self[NV];
+    float acc[NV];
 #pragma unroll
-    for (int v = 0; v < NV; ++v) acc[v] = self[v] = 0.f;
+    for (int v = 0; v < NV; ++v) acc[v] = 0.f;
     auto flush = [&]() {
       if (cur != kBadKey) {
 #pragma unroll
@@ -270,47 +267,53 @@ __global__ __launch_bounds__(256) void bpr_bwd_sorted_kernel(
         }
       }
     };
-    for (int e = 0; e < cnt; ++e) {
-      const uint32_t key = (uint32_t)__builtin_amdgcn_readlane((int)my_key, e);
-      if (key == kBadKey) continue;
-      if (key != cur) {
-        flush();
-        cur = key;
+    auto lane64 = [&](int64_t x, int e) {
+      return ((int64_t)__builtin_amdgcn_readlane((int)(x >> 32), e) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)x, e);
+    };
+    // kGather entries at a time: all their row gathers are issued before the first is consumed
+    constexpr int kGather = NV == 1 ? 8 : 4;
+    for (int e0 = 0; e0 < cnt; e0 += kGather) {
+      uint32_t key[kGather];
+      float coef[kGather], row[kGather][NV], own[kGather][NV];
+#pragma unroll
+      for (int q = 0; q < kGather; ++q) {
+        const int e = e0 + q < cnt ? e0 + q : cnt - 1;
+        key[q] = e0 + q < cnt ? (uint32_t)__builtin_amdgcn_readlane((int)my_key, e) : kBadKey;
+        coef[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_coef), e));
+        const bool live = key[q] != kBadKey;
+        const int64_t src = live ? lane64(SIDE == 0 ? my_i : my_u, e) : 0;
+        const float* tab = SIDE == 0 ? item_tab : user_tab;
+        const int64_t self_row = live ? (int64_t)key[q] : 0;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
           const int c = lane + 64 * v;
-          acc[v] = 0.f;
-          self[v] = c < d ? c_self * self_tab[(int64_t)key * d + c] : 0.f;
+          row[q][v] = c < d ? tab[src * d + c] : 0.f;
+          own[q][v] = c < d ? self_tab[self_row * d + c] : 0.f;      // same row for a whole run: L1 / L2 hits
         }
-      }
-      const float coef = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_coef), e));
-      if (SIDE == 0) {
-        const int64_t i = ((int64_t)__builtin_amdgcn_readlane((int)(my_i >> 32), e) << 32) |
-                          (uint32_t)__builtin_amdgcn_readlane((int)my_i, e);
-        const int64_t b = ((int64_t)__builtin_amdgcn_readlane((int)(my_b >> 32), e) << 32) |
-                          (uint32_t)__builtin_amdgcn_readlane((int)my_b, e);
+        if (SIDE == 0) {
+          const int64_t b = lane64(my_b, e);
+          const float inv = 1.0f / (float)n_neg;
+          for (int k = 0; k < n_neg; ++k) {
+            const int64_t j = live ? j_idx[b * n_neg + k] : 0;
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-          const int c = lane + 64 * v;
-          if (c < d) acc[v] += coef * item_tab[i * d + c] + self[v];
-        }
-        const float gn = -coef / (float)n_neg;
-        for (int k = 0; k < n_neg; ++k) {
-          const int64_t j = j_idx[b * n_neg + k];
-#pragma unroll
-          for (int v = 0; v < NV; ++v) {
-            const int c = lane + 64 * v;
-            if (c < d) acc[v] += gn * item_tab[j * d + c];
+            for (int v = 0; v < NV; ++v) {
+              const int c = lane + 64 * v;
+              if (c < d) row[q][v] -= inv * item_tab[j * d + c];
+            }
           }
         }
-      } else {
-        const int64_t u = ((int64_t)__builtin_amdgcn_readlane((int)(my_u >> 32), e) << 32) |
-                          (uint32_t)__builtin_amdgcn_readlane((int)my_u, e);
+      }
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-          const int c = lane + 64 * v;
-          if (c < d) acc[v] += coef * user_tab[u * d + c] + self[v];
+      for (int q = 0; q < kGather; ++q) {
+        if (key[q] == kBadKey) continue;
+        if (key[q] != cur) {
+          flush();
+          cur = key[q];
+#pragma unroll
+          for (int v = 0; v < NV; ++v) acc[v] = 0.f;
         }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[v] += coef[q] * row[q][v] + c_self * own[q][v];
       }
     }
     flush();

@@ -384,6 +384,24 @@ def bench_extra(ra, Fn, graph, x0, k_layers, nnz, dev, n_u, n_i):
         opt.step()
 
     out["ncl_train_step_ms"] = 1e3 * timeit(ncl_step, 5)
+
+    # one whole lightgcn.py training step (lightgcn.py:91-118): full batch = every training edge, fresh
+    # torch.randint negatives, -log(sigmoid) BPR + L2 on the batch rows, backward, Adam
+    eu = torch.repeat_interleave(torch.arange(n_u, device=dev), rowptr_u[1:] - rowptr_u[:-1])
+    ei = items_u.to(torch.int64)
+
+    def lightgcn_step():
+        neg = torch.randint(0, n_i, (eu.numel(),), device=dev, generator=gen)
+        final = Fn.lightgcn_propagate(graph, xp, k_layers, "sum")
+        ue, ie = Fn.split_rows(final, n_u)
+        s = Fn.bpr_sums(ue, ie, eu, ei, neg, Fn.BPR_LOG_SIGMOID)
+        loss = s[0] / eu.numel() + 1e-4 * (s[1] + s[2]) / eu.numel()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+
+    out["lightgcn_full_batch_step_ms"] = 1e3 * timeit(lightgcn_step, 5)
+    out["lightgcn_full_batch_edges"] = int(eu.numel())
     del xp, opt
 
     # the stages either side of the path: NCL's k-means E-step and full-ranking eval

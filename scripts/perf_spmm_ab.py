@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Interleaved A/B of the SpMM partition size (nnz_per_part) in one process on the bench graphs."""
+"""Interleaved A/B of the SpMM partition -> XCD mapping knob (GCR_SPMM_XCD) in one process on the bench graphs."""
 import os
 import statistics
 import sys
@@ -21,12 +21,12 @@ d = 64
 x = torch.randn(n, d, device=dev)
 y = torch.empty_like(x)
 variants = [512]
-unrs = ["4", "8", "16"]
+unrs = ["0", "1"]
 graphs = {L: ra.CsrGraph(rp, c, v, n, n, dev, symmetric=True, nnz_per_part=L, validate=False) for L in variants}
 res = {L: [] for L in unrs}
 for rnd in range(7):
     for L in unrs:
-        os.environ["GCR_SPMM_UNR"] = L
+        os.environ["GCR_SPMM_XCD"] = L
         g = graphs[512]
         if rnd == 0:
             Fn.spmm_into(g, x, y=y)
@@ -43,4 +43,4 @@ bytes_alg = nnz * 264 + n * 260
 print(name, "nnz", nnz)
 for L in unrs:
     med = statistics.median(res[L])
-    print(f"  UNR {L:>3s}: median {med:.4f} ms  min {min(res[L]):.4f} ms  {bytes_alg / med / 1e6:.0f} GB/s alg")
+    print(f"  XCD-chunked {L:>3s}: median {med:.4f} ms  min {min(res[L]):.4f} ms  {bytes_alg / med / 1e6:.0f} GB/s alg")

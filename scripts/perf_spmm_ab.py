@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Interleaved A/B of the SpMM partition -> XCD mapping knob (GCR_SPMM_XCD) in one process on the bench graphs."""
+"""Interleaved A/B of the issue order of the SpMM partitions (GCR_SPMM_INTERLEAVE = stride of a round-robin
+shuffle of the descriptor list; GCR_SPMM_XCD=1 in the environment adds the XCD-chunked mapping) on the bench graphs."""
 import os
 import statistics
 import sys
@@ -20,14 +21,16 @@ n = wl["users"] + wl["items"]
 d = 64
 x = torch.randn(n, d, device=dev)
 y = torch.empty_like(x)
-variants = [512]
-unrs = ["0", "1"]
-graphs = {L: ra.CsrGraph(rp, c, v, n, n, dev, symmetric=True, nnz_per_part=L, validate=False) for L in variants}
+unrs = ["0", "2", "8", "64", "1024"]
+graphs = {}
+for L in unrs:
+    os.environ["GCR_SPMM_INTERLEAVE"] = L
+    graphs[L] = ra.CsrGraph(rp, c, v, n, n, dev, symmetric=True, nnz_per_part=512, validate=False)
+os.environ["GCR_SPMM_INTERLEAVE"] = "0"
 res = {L: [] for L in unrs}
 for rnd in range(7):
     for L in unrs:
-        os.environ["GCR_SPMM_XCD"] = L
-        g = graphs[512]
+        g = graphs[L]
         if rnd == 0:
             Fn.spmm_into(g, x, y=y)
             torch.cuda.synchronize()
@@ -38,9 +41,9 @@ for rnd in range(7):
         e1.record()
         torch.cuda.synchronize()
         res[L].append(e0.elapsed_time(e1) / 5)
-nnz = graphs[512].nnz
+nnz = graphs[unrs[0]].nnz
 bytes_alg = nnz * 264 + n * 260
 print(name, "nnz", nnz)
 for L in unrs:
     med = statistics.median(res[L])
-    print(f"  XCD-chunked {L:>3s}: median {med:.4f} ms  min {min(res[L]):.4f} ms  {bytes_alg / med / 1e6:.0f} GB/s alg")
+    print(f"  interleave stride {L:>5s}: median {med:.4f} ms  min {min(res[L]):.4f} ms  {bytes_alg / med / 1e6:.0f} GB/s alg")

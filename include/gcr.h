@@ -115,7 +115,7 @@ int32_t gcr_bpr_bwd_f32(const float* user_tab, const float* item_tab, int32_t d,
 /*
  * Backward for large batches (lightgcn.py:95-118 trains on all E edges at once): the same gradients from
  * three SORTED orders of the samples instead of three row atomics per sample.  gcr_sort_index produces an
- * order: keys_sorted[k] = idx[perm[k]] ascending (stable), ids outside [0, n_keys) get key 0xFFFFFFFF and
+ * order: keys_sorted[k] = idx[perm[k]] ascending (stable), ids outside [0, n_keys) get the key n_keys and
  * sort last; n and n_keys < 2^31.  (keys_u, perm_u) = order of u_idx, (keys_i, perm_i) of i_idx,
  * (keys_j, perm_j) of the flattened j_idx [batch * n_neg]; orders of index arrays that do not change
  * between steps can be reused.  One row atomic per run of equal keys and 64-entry chunk.
@@ -265,6 +265,12 @@ int32_t gcr_kmeans_assign_f32(const float* x, int64_t n, const float* centroids,
  * sums [k, d] / counts [k] are fp32 scratch. */
 int32_t gcr_kmeans_update_f32(const float* x, int64_t n, int32_t d, const int64_t* assign, int64_t k,
                               float* centroids, float* half_sqnorm, float* sums, float* counts, void* stream);
+/* The same update from the points ordered by cluster — (keys_sorted, perm) = gcr_sort_index(assign, n, k): one
+ * row atomic per run of equal cluster ids and 64-entry chunk instead of one per point (large n). */
+int32_t gcr_kmeans_update_sorted_f32(const float* x, int64_t n, int32_t d, const uint32_t* keys_sorted,
+                                     const int32_t* perm, int64_t k, float* centroids, float* half_sqnorm,
+                                     float* sums, float* counts, void* stream);
+
 
 /* ---------------------------------------------------------------------------------------------
  * Full-ranking evaluation: user x ALL-items scores, training positives masked, exact top-N.

@@ -49,6 +49,7 @@ SIGNATURES = {
     "gcr_normalize_bwd_f32": (c_int32, [_P, _P, _P, c_int64, c_int32, _P, _P]),
     "gcr_kmeans_assign_f32": (c_int32, [_P, c_int64, _P, _P, c_int64, c_int32, _P, _P, _P]),
     "gcr_kmeans_update_f32": (c_int32, [_P, c_int64, c_int32, _P, c_int64, _P, _P, _P, _P, _P]),
+    "gcr_kmeans_update_sorted_f32": (c_int32, [_P, c_int64, c_int32, _P, _P, c_int64, _P, _P, _P, _P, _P]),
     "gcr_score_rows_f32": (c_int32, [_P, _P, c_int64, c_int64, _P, c_int64, c_int32, _P, _P]),
     "gcr_topk_masked_f32": (c_int32, [_P, c_int64, c_int64, _P, c_int64, _P, _P, c_int32, _P, _P, _P]),
     "gcr_coo_to_csr_workspace_bytes": (c_int64, [c_int64]),

@@ -205,7 +205,7 @@ __global__ void sort_keys_kernel(const int64_t* __restrict__ idx, int64_t n, int
                                  int32_t* __restrict__ val) {
   for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
     const int64_t v = idx[k];
-    key[k] = (v >= 0 && v < n_keys) ? (uint32_t)v : kBadKey;
+    key[k] = (v >= 0 && v < n_keys) ? (uint32_t)v : (uint32_t)n_keys;     // invalid ids: one key past the range
     val[k] = (int32_t)k;
   }
 }
@@ -242,6 +242,7 @@ __global__ __launch_bounds__(256) void bpr_bwd_sorted_kernel(
     int64_t my_u = 0, my_i = 0, my_b = 0;
     if (lane < cnt) {
       my_key = keys[c0 + lane];
+      if (my_key >= (uint32_t)(SIDE == 0 ? n_users : n_items)) my_key = kBadKey;   // gcr_sort_index's out-of-range key
       const int64_t slot = perm[c0 + lane];
       const int64_t b = SIDE == 2 ? slot / n_neg : slot;
       // the forward left NaN in dloss_dx for a sample with any id out of range: it contributes nothing
@@ -391,8 +392,10 @@ extern "C" int32_t gcr_sort_index(const int64_t* idx, int64_t n, int64_t n_keys,
   const int64_t blocks = (n + 255) / 256;
   hipLaunchKernelGGL(sort_keys_kernel, dim3((unsigned)(blocks > 65536 ? 65536 : blocks)), dim3(256), 0, s, idx, n, n_keys,
                      key_in, val_in);
-  // invalid ids carry the all-ones key: sort all 32 bits so that they end up last
-  hipError_t err = rocprim::radix_sort_pairs(tmp, tmp_bytes, key_in, keys_sorted, val_in, perm, (size_t)n, 0, 32, s);
+  // only the bits that n_keys (the key of the invalid ids, which therefore sort last) needs
+  int bits = 1;
+  while (bits < 32 && ((uint64_t)n_keys >> bits) != 0) ++bits;
+  hipError_t err = rocprim::radix_sort_pairs(tmp, tmp_bytes, key_in, keys_sorted, val_in, perm, (size_t)n, 0, bits, s);
   if (err != hipSuccess) return gcr_hip_status(err);
   return GCR_LAUNCH_STATUS();
 }

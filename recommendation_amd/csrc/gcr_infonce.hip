@@ -1622,6 +1622,72 @@ __global__ __launch_bounds__(256) void kmeans_accumulate_kernel(const float* __r
   }
 }
 
+// The same sums from the points ORDERED by cluster (gcr_sort_index of `assign`): a wave walks 64 consecutive
+// entries, adds every run of equal cluster ids in registers and issues one row atomic per run and chunk
+// (1M x 64 points: 0.42 ms with one atomic row per point).
+__global__ __launch_bounds__(256) void kmeans_accumulate_sorted_kernel(const float* __restrict__ x, int64_t n, int d,
+                                                                       const uint32_t* __restrict__ keys,
+                                                                       const int32_t* __restrict__ perm, int64_t k,
+                                                                       float* __restrict__ sums,
+                                                                       float* __restrict__ counts) {
+  const int lane = threadIdx.x & 63;
+  const int64_t n_chunks = (n + 63) / 64;
+  for (int64_t chunk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); chunk < n_chunks; chunk += (int64_t)gridDim.x * 4) {
+    const int64_t c0 = chunk * 64;
+    const int cnt = (int)(n - c0 < 64 ? n - c0 : 64);
+    uint32_t my_key = 0xFFFFFFFFu;
+    int my_row = 0;
+    if (lane < cnt) {
+      my_key = keys[c0 + lane];
+      my_row = perm[c0 + lane];
+      if (my_key >= (uint32_t)k) my_key = 0xFFFFFFFFu;
+    }
+    uint32_t cur = 0xFFFFFFFFu;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float run = 0.f;
+    auto flush = [&]() {
+      if (cur != 0xFFFFFFFFu) {
+        for (int v = 0; v < 4; ++v) {
+          const int c = lane + 64 * v;
+          if (c < d) atomicAdd(sums + (int64_t)cur * d + c, acc[v]);
+        }
+        if (lane == 0) atomicAdd(counts + cur, run);
+      }
+    };
+    constexpr int kGather = 8;
+    for (int e0 = 0; e0 < cnt; e0 += kGather) {
+      uint32_t key[kGather];
+      float row[kGather][4];
+#pragma unroll
+      for (int q = 0; q < kGather; ++q) {
+        const int e = e0 + q < cnt ? e0 + q : cnt - 1;
+        key[q] = e0 + q < cnt ? (uint32_t)__builtin_amdgcn_readlane((int)my_key, e) : 0xFFFFFFFFu;
+        const int64_t r = key[q] != 0xFFFFFFFFu ? (int64_t)__builtin_amdgcn_readlane(my_row, e) : 0;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int c = lane + 64 * v;
+          row[q][v] = c < d ? x[r * d + c] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < kGather; ++q) {
+        if (key[q] == 0xFFFFFFFFu) continue;
+        if (key[q] != cur) {
+          flush();
+          cur = key[q];
+          run = 0.f;
+#pragma unroll
+          for (int v = 0; v < 4; ++v) acc[v] = 0.f;
+        }
+        run += 1.f;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[v] += row[q][v];
+      }
+    }
+    flush();
+  }
+}
+
 // centroid = sum / count (empty clusters keep their previous centroid); half_sq = 0.5 ||c||^2
 __global__ __launch_bounds__(256) void kmeans_finalize_kernel(const float* __restrict__ sums,
                                                               const float* __restrict__ counts, int64_t k, int d,
@@ -1690,6 +1756,24 @@ extern "C" int32_t gcr_kmeans_update_f32(const float* x, int64_t n, int32_t d, c
   const int64_t wantk = (k + 15) / 16;
   hipLaunchKernelGGL(kmeans_finalize_kernel, dim3((unsigned)(wantk > 4096 ? 4096 : wantk)), dim3(256), 0, s, sums,
                      n > 0 ? counts : nullptr, k, d, centroids, half_sqnorm);
+  return GCR_LAUNCH_STATUS();
+}
+
+extern "C" int32_t gcr_kmeans_update_sorted_f32(const float* x, int64_t n, int32_t d, const uint32_t* keys_sorted,
+                                                const int32_t* perm, int64_t k, float* centroids, float* half_sqnorm,
+                                                float* sums, float* counts, void* stream) {
+  GCR_CHECK_ARG(n >= 1 && n < (1ll << 31) && k >= 1 && d >= 1 && d <= 256);
+  GCR_CHECK_ARG(x && keys_sorted && perm && centroids && half_sqnorm && sums && counts);
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t err = hipMemsetAsync(sums, 0, sizeof(float) * (size_t)(k * d), s);
+  if (err == hipSuccess) err = hipMemsetAsync(counts, 0, sizeof(float) * (size_t)k, s);
+  if (err != hipSuccess) return gcr_hip_status(err);
+  const int64_t want = ((n + 63) / 64 + 3) / 4;
+  hipLaunchKernelGGL(kmeans_accumulate_sorted_kernel, dim3((unsigned)(want > 65536 ? 65536 : want)), dim3(256), 0, s, x, n,
+                     d, keys_sorted, perm, k, sums, counts);
+  const int64_t wantk = (k + 15) / 16;
+  hipLaunchKernelGGL(kmeans_finalize_kernel, dim3((unsigned)(wantk > 4096 ? 4096 : wantk)), dim3(256), 0, s, sums, counts,
+                     k, d, centroids, half_sqnorm);
   return GCR_LAUNCH_STATUS();
 }
 

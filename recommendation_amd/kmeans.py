@@ -18,6 +18,9 @@ from . import _lib
 from . import functional as Fn
 
 
+SORTED_UPDATE_MIN_POINTS = 1 << 16
+
+
 def kmeans_assign(x, centroids, half_sq):
     L = _lib.lib()
     n, d = x.shape
@@ -54,6 +57,13 @@ def run_kmeans(x, k, niter=20, seed=1234, init_centroids=None, max_points_per_ce
     stream = _lib.cur_stream(x.device)
 
     def update(assign, n_rows):
+        if n_rows >= SORTED_UPDATE_MIN_POINTS:
+            # points ordered by cluster: one row atomic per run instead of one per point
+            keys, perm, _ = Fn._sorted_order(assign, k)
+            _lib.check(L.gcr_kmeans_update_sorted_f32(_lib.dptr(xt), n_rows, d, _lib.dptr(keys), _lib.dptr(perm), k,
+                                                      _lib.dptr(cent), _lib.dptr(half_sq), _lib.dptr(sums),
+                                                      _lib.dptr(counts), stream), "gcr_kmeans_update_sorted_f32")
+            return
         _lib.check(L.gcr_kmeans_update_f32(_lib.dptr(xt), n_rows, d, _lib.dptr(assign), k, _lib.dptr(cent),
                                            _lib.dptr(half_sq), _lib.dptr(sums), _lib.dptr(counts), stream),
                    "gcr_kmeans_update_f32")

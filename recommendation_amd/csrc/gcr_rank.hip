@@ -174,6 +174,118 @@ __device__ int pick_bin(const uint32_t* hist, int nbins, uint32_t want, uint32_t
   return bin;
 }
 
+// Exact top-k of one row by a 3-pass radix select (11 + 11 + 10 bits) over the whole row + gather + bitonic
+// sort; ties at the threshold go to the smaller item id.  Used for short rows and as the fallback of the
+// candidate filter below.
+__device__ void topk_row_full(const float* __restrict__ row, int64_t n_items, int k, int64_t q,
+                              int64_t* __restrict__ top_items, float* __restrict__ top_scores, uint32_t* hist,
+                              uint32_t* sh, unsigned long long* cand, uint32_t* eq_idx, uint32_t& n_gt, uint32_t& n_eq) {
+  const int tid = threadIdx.x;
+  const int kk = (int)(k < n_items ? k : n_items);
+  // --- pass A: top 11 bits
+  for (int b = tid; b < 2048; b += kTopThreads) hist[b] = 0;
+  __syncthreads();
+  for (int64_t j = tid; j < n_items; j += kTopThreads) atomicAdd(&hist[order_key(row[j]) >> 21], 1u);
+  __syncthreads();
+  uint32_t above = 0;
+  const uint32_t b1 = (uint32_t)pick_bin(hist, 2048, (uint32_t)kk, &above, sh);
+  uint32_t want = (uint32_t)kk - above;
+  // --- pass B: next 11 bits inside bin b1
+  for (int b = tid; b < 2048; b += kTopThreads) hist[b] = 0;
+  __syncthreads();
+  for (int64_t j = tid; j < n_items; j += kTopThreads) {
+    const uint32_t key = order_key(row[j]);
+    if ((key >> 21) == b1) atomicAdd(&hist[(key >> 10) & 0x7FFu], 1u);
+  }
+  __syncthreads();
+  const uint32_t b2 = (uint32_t)pick_bin(hist, 2048, want, &above, sh);
+  want -= above;
+  // --- pass C: last 10 bits
+  for (int b = tid; b < 1024; b += kTopThreads) hist[b] = 0;
+  __syncthreads();
+  const uint32_t prefix = (b1 << 11) | b2;
+  for (int64_t j = tid; j < n_items; j += kTopThreads) {
+    const uint32_t key = order_key(row[j]);
+    if ((key >> 10) == prefix) atomicAdd(&hist[key & 0x3FFu], 1u);
+  }
+  __syncthreads();
+  const uint32_t b3 = (uint32_t)pick_bin(hist, 1024, want, &above, sh);
+  const uint32_t need_eq = want - above;          // how many elements equal to the threshold to take
+  const uint32_t thr = (prefix << 10) | b3;
+  // --- gather: everything above the threshold, and the `need_eq` smallest item ids equal to it
+  if (tid == 0) {
+    n_gt = 0;
+    n_eq = 0;
+  }
+  __syncthreads();
+  for (int64_t j = tid; j < n_items; j += kTopThreads) {
+    const uint32_t key = order_key(row[j]);
+    if (key > thr) {
+      const uint32_t p = atomicAdd(&n_gt, 1u);
+      if (p < (uint32_t)kMaxK) cand[p] = ((unsigned long long)key << 32) | (0xFFFFFFFFu - (uint32_t)j);
+    } else if (key == thr) {
+      const uint32_t p = atomicAdd(&n_eq, 1u);
+      if (p < (uint32_t)kEqCap) eq_idx[p] = (uint32_t)j;
+    }
+  }
+  __syncthreads();
+  const uint32_t gt = n_gt;
+  if (n_eq <= (uint32_t)kEqCap) {
+    // rank of each tied id among the ties (O(n_eq^2 / threads), n_eq is tiny for real scores)
+    for (uint32_t a = tid; a < n_eq; a += kTopThreads) {
+      const uint32_t me = eq_idx[a];
+      uint32_t rank = 0;
+      for (uint32_t b = 0; b < n_eq; ++b) rank += eq_idx[b] < me;
+      if (rank < need_eq) cand[gt + rank] = ((unsigned long long)thr << 32) | (0xFFFFFFFFu - me);
+    }
+  } else if (tid == 0) {
+    // pathological (huge tie, e.g. an all-equal row): first `need_eq` ids in index order
+    uint32_t taken = 0;
+    for (int64_t j = 0; j < n_items && taken < need_eq; ++j)
+      if (order_key(row[j]) == thr) cand[gt + taken++] = ((unsigned long long)thr << 32) | (0xFFFFFFFFu - (uint32_t)j);
+  }
+  __syncthreads();
+  // --- bitonic sort (descending) of the kk candidates, padded to a power of two with 0
+  int n2 = 1;
+  while (n2 < kk) n2 <<= 1;
+  for (int i = kk + tid; i < n2; i += kTopThreads) cand[i] = 0ull;
+  __syncthreads();
+  for (int size = 2; size <= n2; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int i = tid; i < n2; i += kTopThreads) {
+        const int partner = i ^ stride;
+        if (partner > i) {
+          const bool desc = (i & size) == 0;
+          const unsigned long long a = cand[i], b = cand[partner];
+          if ((a < b) == desc) {
+            cand[i] = b;
+            cand[partner] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = tid; i < k; i += kTopThreads) {
+    if (i < kk) {
+      const uint32_t item = 0xFFFFFFFFu - (uint32_t)(cand[i] & 0xFFFFFFFFull);
+      top_items[q * k + i] = item;
+      top_scores[q * k + i] = row[item];
+    } else {
+      top_items[q * k + i] = -1;
+      top_scores[q * k + i] = -INFINITY;
+    }
+  }
+}
+
+constexpr int kSample = 4096;      // prefix of the row that supplies the candidate threshold
+constexpr int kCandCap = 4096;     // candidates kept in LDS
+
+// One 256-thread block per user row.  Long rows (the 100K-item catalogue) are not radix-selected in
+// full: the k-th largest key of the first 4096 scores is a lower bound of the row's k-th largest, so one
+// streaming pass keeps only the scores >= that bound (about k * n / 4096 of them) in LDS, and the exact
+// top-k (ties -> smaller item id) is a bitonic sort of those.  More than 4096 candidates (a row whose
+// prefix is unrepresentatively low) falls back to the full select: the result is exact either way.
 __global__ __launch_bounds__(kTopThreads) void topk_masked_kernel(float* __restrict__ scores, int64_t n_query,
                                                                   int64_t n_items, const int64_t* __restrict__ user_ids,
                                                                   int64_t n_users,
@@ -183,9 +295,9 @@ __global__ __launch_bounds__(kTopThreads) void topk_masked_kernel(float* __restr
                                                                   float* __restrict__ top_scores) {
   __shared__ uint32_t hist[2048];
   __shared__ uint32_t sh[kTopThreads + 2];
-  __shared__ unsigned long long cand[kMaxK];   // (key << 32) | (0xFFFFFFFF - item)
+  __shared__ unsigned long long cand[kCandCap];   // (key << 32) | (0xFFFFFFFF - item); first kSample words double as the sample
   __shared__ uint32_t eq_idx[kEqCap];
-  __shared__ uint32_t n_gt, n_eq;
+  __shared__ uint32_t n_gt, n_eq, n_cand;
   const int tid = threadIdx.x;
   for (int64_t q = blockIdx.x; q < n_query; q += gridDim.x) {
     float* row = scores + q * n_items;
@@ -198,100 +310,100 @@ __global__ __launch_bounds__(kTopThreads) void topk_masked_kernel(float* __restr
     }
     __syncthreads();
     const int kk = (int)(k < n_items ? k : n_items);
-    // --- pass A: top 11 bits
-    for (int b = tid; b < 2048; b += kTopThreads) hist[b] = 0;
-    __syncthreads();
-    for (int64_t j = tid; j < n_items; j += kTopThreads) atomicAdd(&hist[order_key(row[j]) >> 21], 1u);
-    __syncthreads();
-    uint32_t above = 0;
-    const uint32_t b1 = (uint32_t)pick_bin(hist, 2048, (uint32_t)kk, &above, sh);
-    uint32_t want = (uint32_t)kk - above;
-    // --- pass B: next 11 bits inside bin b1
-    for (int b = tid; b < 2048; b += kTopThreads) hist[b] = 0;
-    __syncthreads();
-    for (int64_t j = tid; j < n_items; j += kTopThreads) {
-      const uint32_t key = order_key(row[j]);
-      if ((key >> 21) == b1) atomicAdd(&hist[(key >> 10) & 0x7FFu], 1u);
-    }
-    __syncthreads();
-    const uint32_t b2 = (uint32_t)pick_bin(hist, 2048, want, &above, sh);
-    want -= above;
-    // --- pass C: last 10 bits
-    for (int b = tid; b < 1024; b += kTopThreads) hist[b] = 0;
-    __syncthreads();
-    const uint32_t prefix = (b1 << 11) | b2;
-    for (int64_t j = tid; j < n_items; j += kTopThreads) {
-      const uint32_t key = order_key(row[j]);
-      if ((key >> 10) == prefix) atomicAdd(&hist[key & 0x3FFu], 1u);
-    }
-    __syncthreads();
-    const uint32_t b3 = (uint32_t)pick_bin(hist, 1024, want, &above, sh);
-    const uint32_t need_eq = want - above;          // how many elements equal to the threshold to take
-    const uint32_t thr = (prefix << 10) | b3;
-    // --- gather: everything above the threshold, and the `need_eq` smallest item ids equal to it
-    if (tid == 0) {
-      n_gt = 0;
-      n_eq = 0;
-    }
-    __syncthreads();
-    for (int64_t j = tid; j < n_items; j += kTopThreads) {
-      const uint32_t key = order_key(row[j]);
-      if (key > thr) {
-        const uint32_t p = atomicAdd(&n_gt, 1u);
-        if (p < (uint32_t)kMaxK) cand[p] = ((unsigned long long)key << 32) | (0xFFFFFFFFu - (uint32_t)j);
-      } else if (key == thr) {
-        const uint32_t p = atomicAdd(&n_eq, 1u);
-        if (p < (uint32_t)kEqCap) eq_idx[p] = (uint32_t)j;
+    bool done = false;
+    if (n_items >= 4 * kSample) {
+      // --- threshold: kk-th largest key of the prefix (3-pass radix select over the LDS copy)
+      uint32_t* skey = reinterpret_cast<uint32_t*>(cand);
+      for (int j = tid; j < kSample; j += kTopThreads) skey[j] = order_key(row[j]);
+      uint32_t prefix = 0, want = (uint32_t)kk, above = 0;
+      const int shifts[3] = {21, 10, 0}, widths[3] = {11, 11, 10};
+      for (int pass = 0; pass < 3; ++pass) {
+        const int nb = 1 << widths[pass];
+        for (int b2 = tid; b2 < nb; b2 += kTopThreads) hist[b2] = 0;
+        __syncthreads();
+        for (int j = tid; j < kSample; j += kTopThreads) {
+          const uint32_t key = skey[j];
+          const bool in_prefix = pass == 0 || (key >> (shifts[pass] + widths[pass])) == prefix;
+          if (in_prefix) atomicAdd(&hist[(key >> shifts[pass]) & (uint32_t)(nb - 1)], 1u);
+        }
+        __syncthreads();
+        const uint32_t bin = (uint32_t)pick_bin(hist, nb, want, &above, sh);
+        want -= above;
+        prefix = (prefix << widths[pass]) | bin;
       }
-    }
-    __syncthreads();
-    const uint32_t gt = n_gt;
-    if (n_eq <= (uint32_t)kEqCap) {
-      // rank of each tied id among the ties (O(n_eq^2 / threads), n_eq is tiny for real scores)
-      for (uint32_t a = tid; a < n_eq; a += kTopThreads) {
-        const uint32_t me = eq_idx[a];
-        uint32_t rank = 0;
-        for (uint32_t b = 0; b < n_eq; ++b) rank += eq_idx[b] < me;
-        if (rank < need_eq) cand[gt + rank] = ((unsigned long long)thr << 32) | (0xFFFFFFFFu - me);
-      }
-    } else if (tid == 0) {
-      // pathological (huge tie, e.g. an all-equal row): first `need_eq` ids in index order
-      uint32_t taken = 0;
-      for (int64_t j = 0; j < n_items && taken < need_eq; ++j)
-        if (order_key(row[j]) == thr) cand[gt + taken++] = ((unsigned long long)thr << 32) | (0xFFFFFFFFu - (uint32_t)j);
-    }
-    __syncthreads();
-    // --- bitonic sort (descending) of the kk candidates, padded to a power of two with 0
-    int n2 = 1;
-    while (n2 < kk) n2 <<= 1;
-    for (int i = kk + tid; i < n2; i += kTopThreads) cand[i] = 0ull;
-    __syncthreads();
-    for (int size = 2; size <= n2; size <<= 1) {
-      for (int stride = size >> 1; stride > 0; stride >>= 1) {
-        for (int i = tid; i < n2; i += kTopThreads) {
-          const int partner = i ^ stride;
-          if (partner > i) {
-            const bool desc = (i & size) == 0;
-            const unsigned long long a = cand[i], b = cand[partner];
-            if ((a < b) == desc) {
-              cand[i] = b;
-              cand[partner] = a;
+      const uint32_t thr0 = prefix;                 // exact kk-th largest key of the prefix
+      if (tid == 0) n_cand = 0;
+      __syncthreads();
+      // --- one pass over the row: keep everything >= thr0 (16-B loads, four in flight per thread)
+      auto keep = [&](float v, int64_t j) {
+        const uint32_t key = order_key(v);
+        if (key >= thr0) {
+          const uint32_t p = atomicAdd(&n_cand, 1u);
+          if (p < (uint32_t)kCandCap) cand[p] = ((unsigned long long)key << 32) | (0xFFFFFFFFu - (uint32_t)j);
+        }
+      };
+      if ((n_items & 3) == 0) {
+        const float4* row4 = reinterpret_cast<const float4*>(row);
+        const int64_t n4 = n_items >> 2;
+        for (int64_t j0 = 0; j0 < n4; j0 += 4 * kTopThreads) {
+          float4 v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int64_t j4 = j0 + u * kTopThreads + tid;
+            v[u] = j4 < n4 ? row4[j4] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int64_t j = 4 * (j0 + u * kTopThreads + tid);
+            if (j < n_items) {
+              keep(v[u].x, j);
+              keep(v[u].y, j + 1);
+              keep(v[u].z, j + 2);
+              keep(v[u].w, j + 3);
             }
           }
         }
-        __syncthreads();
-      }
-    }
-    for (int i = tid; i < k; i += kTopThreads) {
-      if (i < kk) {
-        const uint32_t item = 0xFFFFFFFFu - (uint32_t)(cand[i] & 0xFFFFFFFFull);
-        top_items[q * k + i] = item;
-        top_scores[q * k + i] = row[item];
       } else {
-        top_items[q * k + i] = -1;
-        top_scores[q * k + i] = -INFINITY;
+        for (int64_t j = tid; j < n_items; j += kTopThreads) keep(row[j], j);
       }
+      __syncthreads();
+      const uint32_t nc = n_cand;
+      if (nc <= (uint32_t)kCandCap) {
+        int n2 = 1;
+        while (n2 < (int)nc) n2 <<= 1;
+        for (int i = (int)nc + tid; i < n2; i += kTopThreads) cand[i] = 0ull;
+        __syncthreads();
+        for (int size = 2; size <= n2; size <<= 1) {
+          for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = tid; i < n2; i += kTopThreads) {
+              const int partner = i ^ stride;
+              if (partner > i) {
+                const bool desc = (i & size) == 0;
+                const unsigned long long x = cand[i], y = cand[partner];
+                if ((x < y) == desc) {
+                  cand[i] = y;
+                  cand[partner] = x;
+                }
+              }
+            }
+            __syncthreads();
+          }
+        }
+        for (int i = tid; i < k; i += kTopThreads) {
+          if (i < kk) {
+            const uint32_t item = 0xFFFFFFFFu - (uint32_t)(cand[i] & 0xFFFFFFFFull);
+            top_items[q * k + i] = item;
+            top_scores[q * k + i] = row[item];
+          } else {
+            top_items[q * k + i] = -1;
+            top_scores[q * k + i] = -INFINITY;
+          }
+        }
+        done = true;
+      }
+      __syncthreads();
     }
+    if (!done) topk_row_full(row, n_items, k, q, top_items, top_scores, hist, sh, cand, eq_idx, n_gt, n_eq);
     __syncthreads();
   }
 }

@@ -95,3 +95,40 @@ def test_topk_ties_and_reference_protocol(golden):
     assert lines[0] == "Top 10\n" and lines[5] == "Top 20\n" and len(lines) == 10
     hits = Metric.hits(data.test_set, rec)
     assert 0 <= Metric.hit_ratio(data.test_set, hits) <= 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["random", "ascending", "descending", "ties", "hot_tail"])
+def test_topk_long_rows_candidate_filter_and_fallback(layout):
+    """gcr_topk_masked_f32 on catalogue-length rows (n_items >= 16384: the prefix-threshold candidate filter):
+    random order (filter path), scores ascending in item id (the prefix is the row's minimum: > 4096
+    candidates, full-select fallback), descending, massive ties at the threshold, and the top scores all at
+    the end of the row.  Exact against numpy's stable sort (ties -> smaller item id)."""
+    from recommendation_amd import _lib
+    rng = np.random.default_rng(7)
+    n_q, n_i, k = 9, 40_000, 50
+    s = rng.standard_normal((n_q, n_i)).astype(np.float32)
+    if layout == "ascending":
+        s = np.sort(s, 1)
+    elif layout == "descending":
+        s = -np.sort(-s, 1)
+    elif layout == "ties":
+        s = np.round(s * 2).astype(np.float32) / 2          # ~20 distinct values: huge tie groups
+    elif layout == "hot_tail":
+        s[:, -200:] += 10.0
+    train = [np.sort(rng.choice(n_i, 30, replace=False)) for _ in range(n_q)]
+    rowptr = np.concatenate([[0], np.cumsum([len(t) for t in train])]).astype(np.int64)
+    items = np.concatenate(train).astype(np.int32)
+    st = torch.from_numpy(s.copy()).cuda()
+    top_i = torch.empty(n_q, k, dtype=torch.int64, device="cuda")
+    top_s = torch.empty(n_q, k, dtype=torch.float32, device="cuda")
+    rp, it = torch.from_numpy(rowptr).cuda(), torch.from_numpy(items).cuda()
+    _lib.check(_lib.lib().gcr_topk_masked_f32(_lib.dptr(st), n_q, n_i, None, n_q, _lib.dptr(rp), _lib.dptr(it), k,
+                                              _lib.dptr(top_i), _lib.dptr(top_s), _lib.cur_stream(st.device)),
+               "gcr_topk_masked_f32")
+    for q in range(n_q):
+        row = s[q].copy()
+        row[train[q]] = -np.inf
+        ref = np.argsort(-row, kind="stable")[:k]           # stable: equal scores keep increasing item id
+        assert np.array_equal(top_i[q].cpu().numpy(), ref), (layout, q)
+        assert np.array_equal(top_s[q].cpu().numpy(), row[ref])

@@ -274,3 +274,25 @@ def test_info_nce_loss_round_trip_properties(Ls):
     from recommendation_amd import functional as F2
     lse, pos = F2.infonce_stats(z1, z1, None, 0.2)
     assert float((pos - 5.0).abs().max()) < 1e-4 and bool((lse >= pos - 1e-4).all())
+
+
+@pytest.mark.parametrize("sa,sb", [(1e15, 1e-15), (1e-12, 1e12), (3e4, 3e-4), (1e-20, 1e20), (1.0, 1.0)])
+def test_exponent_range_of_unnormalised_operands(Fn, sa, sb):
+    """The split-operand engine claims f32's exponent range (bf16 planes): un-normalised operands whose
+    magnitudes differ by up to 40 orders, products O(1) — row LSE and both gradients against float64."""
+    rng = np.random.default_rng(11)
+    m, n, d = 70, 900, 64
+    a = (rng.standard_normal((m, d)) * 0.3 * sa).astype(np.float32)
+    b = (rng.standard_normal((n, d)) * 0.3 * sb).astype(np.float32)
+    pos = rng.integers(0, n, m)
+    w = rng.standard_normal(m)
+    at, bt = _t(a, True), _t(b, True)
+    lse, pl = Fn.infonce_stats(at, bt, pos, 0.5, normalize=False)
+    a64, b64 = torch.from_numpy(a).double().requires_grad_(True), torch.from_numpy(b).double().requires_grad_(True)
+    s = a64 @ b64.T * 2.0
+    ref_lse = torch.logsumexp(s, 1)
+    np.testing.assert_allclose(lse.detach().cpu().numpy(), ref_lse.detach().numpy(), rtol=1e-5, atol=1e-5)
+    ((lse - pl) * _t(w.astype(np.float32))).sum().backward()
+    ((ref_lse - s[torch.arange(m), torch.from_numpy(pos)]) * torch.from_numpy(w)).sum().backward()
+    for got, want in ((at.grad, a64.grad.numpy()), (bt.grad, b64.grad.numpy())):
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-4, atol=1e-5 * np.abs(want).max())

@@ -200,6 +200,11 @@ int32_t gcr_infonce_fwd_f32(const float* a, const float* a_scale, int64_t m,
  * same view.  Not combinable with col_sum.
  */
 #define GCR_INFONCE_EXCLUDE_DIAGONAL 1u
+/* GCR_INFONCE_UNIT_ROWS: the caller promises |a_scale[i] * a_i|_2 <= 1 and |b_scale[j] * b_j|_2 <= 1 (rows
+ * normalised by the scales, as every InfoNCE call site of the reference does).  It allows the two-plane f16
+ * engine (csrc/gcr_infonce.hip, "h2": f32 results, half the matrix-core work of the bf16 split) for d <= 64
+ * and inv_tau <= 20; forward and backward of one problem must pass the same flags. */
+#define GCR_INFONCE_UNIT_ROWS 2u
 int32_t gcr_infonce_fwd_ex_f32(const float* a, const float* a_scale, int64_t m,
                                const float* b, const float* b_scale, int64_t n, int32_t d,
                                float inv_tau, float* lse, float* col_sum, float col_bound,

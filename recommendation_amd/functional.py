@@ -380,9 +380,10 @@ def row_inv_norm(x, eps=1e-12):
 
 
 INFONCE_EXCLUDE_DIAGONAL = 1
+INFONCE_UNIT_ROWS = 2
 
 
-def infonce_lse_raw(a, a_scale, b, b_scale, inv_tau, col_bound=None, exclude_diagonal=False):
+def infonce_lse_raw(a, a_scale, b, b_scale, inv_tau, col_bound=None, exclude_diagonal=False, unit_rows=False):
     """lse[i] = log sum_j exp(inv_tau * a_scale[i] b_scale[j] <a_i, b_j>) (no autograd).
     col_bound (an upper bound of every logit, e.g. inv_tau for unit rows): also return the column
     logsumexp over the anchors [N] from the same pass (float atomics) as a second value.
@@ -396,7 +397,8 @@ def infonce_lse_raw(a, a_scale, b, b_scale, inv_tau, col_bound=None, exclude_dia
     _lib.check(L.gcr_infonce_fwd_ex_f32(_lib.dptr(a), _lib.dptr(a_scale), m, _lib.dptr(b), _lib.dptr(b_scale), n, d,
                                         float(inv_tau), _lib.dptr(lse), _lib.dptr(col_sum),
                                         float(col_bound) if col_bound is not None else 0.0, _lib.dptr(ws),
-                                        INFONCE_EXCLUDE_DIAGONAL if exclude_diagonal else 0,
+                                        (INFONCE_EXCLUDE_DIAGONAL if exclude_diagonal else 0) |
+                                        (INFONCE_UNIT_ROWS if unit_rows else 0),
                                         _lib.cur_stream(a.device)), "gcr_infonce_fwd_ex_f32")
     if col_bound is None:
         return lse
@@ -412,7 +414,7 @@ def pos_logit_raw(a, a_scale, b, b_scale, pos, scale):
     return out
 
 
-def _infonce_bwd_raw(x, x_scale, y, y_scale, inv_tau, lse_x, w_x, lse_y, w_y, exclude_diagonal=False):
+def _infonce_bwd_raw(x, x_scale, y, y_scale, inv_tau, lse_x, w_x, lse_y, w_y, exclude_diagonal=False, unit_rows=False):
     """g = inv_tau * sum_j P_ij yhat_j (see gcr_infonce_bwd_f32): gradient w.r.t. the scaled rows of x."""
     L = _lib.lib()
     mx, d = x.shape
@@ -422,7 +424,8 @@ def _infonce_bwd_raw(x, x_scale, y, y_scale, inv_tau, lse_x, w_x, lse_y, w_y, ex
     _lib.check(L.gcr_infonce_bwd_ex_f32(_lib.dptr(x), _lib.dptr(x_scale), mx, _lib.dptr(y), _lib.dptr(y_scale), y.shape[0],
                                         d, float(inv_tau), _lib.dptr(lse_x), _lib.dptr(w_x), _lib.dptr(lse_y),
                                         _lib.dptr(w_y), _lib.dptr(g), _lib.dptr(ws),
-                                        INFONCE_EXCLUDE_DIAGONAL if exclude_diagonal else 0, _lib.cur_stream(x.device)),
+                                        (INFONCE_EXCLUDE_DIAGONAL if exclude_diagonal else 0) |
+                                        (INFONCE_UNIT_ROWS if unit_rows else 0), _lib.cur_stream(x.device)),
                "gcr_infonce_bwd_ex_f32")
     return g
 
@@ -447,11 +450,12 @@ class _InfoNCEStats(torch.autograd.Function):
         if one_pass:
             lse, col = infonce_lse_raw(a_p, sa, b_p, sb, inv_tau, col_bound=inv_tau * 1.0001)
         else:
-            lse = infonce_lse_raw(a_p, sa, b_p, sb, inv_tau, exclude_diagonal=exd)
-            col = infonce_lse_raw(b_p, sb, a_p, sa, inv_tau, exclude_diagonal=exd) if want_col else None
+            # normalised rows are unit rows: the library may then take the two-plane f16 engine
+            lse = infonce_lse_raw(a_p, sa, b_p, sb, inv_tau, exclude_diagonal=exd, unit_rows=normalize)
+            col = infonce_lse_raw(b_p, sb, a_p, sa, inv_tau, exclude_diagonal=exd, unit_rows=normalize) if want_col else None
         pl = pos_logit_raw(a_p, sa, b_p, sb, pos, inv_tau)
         ctx.save_for_backward(a_p, b_p, pos, sa, sb, lse, col)
-        ctx.inv_tau, ctx.d, ctx.exd = inv_tau, a.shape[1], exd
+        ctx.inv_tau, ctx.d, ctx.exd, ctx.unit = inv_tau, a.shape[1], exd, bool(normalize)
         if want_col:
             return lse, pl, col
         return lse, pl
@@ -469,9 +473,9 @@ class _InfoNCEStats(torch.autograd.Function):
         ga = gb = None
         stream = _lib.cur_stream(a.device)
         if need_a:
-            ga = _infonce_bwd_raw(a, sa, b, sb, inv_tau, lse_r, g_lse, col_r, g_col, ctx.exd)
+            ga = _infonce_bwd_raw(a, sa, b, sb, inv_tau, lse_r, g_lse, col_r, g_col, ctx.exd, ctx.unit)
         if need_b:
-            gb = _infonce_bwd_raw(b, sb, a, sa, inv_tau, col_r, g_col, lse_r, g_lse, ctx.exd)
+            gb = _infonce_bwd_raw(b, sb, a, sa, inv_tau, col_r, g_col, lse_r, g_lse, ctx.exd, ctx.unit)
         if g_pos is not None and (need_a or need_b):
             _lib.check(L.gcr_infonce_pos_bwd_f32(_lib.dptr(a), _lib.dptr(sa), _lib.dptr(b), _lib.dptr(sb), _lib.dptr(pos),
                                                  _lib.dptr(g_pos.contiguous().float()), a.shape[0], b.shape[0], a.shape[1],

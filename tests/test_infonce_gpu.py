@@ -16,10 +16,11 @@ def Fn():
     return functional
 
 
-@pytest.fixture(autouse=True, params=["b3", "f32"])
+@pytest.fixture(autouse=True, params=["b3", "f32", "h2"])
 def engine(request, monkeypatch):
-    """Every test of this module runs on both MFMA engines (csrc/gcr_infonce.hip): the split-operand
-    bf16 engine (default for d <= 128) and the f32 MFMA engine, with the same tolerances."""
+    """Every test of this module runs on all three MFMA engines (csrc/gcr_infonce.hip): the split-operand
+    bf16 engine (d <= 64), the f32 MFMA engine, and the two-plane f16 engine (unit-norm operands, d <= 64,
+    1/tau <= 20; anything else falls back to bf16 / f32), with the same tolerances."""
     monkeypatch.setenv("GCR_INFONCE_ENGINE", request.param)
     return request.param
 
@@ -131,14 +132,17 @@ def test_golden_ncl_infonce_grads(Ls, golden, b_cos):
     _gclose(z2.grad, c[f"ncl_infonce_g2_257_{b_cos}"], floor=floor)
 
 
-def test_golden_ncl_structure_and_prototype(Ls, golden):
+def test_golden_ncl_structure_and_prototype(Ls, golden, engine):
     """NCLModel.ssl_layer_loss / ProtoNCE_loss (ncl.py:358-375) values and gradients."""
     c = golden("contrast.npz")
+    # lse - pos nearly cancels here (the positive dominates its softmax): the opt-in two-plane f16 engine,
+    # whose logits carry ~1.4x the error of the other two, lands at 1.03e-5 of the reference's value
+    rel = 2e-5 if engine == "h2" else 1e-5
     nu = int(c["ncl_num_users"])
     ctx, x0 = _t(c["ncl_ctx"], True), _t(c["ncl_x0"], True)
     ssl = Ls.ssl_layer_loss(ctx, x0, c["ncl_uidx"], c["ncl_iidx"], nu, float(c["ncl_ssl_temp"]),
                             float(c["ncl_ssl_reg"]), float(c["ncl_alpha"]))
-    assert float(ssl) == pytest.approx(float(c["ncl_ssl"]), rel=1e-5)
+    assert float(ssl) == pytest.approx(float(c["ncl_ssl"]), rel=rel)
     ssl.backward()
     _gclose(ctx.grad, c["ncl_ssl_gctx"], floor=1e-12)
     _gclose(x0.grad, c["ncl_ssl_gx0"], floor=1e-12)
@@ -146,7 +150,7 @@ def test_golden_ncl_structure_and_prototype(Ls, golden):
     proto = Ls.ProtoNCE_loss(x0p, c["ncl_uidx"], c["ncl_iidx"], nu, _t(c["ncl_ucent"]), _t(c["ncl_u2c"]),
                              _t(c["ncl_icent"]), _t(c["ncl_i2c"]), float(c["ncl_ssl_temp"]), float(c["ncl_proto_reg"]),
                              int(c["ncl_bsz"]))
-    assert float(proto) == pytest.approx(float(c["ncl_proto"]), rel=1e-5)
+    assert float(proto) == pytest.approx(float(c["ncl_proto"]), rel=rel)
     proto.backward()
     _gclose(x0p.grad, c["ncl_proto_gx0"], floor=1e-13)
 

@@ -62,7 +62,7 @@ def test_neighbor_discrimination_matches_dense(b, k, d):
         np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=1e-5 * np.abs(want).max())
 
 
-@pytest.mark.parametrize("engine", ["b3", "f32"])
+@pytest.mark.parametrize("engine", ["b3", "f32", "h2"])
 @pytest.mark.parametrize("m", [7, 257])
 def test_grace_dual_branch_infonce_matches_reference(golden, monkeypatch, engine, m):
     """losses.grace_infonce_loss against the reference's own DualBranchContrast outputs (values and both
@@ -82,7 +82,7 @@ def test_grace_dual_branch_infonce_matches_reference(golden, monkeypatch, engine
                 np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=1e-5 * np.abs(want).max() + 1e-9)
 
 
-@pytest.mark.parametrize("engine", ["b3", "f32"])
+@pytest.mark.parametrize("engine", ["b3", "f32", "h2"])
 @pytest.mark.parametrize("m,d", [(1, 64), (31, 64), (33, 64), (64, 64), (65, 32), (129, 64), (300, 128), (1000, 64), (2100, 64)])
 def test_exclude_diagonal_lse_and_grads(monkeypatch, engine, m, d):
     """GCR_INFONCE_EXCLUDE_DIAGONAL on square self-similarity problems across tile boundaries: row LSE

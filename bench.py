@@ -181,12 +181,19 @@ def main():
 
     extra = {"graph_build_s": round(t_build, 2), "nnz": nnz, "n_nodes": n,
              "spmm_parts": graph.plan.n_parts, "spmm_split_rows": graph.plan.n_long}
+    # the secondary rates and the CPU baseline must never cost the headline line
     if not args.no_extra:
-        extra.update(bench_extra(ra, Fn, graph, x0, k_layers, nnz, dev, n_u, n_i))
+        try:
+            extra.update(bench_extra(ra, Fn, graph, x0, k_layers, nnz, dev, n_u, n_i))
+        except Exception as e:      # noqa: BLE001
+            extra["extra_error"] = repr(e)
 
     cpu = None
     if not args.no_cpu_baseline:
-        cpu = cpu_baseline(graph, x0, k_layers, nnz)
+        try:
+            cpu = cpu_baseline(graph, x0, k_layers, nnz)
+        except Exception as e:      # noqa: BLE001
+            cpu = {"value": None, "unit": "edges/s", "cores": 0, "kind": "port", "sample": "failed: " + repr(e)}
 
     line = {
         "metric": "edges propagated/sec (LightGCN d=%d, %d-layer fwd message pass)" % (d, k_layers),

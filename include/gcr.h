@@ -160,11 +160,11 @@ int32_t gcr_edge_mask_bits(int64_t nnz, float pe, uint64_t seed, const int64_t* 
  * InfoNCE / prototype contrast: all-pairs logits on the matrix cores, fused 1/tau scale + row
  * logsumexp; the M x N score matrix is never materialised.  d must be 32, 64, 128 or 256
  * (GCR_EUNSUPPORTED otherwise; the host wrapper zero-pads other widths).  f32 in, f32 out, f32
- * accuracy on both engines: the f32 MFMA (v_mfma_f32_32x32x2_f32), or for d <= 64 the bf16 MFMA on
+ * accuracy on both engines: the f32 MFMA (v_mfma_f32_32x32x2_f32), or for d <= 128 the bf16 MFMA on
  * three error-free bf16 planes per operand (csrc/gcr_infonce.hip, "split-operand engine").
  * --------------------------------------------------------------------------------------------- */
 /* engine the InfoNCE / k-means kernels use for width d right now: 0 = f32 MFMA, 1 = split-operand bf16
- * (default for d <= 64; the environment variable GCR_INFONCE_ENGINE=f32 selects 0 everywhere) */
+ * (default for d <= 128; the environment variable GCR_INFONCE_ENGINE=f32 selects 0 everywhere) */
 int32_t gcr_infonce_engine(int32_t d);
 
 

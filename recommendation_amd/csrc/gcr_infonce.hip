@@ -840,10 +840,9 @@ __global__ __launch_bounds__(256, 2) void infonce_fwd_h2_kernel(const float* __r
 
 // engine selection: GCR_INFONCE_ENGINE = f32 | b3 (read per call so that A/B rounds interleave
 // in-process); d = 256 stays on the f32 engine (its three operand planes would not fit the registers)
-// Default: b3 for d <= 64, where forward AND backward have it (the backward must recompute the
+// Default: b3 for d <= 128, where forward AND backward have it (the backward must recompute the
 // forward's logits with the forward's engine, or sum_j P_ij = 1 only holds to ~1e-6 and
-// near-cancelling gradients lose digits).  GCR_INFONCE_ENGINE=b3all (measurement only) also takes
-// the forward-only kernels (row LSE, k-means assignment) at d = 128.
+// near-cancelling gradients lose digits).
 // h2 (two-plane f16) needs the caller's unit-rows promise, 1/tau <= 20 and d <= 64; GCR_INFONCE_ENGINE=b3 or
 // f32 switches it off
 bool use_h2(int d, float inv_tau, bool unit_rows) {
@@ -857,8 +856,7 @@ bool use_b3(int d) {
   if (d > 128) return false;
   const char* e = getenv("GCR_INFONCE_ENGINE");
   if (e != nullptr && e[0] == 'f') return false;
-  if (e != nullptr && e[0] == 'b' && e[1] == '3' && e[2] == 'a') return true;
-  return d <= 64;
+  return true;
 }
 
 // natural-log LSE of the scaled logits from the per-split (max2, sum2) partials
@@ -1191,7 +1189,11 @@ __global__ __launch_bounds__(256, 2) void infonce_bwd_b3_kernel(
     int64_t tiles_per_split, float* __restrict__ gpart) {
   using S = ShapeB3<D>;
   using B = BwdB3<D>;
-  __shared__ __align__(16) unsigned char lds[2][B::TILE_BYTES];
+  // d = 128: one tile is 54 KB (row-major + transposed planes): a single LDS buffer (two barriers per tile,
+  // two blocks per CU cover each other) instead of the double buffer of d <= 64
+  constexpr int NBUF = D <= 64 ? 2 : 1;
+  static_assert(NBUF == 2 || !ILV, "the interleaved loop is double-buffered");
+  __shared__ __align__(16) unsigned char lds[NBUF][B::TILE_BYTES];
   __shared__ __align__(16) float st_lse[2][kTileJ];
   __shared__ __align__(16) float st_w[2][kTileJ];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1236,13 +1238,13 @@ __global__ __launch_bounds__(256, 2) void infonce_bwd_b3_kernel(
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int u = 0; u < S::NLD; ++u) stage_store_b3t_one<D>(lds[buf], tid, regs[u], u);
+    for (int u = 0; u < S::NLD; ++u) stage_store_b3t_one<D>(lds[buf % NBUF], tid, regs[u], u);
     if (tid < kTileJ) {
       st_lse[buf][tid] = s_lse;
       st_w[buf][tid] = s_w;
     }
   };
-  if (ILV) {
+  if constexpr (ILV) {
     // Interleaved by hand (a wave issues in order, see the forward): phase 1 alternates the 6*KC score
     // MFMAs with the operand split + LDS stores of the NEXT tile (loaded one iteration earlier: two
     // staging register sets); phase 2 (exposed) forms P and splits its first 16 rows; phase 3
@@ -1452,7 +1454,7 @@ __global__ __launch_bounds__(256, 2) void infonce_bwd_b3_kernel(
         load_stats((tt + 1) * kTileJ);
       }
       f32x16 acc[1];
-      score_tile_b3<D, 1>(lds[cur], i32, h, bq, acc);
+      score_tile_b3<D, 1>(lds[cur % NBUF], i32, h, bq, acc);
       const int64_t j0 = tt * kTileJ;
       const bool ragged = j0 + kTileJ > ny;
       const int xr = EXD ? diag_offset(row_i, j0, h) : -1;
@@ -1472,7 +1474,7 @@ __global__ __launch_bounds__(256, 2) void infonce_bwd_b3_kernel(
         }
       }
       // G^T[c][i] += yhat[j][c] * P[j][i], 16 streamed rows per k-chunk, six bf16 terms
-      const unsigned char* tbase = lds[cur] + 3 * S::PLANE + i32 * B::RT + 8 * h;
+      const unsigned char* tbase = lds[cur % NBUF] + 3 * S::PLANE + i32 * B::RT + 8 * h;
   #pragma unroll
       for (int kc = 0; kc < 2; ++kc) {
         u32x4 pp[3];
@@ -1501,6 +1503,7 @@ __global__ __launch_bounds__(256, 2) void infonce_bwd_b3_kernel(
           gacc[c] = mfma_bf16(ya[0], pp[0], gacc[c]);
         }
       }
+      if (NBUF == 1) __syncthreads();          // every wave is done reading the only buffer
       if (more) store_tile(cur ^ 1);
       __syncthreads();
     }
@@ -1613,7 +1616,7 @@ int32_t launch_bwd(const float* x, const float* x_scale, int64_t mx, const float
     if (use_b3(D)) {
       const FwdPlan p = plan_bwd_rows(mx, ny, D, BwdB3<D>::ROWS_PER_BLOCK);
       float* gpart = p.nsplit == 1 ? g : reinterpret_cast<float*>(workspace);
-      const char* ie = getenv("GCR_INFONCE_BWD_ILV");   // A/B knob
+      const char* ie = getenv("GCR_INFONCE_BWD_ILV");   // A/B knob (d <= 64)
       if (exd)
         hipLaunchKernelGGL((infonce_bwd_b3_kernel<D, true, true>), dim3((unsigned)(p.m_blocks * p.nsplit)), dim3(256), 0,
                            s, x, x_scale, mx, y, y_scale, ny, inv_tau * kLog2e, inv_tau, lse_x, w_x, lse_y, w_y, p.nsplit,
@@ -1624,6 +1627,30 @@ int32_t launch_bwd(const float* x, const float* x_scale, int64_t mx, const float
                            p.tiles_per_split, gpart);
       else
         hipLaunchKernelGGL((infonce_bwd_b3_kernel<D, true>), dim3((unsigned)(p.m_blocks * p.nsplit)), dim3(256), 0, s,
+                           x, x_scale, mx, y, y_scale, ny, inv_tau * kLog2e, inv_tau, lse_x, w_x, lse_y, w_y, p.nsplit,
+                           p.tiles_per_split, gpart);
+      int32_t st = GCR_LAUNCH_STATUS();
+      if (st != GCR_OK) return st;
+      if (p.nsplit > 1) {
+        const int64_t n4 = mx * D / 4;
+        const int64_t want = (n4 + 255) / 256;
+        hipLaunchKernelGGL(bwd_reduce_kernel, dim3((unsigned)(want > 4096 ? 4096 : want)), dim3(256), 0, s, gpart,
+                           p.nsplit, n4, g);
+        return GCR_LAUNCH_STATUS();
+      }
+      return GCR_OK;
+    }
+  }
+  if constexpr (D == 128) {
+    if (use_b3(D)) {                    // single-buffered, un-pipelined variant of the bf16-split backward
+      const FwdPlan p = plan_bwd_rows(mx, ny, D, BwdB3<D>::ROWS_PER_BLOCK);
+      float* gpart = p.nsplit == 1 ? g : reinterpret_cast<float*>(workspace);
+      if (exd)
+        hipLaunchKernelGGL((infonce_bwd_b3_kernel<D, false, true>), dim3((unsigned)(p.m_blocks * p.nsplit)), dim3(256), 0,
+                           s, x, x_scale, mx, y, y_scale, ny, inv_tau * kLog2e, inv_tau, lse_x, w_x, lse_y, w_y, p.nsplit,
+                           p.tiles_per_split, gpart);
+      else
+        hipLaunchKernelGGL((infonce_bwd_b3_kernel<D, false>), dim3((unsigned)(p.m_blocks * p.nsplit)), dim3(256), 0, s,
                            x, x_scale, mx, y, y_scale, ny, inv_tau * kLog2e, inv_tau, lse_x, w_x, lse_y, w_y, p.nsplit,
                            p.tiles_per_split, gpart);
       int32_t st = GCR_LAUNCH_STATUS();
@@ -2218,7 +2245,7 @@ extern "C" int64_t gcr_infonce_bwd_workspace_bytes(int64_t mx, int64_t ny, int32
     default: p = plan_bwd<256>(mx, ny); break;
   }
   int64_t nsplit = p.nsplit;
-  if (d <= 64) {   // either engine (chosen per call)
+  if (d <= 128) {   // either engine (chosen per call)
     const FwdPlan q = plan_bwd_rows(mx, ny, d, 128);
     if (q.nsplit > nsplit) nsplit = q.nsplit;
   }

@@ -18,7 +18,7 @@ def once(fn, reps):
 
 
 g = torch.Generator(device="cuda").manual_seed(0)
-for (m, n, d) in [(2048, 1_000_000, 64), (2048, 100_000, 64), (20_000, 20_000, 64), (2048, 100_000, 32)]:
+for (m, n, d) in [(2048, 1_000_000, 64), (2048, 1_000_000, 128), (20_000, 20_000, 128), (2048, 100_000, 32)]:
     a = torch.randn(m, d, device="cuda", generator=g)
     b = torch.randn(n, d, device="cuda", generator=g)
     sa, sb = Fn.row_inv_norm(a), Fn.row_inv_norm(b)

@@ -19,8 +19,8 @@ def Fn():
 @pytest.fixture(autouse=True, params=["b3", "f32", "h2"])
 def engine(request, monkeypatch):
     """Every test of this module runs on all three MFMA engines (csrc/gcr_infonce.hip): the split-operand
-    bf16 engine (d <= 64), the f32 MFMA engine, and the two-plane f16 engine (unit-norm operands, d <= 64,
-    1/tau <= 20; anything else falls back to bf16 / f32), with the same tolerances."""
+    bf16 engine (d <= 128, the default), the f32 MFMA engine, and the two-plane f16 engine (unit-norm
+    operands, d <= 64, 1/tau <= 20; anything else falls back to bf16 / f32), with the same tolerances."""
     monkeypatch.setenv("GCR_INFONCE_ENGINE", request.param)
     return request.param
 

@@ -222,7 +222,7 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // SIDE 0: rows of grad_user keyed by u; 1: rows of grad_item keyed by the positive item; 2: keyed by the
 // negative item (entries are the batch * n_neg negative slots).  Same arithmetic as bpr_bwd_kernel.
-template <int SIDE, int NV>
+template <int SIDE, int NV, bool ONE_NEG>
 __global__ __launch_bounds__(256) void bpr_bwd_sorted_kernel(
     const float* __restrict__ user_tab, const float* __restrict__ item_tab, int d, const int64_t* __restrict__ u_idx,
     const int64_t* __restrict__ i_idx, const int64_t* __restrict__ j_idx, int64_t batch, int n_neg, int64_t n_users,
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void bpr_bwd_sorted_kernel(
     // lane e prepares entry c0 + e: key, coefficient and the row(s) it pulls in
     uint32_t my_key = kBadKey;
     float my_coef = 0.f;
-    int64_t my_u = 0, my_i = 0, my_b = 0;
+    int64_t my_u = 0, my_i = 0, my_b = 0, my_j = 0;
     if (lane < cnt) {
       my_key = keys[c0 + lane];
       if (my_key >= (uint32_t)(SIDE == 0 ? n_users : n_items)) my_key = kBadKey;   // gcr_sort_index's out-of-range key
@@ -250,13 +250,18 @@ __global__ __launch_bounds__(256) void bpr_bwd_sorted_kernel(
       const bool ok = my_key != kBadKey && dl == dl;
       const float g = g_loss * dl;
       my_coef = SIDE == 2 ? -g / (float)n_neg : g;
-      if (SIDE == 0) my_i = ok ? i_idx[b] : 0;
-      else my_u = ok ? u_idx[b] : 0;
+      if (SIDE == 0) {
+        my_i = ok ? i_idx[b] : 0;
+        if (ONE_NEG) my_j = ok ? j_idx[b] : 0;
+      } else {
+        my_u = ok ? u_idx[b] : 0;
+      }
       my_b = b;
       if (!ok) my_key = kBadKey;
     }
     uint32_t cur = kBadKey;
     float acc[NV];
+    float run_n = 0.f;                      // entries of the current run: the regulariser's 2 g x per entry
 #pragma unroll
     for (int v = 0; v < NV; ++v) acc[v] = 0.f;
     auto flush = [&]() {
@@ -264,7 +269,7 @@ __global__ __launch_bounds__(256) void bpr_bwd_sorted_kernel(
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
           const int c = lane + 64 * v;
-          if (c < d) atomicAdd(grad_out + (int64_t)cur * d + c, acc[v]);
+          if (c < d) atomicAdd(grad_out + (int64_t)cur * d + c, acc[v] + c_self * run_n * self_tab[(int64_t)cur * d + c]);
         }
       }
     };
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(256) void bpr_bwd_sorted_kernel(
     constexpr int kGather = NV == 1 ? 8 : 4;
     for (int e0 = 0; e0 < cnt; e0 += kGather) {
       uint32_t key[kGather];
-      float coef[kGather], row[kGather][NV], own[kGather][NV];
+      float coef[kGather], row[kGather][NV];
 #pragma unroll
       for (int q = 0; q < kGather; ++q) {
         const int e = e0 + q < cnt ? e0 + q : cnt - 1;
@@ -284,14 +289,19 @@ __global__ __launch_bounds__(256) void bpr_bwd_sorted_kernel(
         const bool live = key[q] != kBadKey;
         const int64_t src = live ? lane64(SIDE == 0 ? my_i : my_u, e) : 0;
         const float* tab = SIDE == 0 ? item_tab : user_tab;
-        const int64_t self_row = live ? (int64_t)key[q] : 0;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
           const int c = lane + 64 * v;
           row[q][v] = c < d ? tab[src * d + c] : 0.f;
-          own[q][v] = c < d ? self_tab[self_row * d + c] : 0.f;      // same row for a whole run: L1 / L2 hits
         }
-        if (SIDE == 0) {
+        if (SIDE == 0 && ONE_NEG) {
+          const int64_t j = live ? lane64(my_j, e) : 0;
+#pragma unroll
+          for (int v = 0; v < NV; ++v) {
+            const int c = lane + 64 * v;
+            if (c < d) row[q][v] -= item_tab[j * d + c];
+          }
+        } else if (SIDE == 0) {
           const int64_t b = lane64(my_b, e);
           const float inv = 1.0f / (float)n_neg;
           for (int k = 0; k < n_neg; ++k) {
@@ -310,11 +320,13 @@ __global__ __launch_bounds__(256) void bpr_bwd_sorted_kernel(
         if (key[q] != cur) {
           flush();
           cur = key[q];
+          run_n = 0.f;
 #pragma unroll
           for (int v = 0; v < NV; ++v) acc[v] = 0.f;
         }
+        run_n += 1.f;
 #pragma unroll
-        for (int v = 0; v < NV; ++v) acc[v] += coef[q] * row[q][v] + c_self * own[q][v];
+        for (int v = 0; v < NV; ++v) acc[v] += coef[q] * row[q][v];
       }
     }
     flush();
@@ -417,8 +429,14 @@ extern "C" int32_t gcr_bpr_bwd_sorted_f32(const float* user_tab, const float* it
     return (unsigned)(want < 1 ? 1 : (want > 65536 ? 65536 : want));
   };
 #define GCR_SIDE(SIDE, NV, KEYS, PERM, NE, OUT)                                                                       \
-  hipLaunchKernelGGL((bpr_bwd_sorted_kernel<SIDE, NV>), dim3(blocks_for(NE)), dim3(256), 0, s, user_tab, item_tab, d, \
-                     u_idx, i_idx, j_idx, batch, n_neg, n_users, n_items, dloss_dx, grad_sums, KEYS, PERM, NE, OUT)
+  if (n_neg == 1)                                                                                                     \
+    hipLaunchKernelGGL((bpr_bwd_sorted_kernel<SIDE, NV, true>), dim3(blocks_for(NE)), dim3(256), 0, s, user_tab,       \
+                       item_tab, d, u_idx, i_idx, j_idx, batch, n_neg, n_users, n_items, dloss_dx, grad_sums, KEYS,    \
+                       PERM, NE, OUT);                                                                                 \
+  else                                                                                                                \
+    hipLaunchKernelGGL((bpr_bwd_sorted_kernel<SIDE, NV, false>), dim3(blocks_for(NE)), dim3(256), 0, s, user_tab,      \
+                       item_tab, d, u_idx, i_idx, j_idx, batch, n_neg, n_users, n_items, dloss_dx, grad_sums, KEYS,    \
+                       PERM, NE, OUT)
 #define GCR_ALL(NV)                                           \
   GCR_SIDE(0, NV, keys_u, perm_u, batch, grad_user);          \
   GCR_SIDE(1, NV, keys_i, perm_i, batch, grad_item);          \

@@ -36,6 +36,9 @@ with torch.no_grad():
     final = Fn.lightgcn_propagate(graph, x, 3, "sum")
     print("propagate fwd      %.2f ms" % timeit(lambda: Fn.lightgcn_propagate(graph, x, 3, "sum")))
     print("bpr fwd            %.2f ms" % timeit(lambda: Fn.bpr_sums(final[:n_u], final[n_u:], users, items, neg, Fn.BPR_LOG_SIGMOID)))
-print("whole step (edges in generation order)   %.2f ms" % timeit(lambda: step(users, items, neg)))
 o = torch.argsort(users)
-print("whole step (edges sorted by user)         %.2f ms" % timeit(lambda: step(users[o], items[o], neg[o])))
+us, its, ns = users[o].contiguous(), items[o].contiguous(), neg[o].contiguous()
+if os.environ.get("ONLY") != "sorted":
+    print("whole step (edges in generation order)   %.2f ms" % timeit(lambda: step(users, items, neg)))
+if os.environ.get("ONLY") != "random":
+    print("whole step (edges sorted by user)         %.2f ms" % timeit(lambda: step(us, its, ns)))

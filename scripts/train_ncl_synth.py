@@ -10,7 +10,6 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import oracle_np as O   # synthetic graph generator only (test / bench infrastructure)
 from recommendation_amd.ncl import NCLModel
 
 n_u, n_i, n_e, epochs = (int(v) for v in (sys.argv[1:5] + ["200000", "20000", "2000000", "1"][len(sys.argv) - 1:]))

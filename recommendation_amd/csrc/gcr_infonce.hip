@@ -838,6 +838,130 @@ __global__ __launch_bounds__(256, 2) void infonce_fwd_h2_kernel(const float* __r
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Experimental forward of the bf16 split on the 16x16x32 MFMA shape (GCR_INFONCE_MFMA=16; measurement
+// only).  Same LDS image, same planes and terms; a wave still covers 64 anchors x 32 table rows per tile, as
+// 4 x 2 accumulator tiles of 16 x 16: lane (n = lane & 15, g = lane >> 4) holds anchor n of each of the four
+// anchor sub-tiles and table rows 4g .. 4g+3 of each 16-row half; K is split over the four lane groups
+// (group g owns features [g d/4, (g+1) d/4)).  MI355X_MICROARCH.md measures a higher sustained clock for this
+// shape under load.
+// ------------------------------------------------------------------------------------------
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4v mfma16_bf16(u32x4 a, u32x4 b, f32x4v c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void infonce_fwd_b3m16_kernel(const float* __restrict__ a,
+                                                                   const float* __restrict__ a_scale, int64_t m_rows,
+                                                                   const float* __restrict__ b,
+                                                                   const float* __restrict__ b_scale, int64_t n_rows,
+                                                                   float scale2, int nsplit, int64_t tiles_per_split,
+                                                                   float2* __restrict__ part) {
+  using S = ShapeB3<D>;
+  constexpr int KG = D / 4, KC = KG / 8;                       // features per lane group, 8-feature chunks of them
+  __shared__ __align__(16) unsigned char lds[2][3 * S::PLANE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n16 = lane & 15, g = lane >> 4;
+  const int64_t mblk = blockIdx.x / nsplit;
+  const int split = blockIdx.x % nsplit;
+  const int64_t i0 = (mblk * 4 + wave) * 64;
+  u32x4 bq[4][3][KC];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int64_t row = i0 + 16 * t + n16;
+    const bool valid = row < m_rows;
+    const float sc = valid ? (a_scale != nullptr ? a_scale[row] : 1.0f) * scale2 : 0.f;
+    const float* p = a + (valid ? row : 0) * D + g * KG;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      const float4 v0 = valid ? *reinterpret_cast<const float4*>(p + 8 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 v1 = valid ? *reinterpret_cast<const float4*>(p + 8 * c + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      unsigned q[3][4];
+      split3(v0.x * sc, v0.y * sc, q[0][0], q[1][0], q[2][0]);
+      split3(v0.z * sc, v0.w * sc, q[0][1], q[1][1], q[2][1]);
+      split3(v1.x * sc, v1.y * sc, q[0][2], q[1][2], q[2][2]);
+      split3(v1.z * sc, v1.w * sc, q[0][3], q[1][3], q[2][3]);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) bq[t][pl][c] = (u32x4){q[pl][0], q[pl][1], q[pl][2], q[pl][3]};
+    }
+  }
+  float m_run[4], l_run[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    m_run[t] = kNegBig;
+    l_run[t] = 0.f;
+  }
+  const int64_t total_tiles = (n_rows + kTileJ - 1) / kTileJ;
+  const int64_t tile0 = (int64_t)split * tiles_per_split;
+  const int64_t tile1 = min(total_tiles, tile0 + tiles_per_split);
+  float4 regs[S::NLD];
+  if (tile0 < tile1) {
+    stage_load<D>(b, b_scale, n_rows, tile0 * kTileJ, tid, regs);
+    stage_store_b3<D>(lds[0], tid, regs);
+  }
+  __syncthreads();
+  constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+  for (int64_t tt = tile0; tt < tile1; ++tt) {
+    const int cur = (int)((tt - tile0) & 1);
+    const int64_t nxt = tt + 1 < tile1 ? tt + 1 : tt;
+    stage_load<D>(b, b_scale, n_rows, nxt * kTileJ, tid, regs);
+    f32x4v acc[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int rs = 0; rs < 2; ++rs) acc[t][rs] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int rs = 0; rs < 2; ++rs) {
+      const unsigned char* base = lds[cur] + (16 * rs + n16) * S::ROWB + g * (KG * 2);
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        u32x4 ap[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) ap[pl] = *reinterpret_cast<const u32x4*>(base + pl * S::PLANE + 16 * c);
+#pragma unroll
+        for (int term = 0; term < 6; ++term)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[t][rs] = mfma16_bf16(ap[TA[term]], bq[t][TB[term]][c], acc[t][rs]);
+      }
+    }
+    const int64_t rem = n_rows - tt * kTileJ;                  // rows of this tile that exist
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float v[8];
+#pragma unroll
+      for (int rs = 0; rs < 2; ++rs)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[4 * rs + r] = (16 * rs + 4 * g + r < rem) ? acc[t][rs][r] : -INFINITY;
+      float tmax = v[0];
+#pragma unroll
+      for (int r = 1; r < 8; ++r) tmax = fmaxf(tmax, v[r]);
+      const float m_new = fmaxf(m_run[t], tmax);
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) sum += __builtin_amdgcn_exp2f(v[r] - m_new);
+      l_run[t] = l_run[t] * __builtin_amdgcn_exp2f(m_run[t] - m_new) + sum;
+      m_run[t] = m_new;
+    }
+    stage_store_b3<D>(lds[cur ^ 1], tid, regs);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    float m = m_run[t], l = l_run[t];
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {                  // merge the four lane groups
+      const float m_o = __shfl_xor(m, off, 64), l_o = __shfl_xor(l, off, 64);
+      const float mm = fmaxf(m, m_o);
+      l = l * __builtin_amdgcn_exp2f(m - mm) + l_o * __builtin_amdgcn_exp2f(m_o - mm);
+      m = mm;
+    }
+    const int64_t row = i0 + 16 * t + n16;
+    if (g == 0 && row < m_rows) part[(int64_t)split * m_rows + row] = make_float2(m, l);
+  }
+}
+
 // engine selection: GCR_INFONCE_ENGINE = f32 | b3 (read per call so that A/B rounds interleave
 // in-process); d = 256 stays on the f32 engine (its three operand planes would not fit the registers)
 // Default: b3 for d <= 128, where forward AND backward have it (the backward must recompute the
@@ -1726,6 +1850,17 @@ int32_t launch_fwd(const float* a, const float* a_scale, int64_t m, const float*
 #define GCR_B3(CS, PP)                                                                                              \
   hipLaunchKernelGGL((infonce_fwd_b3_kernel<D, CS, PP>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale, n,       \
                      inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part, col_sum, cb2)
+      const char* me = getenv("GCR_INFONCE_MFMA");    // measurement knob: the 16x16x32 shape
+      if constexpr (D == 64 || D == 32) {
+        if (me != nullptr && me[0] == '1' && me[1] == '6' && !exd && col_sum == nullptr) {
+          hipLaunchKernelGGL((infonce_fwd_b3m16_kernel<D>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale, n,
+                             inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part);
+          int32_t st16 = GCR_LAUNCH_STATUS();
+          if (st16 != GCR_OK) return st16;
+          hipLaunchKernelGGL(infonce_merge_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, part, p.nsplit, m, lse);
+          return GCR_LAUNCH_STATUS();
+        }
+      }
       if (exd) {
         hipLaunchKernelGGL((infonce_fwd_b3_kernel<D, false, true, true>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale,
                            n, inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part, col_sum, cb2);

@@ -18,7 +18,7 @@ def once(fn, reps):
 
 
 g = torch.Generator(device="cuda").manual_seed(0)
-shapes = [(2048, 1_000_000, 64), (100_000, 100_000, 64), (2048, 1_000_000, 128), (2048, 100_000, 32)]
+shapes = [(2048, 1_000_000, 64), (100_000, 100_000, 64), (2048, 100_000, 32)]
 for (m, n, d) in shapes:
     a = torch.randn(m, d, device="cuda", generator=g)
     b = torch.randn(n, d, device="cuda", generator=g)
@@ -34,12 +34,13 @@ for (m, n, d) in shapes:
             bn = b[j0:j0 + 250_000].double() * sb[j0:j0 + 250_000].double()[:, None]
             chunks.append(torch.logsumexp(an @ bn.T * inv_tau, 1))
         ref = torch.logsumexp(torch.stack(chunks, 1), 1)
-        variants = ("f32", "b3/1", "h2/1")
+        variants = ("b3/0", "b3/1", "b3/0/16")
         res, err = {v: [] for v in variants}, {}
         for rnd in range(5):
             for v in variants:
                 os.environ["GCR_INFONCE_ENGINE"] = v.split("/")[0]
-                os.environ["GCR_INFONCE_PIPE"] = v.split("/")[-1]
+                os.environ["GCR_INFONCE_PIPE"] = v.split("/")[1]
+                os.environ["GCR_INFONCE_MFMA"] = v.split("/")[2] if v.count("/") == 2 else "32"
                 if rnd == 0:
                     out = fn()
                     torch.cuda.synchronize()

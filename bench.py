@@ -94,6 +94,196 @@ def sym_norm_csr_device(users, items, n_users, n_items):
     return rowptr, col.to(torch.int32), val
 
 
+def _file_digest(paths, salt=""):
+    import hashlib
+    h = hashlib.sha256(salt.encode())
+    for rel in paths:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(rel.encode())
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def spmm_source_digest():
+    """Identifies the SpMM kernel + plan a PMC capture belongs to (the .git directory does not travel to
+    the GPU box, so the check is on source content, not on a commit id)."""
+    from recommendation_amd.graph import DEFAULT_NNZ_PER_PART
+    return _file_digest(["recommendation_amd/csrc/gcr_spmm.hip", "recommendation_amd/csrc/gcr_plan.cpp",
+                         "recommendation_amd/csrc/gcr_common.h"], salt=f"nnz_per_part={DEFAULT_NNZ_PER_PART}")
+
+
+def infonce_source_digest():
+    return _file_digest(["recommendation_amd/csrc/gcr_infonce.hip", "recommendation_amd/csrc/gcr_common.h"])
+
+
+def _committed_pmc(key, digest):
+    """Entry `key` of profiles/pmc_traffic.json, or None when there is none or it was captured on other
+    kernel sources than the ones being benchmarked (a stale constant is worse than null)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            ent = json.load(f).get(key)
+    except (OSError, ValueError):
+        return None
+    if not ent or ent.get("source_digest") != digest:
+        return None
+    return ent
+
+
+def _event_ms(fn, reps):
+    """Average device time of fn() in ms, HIP events on the stream the kernels are launched on (torch's
+    current stream is the one every gcr_* launch receives)."""
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def memory_probes(table, dev):
+    """Measured ceilings of this box's memory system (gcr_probe_*): float4 copy / read over 1 GiB buffers
+    (far past the 256 MiB Infinity Cache) and the 256-B row gather of the SpMM on `table` itself."""
+    from recommendation_amd import _lib
+    L = _lib.lib()
+    st = _lib.cur_stream(dev)
+    n = 1 << 28                                            # 1 GiB of floats
+    src = torch.empty(n, device=dev).normal_()
+    dst = torch.empty(n, device=dev)
+    sink = torch.zeros(1, device=dev)
+    t_copy = _event_ms(lambda: _lib.check(L.gcr_probe_copy_f32(_lib.dptr(src), _lib.dptr(dst), n, st), "probe_copy"), 10)
+    t_read = _event_ms(lambda: _lib.check(L.gcr_probe_read_f32(_lib.dptr(src), n, _lib.dptr(sink), st), "probe_read"), 10)
+    del src, dst
+    out = {"copy_GBs": round(2 * n * 4 / t_copy / 1e6, 1), "read_GBs": round(n * 4 / t_read / 1e6, 1),
+           "buffer_MiB": n * 4 >> 20}
+    rows = table.shape[0]
+    if table.shape[1] == 64:
+        n_idx = 1 << 24
+        idx = torch.randint(0, rows, (n_idx,), device=dev, dtype=torch.int32)
+        o = torch.empty(n_idx // 64, 64, device=dev)
+        t_g = _event_ms(lambda: _lib.check(L.gcr_probe_gather_rows_f32(_lib.dptr(table), rows, _lib.dptr(idx), n_idx,
+                                                                        _lib.dptr(o), st), "probe_gather"), 10)
+        out["gather_256B_rows_GBs"] = round((n_idx * 260 + o.numel() * 4) / t_g / 1e6, 1)
+        out["gather_table_MB"] = round(table.numel() * 4 / 1e6, 1)
+    return out
+
+
+def measure_propagation(ra, Fn, name, d, dev, steps, warmup):
+    """Builds workload `name` through the library ingest and times `steps` K-layer forward passes (the
+    Horner form, one launch per layer) with HIP events around every gcr_spmm_csr_f32 launch."""
+    wl = WORKLOADS[name]
+    n_u, n_i, n_e, k_layers = wl["users"], wl["items"], wl["edges"], wl["layers"]
+    n = n_u + n_i
+    t_build = time.time()
+    users, items = synth_interactions_device(n_u, n_i, n_e, SEED, dev)
+    # graph ingest through the library: gcr_coo_to_csr (radix sort + merge) + gcr_csr_sym_norm_f32
+    graph = ra.CsrGraph.bipartite_sym_norm(users, items, n_u, n_i, dev)
+    del users, items
+    nnz = graph.nnz
+    x0 = torch.empty(n, d, device=dev)
+    torch.nn.init.xavier_uniform_(x0, generator=torch.Generator(device=dev).manual_seed(0))
+    torch.cuda.synchronize()
+    t_build = time.time() - t_build
+
+    events = []
+    Fn.EVENT_SINK = None
+
+    def step():
+        with torch.no_grad():
+            return Fn.lightgcn_propagate(graph, x0, k_layers, combine="sum")
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    Fn.EVENT_SINK = events          # HIP events around every gcr_spmm_csr_f32 launch (same stream)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    Fn.EVENT_SINK = None
+
+    launch_ms = [a.elapsed_time(b) for a, b in events]
+    avg_launch_ms = sum(launch_ms) / len(launch_ms)
+    t_launch = avg_launch_ms * 1e-3
+    bytes_alg = nnz * (4 + 4 + 4 * d) + n * (4 * d + 4)      # BASELINE.md §4 / SURVEY §8d, per layer
+    bytes_comp = nnz * 8 + (n + 1) * 4 + 2 * n * 4 * d
+    achieved = bytes_alg / t_launch / 1e9
+    roofline = {
+        "bound": "hbm", "kernel": "spmm_parts + spmm_long_rows (one gcr_spmm_csr_f32 launch = one layer)",
+        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+        "traffic": None,
+        "frac_alg": round(achieved / HBM_PEAK_GBS, 4),
+        "frac_alg_note": "SURVEY §8d no-reuse byte model / launch time / 8 TB/s; it is cache-assisted (L2 and the "
+                         "Infinity Cache serve repeated gathers), so it may exceed the fabric rate and even 1.0 — "
+                         "frac_fabric is the counter-based figure",
+        "frac_fabric": None,
+        "frac_compulsory": round(bytes_comp / t_launch / 1e9 / HBM_PEAK_GBS, 4),
+        "bytes_alg_per_launch": bytes_alg, "avg_launch_ms": round(avg_launch_ms, 4),
+        "compulsory_bytes_per_launch": bytes_comp, "launches_timed": len(launch_ms),
+    }
+    # fabric traffic per launch from the committed rocprofv3 --pmc passes of the SAME workload and the same
+    # kernel sources (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, MI355X_MICROARCH.md §HBM); null otherwise
+    pmc = _committed_pmc(name, spmm_source_digest()) if d == 64 else None
+    if pmc:
+        roofline["traffic"] = pmc["bytes_per_launch"]
+        roofline["frac_fabric"] = round(pmc["bytes_per_launch"] / t_launch / 1e9 / HBM_PEAK_GBS, 4)
+        roofline["traffic_source"] = pmc["source"]
+        roofline["traffic_source_digest"] = pmc["source_digest"]
+    else:
+        roofline["traffic_note"] = "no committed PMC capture matches these kernel sources (digest %s)" % spmm_source_digest()
+    res = {"name": name, "graph": graph, "x0": x0, "nnz": nnz, "n": n, "n_u": n_u, "n_i": n_i, "n_e": n_e,
+           "k_layers": k_layers, "elapsed": elapsed, "ms_per_step": 1e3 * elapsed / steps,
+           "edges_per_s": nnz * k_layers * steps / elapsed, "roofline": roofline, "graph_build_s": round(t_build, 2)}
+    return res
+
+
+def infonce_roofline(Fn, x0, n_u, dev):
+    """Dominant InfoNCE kernel at the NCL structure-contrast shape (ncl.py:358-367): B = 2048 anchors against
+    all n_u layer-0 user rows, d = 64 — bare kernel launches (gcr_infonce_fwd_ex_f32 / gcr_infonce_bwd_ex_f32),
+    HIP events on the launch stream."""
+    d = x0.shape[1]
+    m = 2048
+    gen = torch.Generator(device=dev).manual_seed(11)
+    table = x0[:n_u].contiguous()
+    anchors = table[torch.randint(0, n_u, (m,), device=dev, generator=gen)] + \
+        0.1 * torch.randn(m, d, device=dev, generator=gen) * table.std()
+    sa, sb = Fn.row_inv_norm(anchors), Fn.row_inv_norm(table)
+    inv_tau = 10.0
+    lse = Fn.infonce_lse_raw(anchors, sa, table, sb, inv_tau, unit_rows=True)
+    w = torch.ones(m, device=dev)
+    t_f = _event_ms(lambda: Fn.infonce_lse_raw(anchors, sa, table, sb, inv_tau, unit_rows=True), 10)
+    t_b = _event_ms(lambda: Fn.infonce_bwd_pair_raw(anchors, sa, table, sb, inv_tau, lse, w, None, None, unit_rows=True), 5)
+    flops = 2.0 * m * n_u * d
+    from recommendation_amd import _lib
+    engine = int(_lib.lib().gcr_infonce_engine(d))
+    mult = 6 if engine == 1 else 1                       # bf16 split: six bf16 MFMA products per f32 product
+    peak = BF16_MFMA_PEAK_TF if engine == 1 else FP32_MFMA_PEAK_TF
+    out = {
+        "bound": "mfma", "kernel": "infonce_fwd_b3_kernel<64>" if engine == 1 else "infonce_fwd_kernel<64>",
+        "engine": "split-operand bf16 MFMA (3 planes per f32 operand, 6 products per f32 product, f32 accumulate)"
+                  if engine == 1 else "f32 MFMA",
+        "shape": f"{m} x {n_u} x {d}", "pairs_per_launch": m * n_u, "flops_alg_per_launch": flops,
+        "avg_launch_ms": round(t_f, 4), "pairs_per_s": m * n_u / t_f * 1e3,
+        "achieved_alg": round(flops / t_f / 1e9, 1), "achieved": round(mult * flops / t_f / 1e9, 1),
+        "peak": peak, "unit": "TFLOP/s", "frac": round(mult * flops / t_f / 1e9 / peak, 4),
+        "note": "achieved = MFMA flops issued (6 x algorithmic on the bf16 split) / launch time; peak = dense bf16 MFMA",
+        "mfma_busy_pct": None,
+        "bwd": {"kernel": "infonce_bwd2 (both input gradients from one recomputed score tile)",
+                "avg_launch_ms": round(t_b, 4), "flops_alg_per_launch": 3 * flops,
+                "achieved_alg": round(3 * flops / t_b / 1e9, 1), "achieved": round(mult * 3 * flops / t_b / 1e9, 1),
+                "frac": round(mult * 3 * flops / t_b / 1e9 / peak, 4), "mfma_busy_pct": None},
+    }
+    pmc = _committed_pmc("infonce", infonce_source_digest())
+    if pmc:
+        out["mfma_busy_pct"] = pmc.get("fwd_mfma_busy_pct")
+        out["bwd"]["mfma_busy_pct"] = pmc.get("bwd_mfma_busy_pct")
+        out["mfma_busy_source"] = pmc.get("source")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,8 +291,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--dim", type=int, default=64)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = a cfg2-sized user block per rank; strong = the fixed workload graph over N ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--no-cfg4", action="store_true", help="skip the 10M x 1M / 100M-edge 1-GPU companion line")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -124,64 +317,24 @@ def main():
         return main_sharded(args, rank, world, dev, ra)
 
     name = args.workload or "cfg2"
-    wl = WORKLOADS[name]
-    n_u, n_i, n_e, k_layers, d = wl["users"], wl["items"], wl["edges"], wl["layers"], args.dim
-    n = n_u + n_i
-    t_build = time.time()
-    users, items = synth_interactions_device(n_u, n_i, n_e, SEED, dev)
-    # graph ingest through the library: gcr_coo_to_csr (radix sort + merge) + gcr_csr_sym_norm_f32
-    graph = ra.CsrGraph.bipartite_sym_norm(users, items, n_u, n_i, dev)
-    del users, items
-    nnz = graph.nnz
-    x0 = torch.empty(n, d, device=dev)
-    torch.nn.init.xavier_uniform_(x0, generator=torch.Generator(device=dev).manual_seed(0))
-    torch.cuda.synchronize()
-    t_build = time.time() - t_build
-
-    events = []
-    Fn.EVENT_SINK = None
-
-    def step():
-        with torch.no_grad():
-            return Fn.lightgcn_propagate(graph, x0, k_layers, combine="sum")
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    Fn.EVENT_SINK = events          # HIP events around every gcr_spmm_csr_f32 launch (same stream)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    Fn.EVENT_SINK = None
-    elapsed = t1 - t0
-    ms_per_step = 1e3 * elapsed / args.steps
-    edges_per_s = nnz * k_layers * args.steps / elapsed
-
-    launch_ms = [a.elapsed_time(b) for a, b in events]
-    avg_launch_ms = sum(launch_ms) / len(launch_ms)
-    bytes_alg = nnz * (4 + 4 + 4 * d) + n * (4 * d + 4)      # BASELINE.md §4 / SURVEY §8d, per layer
-    achieved = bytes_alg / (avg_launch_ms * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "spmm_parts (gcr_spmm_csr_f32)", "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "bytes_alg_per_launch": bytes_alg, "avg_launch_ms": round(avg_launch_ms, 4),
-                "compulsory_bytes_per_launch": nnz * 8 + (n + 1) * 4 + 2 * n * 4 * d}
-
-    # HBM traffic per launch from the committed rocprofv3 --pmc passes of the same workload
-    # (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, MI355X_MICROARCH.md §HBM); null when not profiled
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            pmc = json.load(f).get(name)
-        if pmc and d == 64:
-            roofline["traffic"] = pmc["bytes_per_launch"]
-            roofline["traffic_source"] = pmc["source"]
-    except OSError:
-        pass
-
-    extra = {"graph_build_s": round(t_build, 2), "nnz": nnz, "n_nodes": n,
+    d = args.dim
+    r = measure_propagation(ra, Fn, name, d, dev, args.steps, args.warmup)
+    graph, x0, nnz, n, n_u, n_i, k_layers = r["graph"], r["x0"], r["nnz"], r["n"], r["n_u"], r["n_i"], r["k_layers"]
+    roofline = r["roofline"]
+    extra = {"graph_build_s": r["graph_build_s"], "nnz": nnz, "n_nodes": n,
              "spmm_parts": graph.plan.n_parts, "spmm_split_rows": graph.plan.n_long}
-    # the secondary rates and the CPU baseline must never cost the headline line
+    # everything below is secondary: it must never cost the headline line
+    try:
+        roofline["probe"] = memory_probes(x0, dev)
+    except Exception as e:      # noqa: BLE001
+        roofline["probe_error"] = repr(e)
+    infonce_pairs_per_s = None
+    if d == 64 and n_u >= 100000:
+        try:
+            roofline["infonce"] = infonce_roofline(Fn, x0, n_u, dev)
+            infonce_pairs_per_s = roofline["infonce"]["pairs_per_s"]
+        except Exception as e:      # noqa: BLE001
+            roofline["infonce_error"] = repr(e)
     if not args.no_extra:
         try:
             extra.update(bench_extra(ra, Fn, graph, x0, k_layers, nnz, dev, n_u, n_i))
@@ -191,19 +344,40 @@ def main():
     cpu = None
     if not args.no_cpu_baseline:
         try:
-            cpu = cpu_baseline(graph, x0, k_layers, nnz)
+            cpu = cpu_baseline(graph, x0, k_layers, nnz, n_u, n_i)
         except Exception as e:      # noqa: BLE001
             cpu = {"value": None, "unit": "edges/s", "cores": 0, "kind": "port", "sample": "failed: " + repr(e)}
 
+    # the graph the >= 60 % target is quoted on (10M x 1M / 100M interactions) fits one GPU (~6 GB): same timed
+    # step, its own roofline block
+    if name != "cfg4" and not args.no_cfg4 and d == 64:
+        try:
+            del graph, x0
+            r4 = measure_propagation(ra, Fn, "cfg4", d, dev, max(3, args.steps // 4), 2)
+            try:
+                r4["roofline"]["probe"] = memory_probes(r4["x0"], dev)
+            except Exception as e:      # noqa: BLE001
+                r4["roofline"]["probe_error"] = repr(e)
+            roofline["cfg4_graph"] = {
+                "workload": "cfg4 on 1 GPU: 10000000 users x 1000000 items / 100000000 interactions (nnz=%d), 3-layer "
+                            "d=64 forward" % r4["nnz"],
+                "edges_per_s": r4["edges_per_s"], "ms_per_step": r4["ms_per_step"], "graph_build_s": r4["graph_build_s"],
+                **r4["roofline"]}
+            del r4
+        except Exception as e:      # noqa: BLE001
+            roofline["cfg4_graph_error"] = repr(e)
+
     line = {
         "metric": "edges propagated/sec (LightGCN d=%d, %d-layer fwd message pass)" % (d, k_layers),
-        "value": edges_per_s, "unit": "edges/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": r["edges_per_s"], "unit": "edges/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{name}: LightGCN {k_layers}-layer d={d}, {n_u} users x {n_i} items / {n_e} "
+        "config": {"workload": f"{name}: LightGCN {k_layers}-layer d={d}, {n_u} users x {n_i} items / {r['n_e']} "
                                f"interactions (nnz={nnz}), sym-normalised CSR, forward propagation + fused layer sum",
-                   "users": n_u, "items": n_i, "interactions": n_e, "layers": k_layers, "dim": d},
-        "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
+                   "users": n_u, "items": n_i, "interactions": r["n_e"], "layers": k_layers, "dim": d},
+        "infonce_pairs_per_s": infonce_pairs_per_s,
+        "roofline": roofline, "roofline_infonce": roofline.get("infonce"), "cpu_baseline": cpu,
+        "dist_backend": None, "dist_world": 1, "extra": extra,
     }
     print(json.dumps(line))
 
@@ -354,7 +528,6 @@ def bench_extra(ra, Fn, graph, x0, k_layers, nnz, dev, n_u, n_i):
         "engine": "split-operand bf16 MFMA (3 planes per f32 operand, 6 terms per product, f32 accumulate)",
         "fwd_mfma_issued_tflops": round(6 * 2 * pairs * d / t_f / 1e12, 1),
         "fwd_frac_of_bf16_mfma_peak": round(6 * 2 * pairs * d / t_f / 1e12 / BF16_MFMA_PEAK_TF, 4),
-        "fwd_vs_fp32_mfma_peak": round(2 * pairs * d / t_f / 1e12 / FP32_MFMA_PEAK_TF, 4),
         "note": "fwd includes gathers, row norms, positive logits and the loss reductions; fwd_tflops counts the "
                 "algorithmic 2*M*N*d, the engine issues 6x that on the bf16 MFMA"}
     del xi, xc, ctx
@@ -423,9 +596,10 @@ def bench_extra(ra, Fn, graph, x0, k_layers, nnz, dev, n_u, n_i):
     return out
 
 
-def cpu_baseline(graph, x0, k_layers, nnz):
+def cpu_baseline(graph, x0, k_layers, nnz, n_u, n_i):
     """The C restatement of the reference path (oracle/oracle.c, OpenMP) on this box's host cores,
-    bounded to ~10-30 s: the same graph, the same K-layer propagation."""
+    bounded to ~10-30 s: the same graph, the same K-layer propagation; plus the other §8(d) legs
+    (the reference's dense contrast formulations and its Python sampler), each bounded to seconds."""
     from oracle import oracle_c
     rowptr = graph.rowptr_host
     col = graph.col.cpu().numpy()
@@ -442,10 +616,10 @@ def cpu_baseline(graph, x0, k_layers, nnz):
     out = {"value": nnz * k_layers * reps / spent, "unit": "edges/s", "cores": threads, "kind": "port",
            "sample": f"{reps} x full {k_layers}-layer CSR propagation of the same graph (oracle/oracle.c, "
                      f"OpenMP {threads} threads, fp32)"}
+    import numpy as np
     # the op the reference itself calls (stock PyTorch, ncl.py:203-209,419): torch.sparse.mm on the
     # uncoalesced COO tensor, one layer, timed on the same host cores (informative companion line)
     try:
-        import numpy as np
         rows = np.repeat(np.arange(rowptr.size - 1, dtype=np.int64), np.diff(rowptr))
         idx = torch.from_numpy(np.stack([rows, col.astype(np.int64)]))
         a_coo = torch.sparse_coo_tensor(idx, torch.from_numpy(val), (rowptr.size - 1, rowptr.size - 1))
@@ -456,8 +630,53 @@ def cpu_baseline(graph, x0, k_layers, nnz):
         dt = time.perf_counter() - t
         out["torch_sparse_mm_coo_edges_per_s"] = nnz / dt
         out["torch_threads"] = torch.get_num_threads()
+        del a_coo, idx, rows
     except Exception as e:  # informative only
         out["torch_sparse_mm_coo_error"] = str(e)[:100]
+    # SURVEY §8(d) legs 3 and 4: the reference's dense contrast formulations and Python sampler
+    legs = {}
+    try:
+        from oracle import cpu_legs
+        xt = torch.from_numpy(xh)
+        g = torch.Generator().manual_seed(5)
+        bsz = 2048
+        n_tab = min(n_u, 250_000)                 # 2048 x 250K logits = 2 GB materialised (the reference's way)
+        anchors = xt[torch.randint(0, n_u, (bsz,), generator=g)]
+        cpu_legs.ncl_structure_denominator(anchors[:64], xt[:n_tab], 0.1)
+        t = time.perf_counter()
+        cpu_legs.ncl_structure_denominator(anchors, xt[:n_tab], 0.1)
+        dt = time.perf_counter() - t
+        legs["ncl_structure_denominator"] = {
+            "pairs_per_s": bsz * n_tab / dt, "ms": 1e3 * dt, "threads": torch.get_num_threads(),
+            "sample": f"ncl.py:363-364 dense exp(A @ ALL^T / t).sum(1), {bsz} x {n_tab} (of {n_u} user rows), d={xt.shape[1]}, "
+                      "torch CPU f32; the full table scales linearly (extrapolated)"}
+        m = 8192
+        z1, z2 = xt[:m], xt[n_u:n_u + m] if n_i >= m else xt[m:2 * m]
+        cpu_legs.gcl_info_nce_loss(z1[:256], z2[:256])
+        t = time.perf_counter()
+        cpu_legs.gcl_info_nce_loss(z1, z2)
+        dt = time.perf_counter() - t
+        legs["gcl_info_nce_loss"] = {"pairs_per_s": m * m / dt, "ms": 1e3 * dt, "threads": torch.get_num_threads(),
+                                     "sample": f"gcl.py:28-35 dense symmetric InfoNCE, {m} x {m}, d={xt.shape[1]}, torch CPU f32"}
+        # Python rejection sampler at B = 2048 (ncl.py:91-114): one batch over this graph's users / items
+        ub = torch.randint(0, n_u, (bsz,), generator=g).tolist()
+        item_map = {i: i for i in range(n_i)}
+        tset, pairs = {}, []
+        for u in ub:
+            its = (col[rowptr[u]:rowptr[u + 1]] - n_u).tolist()
+            tset[u] = set(its)
+            pairs.append((u, its[0] if its else 0))
+        user_map = {u: u for u in tset}
+        import random
+        t = time.perf_counter()
+        batch = next(cpu_legs.python_pairwise_sampler(pairs, user_map, item_map, tset, bsz, random.Random(3)))
+        dt = time.perf_counter() - t
+        legs["python_sampler"] = {"samples_per_s": len(batch[2]) / dt, "ms_per_batch": 1e3 * dt, "threads": 1,
+                                  "sample": f"ncl.py:91-114 next_batch_pairwise, one batch of {bsz} over {n_i} items "
+                                            "(list(item keys) rebuilt per draw, as the reference does)"}
+    except Exception as e:  # noqa: BLE001
+        legs["error"] = repr(e)[:200]
+    out["legs"] = legs
     return out
 
 

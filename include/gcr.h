@@ -341,6 +341,20 @@ int64_t gcr_edge_mask_exact_workspace_bytes(int64_t nnz);
 int32_t gcr_edge_mask_exact_bits(int64_t nnz, int64_t n_keep, uint64_t seed, uint32_t* bits,
                                  void* workspace, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Memory-system probes (measurement aids for the roofline block of bench.py; SURVEY.md §8d asks for
+ * a device-copy bandwidth measured on the box next to the vendor peak).  16 B per lane.
+ * --------------------------------------------------------------------------------------------- */
+/* dst[i] = src[i]; n_floats a multiple of 4, both pointers 16-B aligned (reads n*4 B, writes n*4 B). */
+int32_t gcr_probe_copy_f32(const float* src, float* dst, int64_t n_floats, void* stream);
+/* streaming read of n_floats (multiple of 4) with an in-register reduction; sink is never written in practice. */
+int32_t gcr_probe_read_f32(const float* src, int64_t n_floats, float* sink, void* stream);
+/* out[k, :] = sum of the 64 table rows idx[64k .. 64k+63] (256-B rows, d = 64, 16 loads in flight per wave):
+ * the gather shape of gcr_spmm_csr_f32 without its CSR streams.  n_idx a multiple of 64; ids are clamped
+ * to [0, n_rows). out: [n_idx / 64, 64]. */
+int32_t gcr_probe_gather_rows_f32(const float* table, int64_t n_rows, const int32_t* idx, int64_t n_idx,
+                                  float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,4 +22,10 @@ for _ in range(3):
     lse, pl = Fn.infonce_stats(a, b, pos, 0.2)
     (lse - pl).sum().backward()
 torch.cuda.synchronize()
+import json  # noqa: E402
+import bench  # noqa: E402
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+with open(os.path.join(root, "gpurun_out", "pmc_probe_infonce.json"), "w") as f:
+    json.dump({"shape": f"{m} x {n} x {d}", "source_digest": bench.infonce_source_digest()}, f)
 print("infonce probe done: pairs per call", m * n, "flop per fwd call", 2 * m * n * d)

@@ -3,16 +3,21 @@
 MI355X_MICROARCH.md §HBM prescribes).  Dispatch order of spmm_parts:
   1..3   calibration: diagonal graph, N = 4M rows, d = 64 -> every byte is known
          (read x once = N*256 B + col/val/rowptr/desc, write y once = N*256 B)
-  4..9   cfg2 LightGCN layers (2 forward passes x 3 layers)   [--workload cfg4 for the big graph]
-Run e.g.:
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/prof/pmc_fetch -- python3 profiles/pmc_probe.py
+  4..    the bench's own timed step (bench.py: `lightgcn_propagate(graph, x0, K, combine="sum")`, the
+         Horner form), 2 forward passes x K layers, on the graph bench.py builds (library ingest)
+Usage (the program goes directly after `--`):
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/prof/pmc_fetch_cfg2 -- \
+      python3 profiles/pmc_probe.py --workload cfg2
+Writes gpurun_out/pmc_probe_<workload>.json (sizes + the digest of the kernel sources it ran).
 """
+import json
 import os
 import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 import recommendation_amd as ra  # noqa: E402
 from recommendation_amd import functional as Fn  # noqa: E402
@@ -30,17 +35,24 @@ yc = torch.empty_like(xc)
 for _ in range(3):
     Fn.spmm_into(gcal, xc, y=yc)
 torch.cuda.synchronize()
+cal_parts = gcal.plan.n_parts
 del xc, yc, gcal
 
 wl = bench.WORKLOADS[name]
 users, items = bench.synth_interactions_device(wl["users"], wl["items"], wl["edges"], bench.SEED, dev)
-rp, c, v = bench.sym_norm_csr_device(users, items, wl["users"], wl["items"])
+graph = ra.CsrGraph.bipartite_sym_norm(users, items, wl["users"], wl["items"], dev)
+del users, items
 n = wl["users"] + wl["items"]
-graph = ra.CsrGraph(rp, c, v, n, n, dev, symmetric=True)
 x0 = torch.empty(n, 64, device=dev)
 torch.nn.init.xavier_uniform_(x0, generator=torch.Generator(device=dev).manual_seed(0))
 with torch.no_grad():
     for _ in range(2):
         Fn.lightgcn_propagate(graph, x0, wl["layers"], combine="sum")
 torch.cuda.synchronize()
-print("probe done", name, "nnz", graph.nnz, "n", n, "cal_rows", n_cal)
+info = {"workload": name, "nnz": graph.nnz, "n": n, "layers": wl["layers"], "d": 64, "cal_rows": n_cal,
+        "cal_parts": cal_parts, "parts": graph.plan.n_parts, "long_rows": graph.plan.n_long,
+        "source_digest": bench.spmm_source_digest()}
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+with open(os.path.join(ROOT, "gpurun_out", f"pmc_probe_{name}.json"), "w") as f:
+    json.dump(info, f)
+print("probe done", json.dumps(info))

@@ -1,28 +1,43 @@
 #!/usr/bin/env python3
 """Turns the rocprofv3 CSV trees under gpurun_out/<dir>/ into the small, tracked summaries of this
-directory.  Usage: python profiles/summarize.py gpurun_out/prof5 r01
+directory.  Usage: python profiles/summarize.py gpurun_out/prof_r02 r02
 
-  <tag>_cfg2_kernel_stats.csv   top kernels of `bench.py` (kernel-trace --stats)
-  <tag>_cfg2_pmc_hbm.csv        FETCH_SIZE / WRITE_SIZE per spmm dispatch (separate --pmc passes of
-                                profiles/pmc_probe.py: 3 calibration launches, then 2 x 3 cfg2 layers)
-  pmc_traffic.json              per-launch HBM bytes bench.py reports as roofline.traffic
-  <tag>_infonce_kernel_stats.csv, <tag>_infonce_pmc_mfma.csv   profiles/infonce_probe.py
-  <tag>_ncl_step_kernel_stats.csv, <tag>_kmeans_kernel_stats.csv  profiles/ncl_step_probe.py, kmeans_probe.py
+  <dir>/kt[_cfg4]/                        bench.py under --kernel-trace --stats  -> <tag>_<wl>_kernel_stats.csv
+  <dir>/pmc_fetch_<wl>/, pmc_write_<wl>/  profiles/pmc_probe.py --workload <wl> under --pmc FETCH_SIZE / WRITE_SIZE
+                                          (separate passes) -> <tag>_<wl>_pmc_hbm.csv + pmc_traffic.json[<wl>]
+  <dir>/kt_nce/, pmc_nce/                 profiles/infonce_probe.py -> <tag>_infonce_kernel_stats.csv,
+                                          <tag>_infonce_pmc_mfma.csv + pmc_traffic.json["infonce"]
+  <dir>/kt_ncl/, kt_km/, kt_rank/         profiles/ncl_step_probe.py, kmeans_probe.py, rank_probe.py
+pmc_traffic.json entries carry the digest of the kernel sources the probe ran (written by the probe on the
+GPU box) and the git commit of the tree they were summarised in; bench.py attaches an entry only when the
+digest matches the sources it benchmarks.
 """
 import collections
 import csv
 import glob
 import json
 import os
+import subprocess
 import sys
 
 src, tag = sys.argv[1], sys.argv[2]
 here = os.path.dirname(os.path.abspath(__file__))
+root = os.path.dirname(here)
 
 
 def one(pattern):
     hits = glob.glob(os.path.join(src, pattern)) or glob.glob(os.path.join(src, pattern.replace("/*/", "/")))
     return hits[0] if hits else None
+
+
+def git_state():
+    try:
+        sha = subprocess.run(["git", "rev-parse", "HEAD"], cwd=root, capture_output=True, text=True).stdout.strip()
+        dirty = bool(subprocess.run(["git", "status", "--porcelain", "--", "recommendation_amd", "bench.py"], cwd=root,
+                                    capture_output=True, text=True).stdout.strip())
+        return sha, dirty
+    except OSError:
+        return None, None
 
 
 def stats(pattern, out, top=12):
@@ -36,15 +51,29 @@ def stats(pattern, out, top=12):
         w.writerow(cols)
         for r in rows[:top]:
             w.writerow([r["Name"][:150]] + [r[c] for c in cols[1:]])
+    print("wrote", out)
 
 
-stats("kt/*/*_kernel_stats.csv", f"{tag}_cfg2_kernel_stats.csv")
+stats("kt/*/*_kernel_stats.csv", f"{tag}_cfg2_kernel_stats.csv", top=16)
+stats("kt_cfg4/*/*_kernel_stats.csv", f"{tag}_cfg4_kernel_stats.csv")
 stats("kt_nce/*/*_kernel_stats.csv", f"{tag}_infonce_kernel_stats.csv", top=10)
 stats("kt_ncl/*/*_kernel_stats.csv", f"{tag}_ncl_step_kernel_stats.csv", top=16)      # profiles/ncl_step_probe.py
 stats("kt_km/*/*_kernel_stats.csv", f"{tag}_kmeans_kernel_stats.csv", top=6)           # profiles/kmeans_probe.py
+stats("kt_rank/*/*_kernel_stats.csv", f"{tag}_rank_kernel_stats.csv", top=6)           # profiles/rank_probe.py
 
-fetch, write = one("pmc_fetch/*/*_counter_collection.csv"), one("pmc_write/*/*_counter_collection.csv")
-if fetch and write:
+traffic_path = os.path.join(here, "pmc_traffic.json")
+try:
+    traffic = json.load(open(traffic_path))
+except (OSError, ValueError):
+    traffic = {}
+sha, dirty = git_state()
+
+for wl in ("cfg2", "cfg4"):
+    fetch, write = one(f"pmc_fetch_{wl}/*/*_counter_collection.csv"), one(f"pmc_write_{wl}/*/*_counter_collection.csv")
+    info_path = os.path.join(root, "gpurun_out", f"pmc_probe_{wl}.json")
+    if not (fetch and write and os.path.exists(info_path)):
+        continue
+    info = json.load(open(info_path))
     rows = []
     for kind, path in (("fetch", fetch), ("write", write)):
         k = 0
@@ -53,26 +82,36 @@ if fetch and write:
                 k += 1
                 name = "spmm_parts" if "spmm_parts" in r["Kernel_Name"] else "spmm_long_rows"
                 rows.append([kind, k, name, r["Grid_Size"], r["Counter_Name"], r["Counter_Value"]])
-    with open(os.path.join(here, f"{tag}_cfg2_pmc_hbm.csv"), "w") as f:
+    with open(os.path.join(here, f"{tag}_{wl}_pmc_hbm.csv"), "w") as f:
         w = csv.writer(f)
         w.writerow(["pass", "dispatch", "kernel", "grid", "counter", "value_KB"])
         w.writerows(rows)
     f_parts = [float(r[5]) for r in rows if r[0] == "fetch" and r[2] == "spmm_parts"]
     w_parts = [float(r[5]) for r in rows if r[0] == "write" and r[2] == "spmm_parts"]
+    f_long = [float(r[5]) for r in rows if r[0] == "fetch" and r[2] == "spmm_long_rows"]
+    w_long = [float(r[5]) for r in rows if r[0] == "write" and r[2] == "spmm_long_rows"]
     cal_f, lay_f, lay_w = f_parts[:3], f_parts[3:], w_parts[3:]
-    expected_read_kb = (4e6 * 256 + 4e6 * 8 + 4e6 * 8 + 4e6 / 512 * 32) / 1024
-    traffic = {"cfg2": {
-        "kernel": "spmm_parts", "fetch_size_kb_avg": sum(lay_f) / len(lay_f), "write_size_kb_avg": sum(lay_w) / len(lay_w),
-        "fetch_correction": 2.0,
-        "calibration": {"graph": "diagonal N=4M d=64", "expected_read_kb": expected_read_kb,
-                        "fetch_size_kb": sum(cal_f) / len(cal_f), "expected_write_kb": 4e6 * 256 / 1024,
-                        "write_size_kb": sum(w_parts[:3]) / 3},
-        "bytes_per_launch": (2.0 * sum(lay_f) / len(lay_f) + sum(lay_w) / len(lay_w)) * 1024,
-        "source": f"profiles/{tag}_cfg2_pmc_hbm.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
-                  "profiles/pmc_probe.py)"}}
-    json.dump(traffic, open(os.path.join(here, "pmc_traffic.json"), "w"), indent=1)
-    print("cfg2 HBM bytes per spmm_parts launch: %.3f GB (calibration ratio %.3f)" %
-          (traffic["cfg2"]["bytes_per_launch"] / 1e9, traffic["cfg2"]["calibration"]["fetch_size_kb"] / expected_read_kb))
+    nc = info["cal_rows"]
+    expected_read_kb = (nc * 256 + nc * 8 + nc * 8 + info["cal_parts"] * 32) / 1024
+    cal_ratio = (sum(cal_f) / len(cal_f)) / expected_read_kb
+    avg = lambda v: sum(v) / len(v) if v else 0.0        # noqa: E731
+    # one gcr_spmm_csr_f32 launch = spmm_parts + spmm_long_rows (the split rows' partial sums)
+    bytes_per_launch = (2.0 * (avg(lay_f) + avg(f_long)) + avg(lay_w) + avg(w_long)) * 1024
+    traffic[wl] = {
+        "kernel": "spmm_parts + spmm_long_rows (one gcr_spmm_csr_f32 launch, Horner layer: reads x0, writes one array)",
+        "fetch_size_kb_avg": avg(lay_f), "write_size_kb_avg": avg(lay_w),
+        "long_rows_fetch_kb_avg": avg(f_long), "long_rows_write_kb_avg": avg(w_long),
+        "fetch_correction": 2.0, "dispatches_averaged": len(lay_f),
+        "calibration": {"graph": "diagonal N=%d d=64" % nc, "expected_read_kb": expected_read_kb,
+                        "fetch_size_kb": avg(cal_f), "ratio": cal_ratio,
+                        "expected_write_kb": nc * 256 / 1024, "write_size_kb": avg(w_parts[:3])},
+        "bytes_per_launch": bytes_per_launch,
+        "nnz": info["nnz"], "n": info["n"],
+        "source_digest": info["source_digest"], "git_sha": sha, "git_dirty_at_summarise": dirty,
+        "source": f"profiles/{tag}_{wl}_pmc_hbm.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
+                  f"profiles/pmc_probe.py --workload {wl})"}
+    print("%s fabric bytes per launch: %.3f GB (calibration ratio %.3f, %d dispatches)" %
+          (wl, bytes_per_launch / 1e9, cal_ratio, len(lay_f)))
 
 pmc = one("pmc_nce/*/*_counter_collection.csv")
 if pmc:
@@ -82,18 +121,35 @@ if pmc:
         if "infonce_fwd" in k or "infonce_bwd" in k:
             name = k.split("::")[-1].split("(")[0]          # infonce_fwd_b3_kernel<64, false, true> ...
             agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    util = {}
     with open(os.path.join(here, f"{tag}_infonce_pmc_mfma.csv"), "w") as f:
         w = csv.writer(f)
         w.writerow(["kernel", "dispatches", "counter", "avg_value", "note"])
         for k, d in agg.items():
             for c, v in d.items():
                 w.writerow([k, len(v), c, sum(v) / len(v), ""])
+            if "SQ_VALU_MFMA_BUSY_CYCLES" not in d or "GRBM_GUI_ACTIVE" not in d:
+                continue
             busy = sum(d["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(d["SQ_VALU_MFMA_BUSY_CYCLES"])
             gui = sum(d["GRBM_GUI_ACTIVE"]) / len(d["GRBM_GUI_ACTIVE"])
-            util = 100 * busy / ((gui / 8) * 1024)
-            w.writerow([k, "", "MfmaUtil_percent", util, "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCDs * 1024 SIMDs)"])
-            print(k, "MfmaUtil %.1f%%" % util)
-bench = os.path.join(src, "bench_kt.json")
-if os.path.exists(bench):
-    with open(bench) as f, open(os.path.join(here, f"{tag}_bench_cfg2_under_rocprof.json"), "w") as g:
-        g.write(f.read())
+            util[k] = 100 * busy / ((gui / 8) * 1024)
+            w.writerow([k, "", "MfmaUtil_percent", util[k], "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCDs * 1024 SIMDs)"])
+            print(k, "MfmaUtil %.1f%%" % util[k])
+    info_path = os.path.join(root, "gpurun_out", "pmc_probe_infonce.json")
+    if util and os.path.exists(info_path):
+        info = json.load(open(info_path))
+        fwd = [v for k, v in util.items() if "infonce_fwd" in k]
+        bwd = [v for k, v in util.items() if "infonce_bwd" in k]
+        traffic["infonce"] = {
+            "fwd_mfma_busy_pct": round(max(fwd), 1) if fwd else None, "bwd_mfma_busy_pct": round(max(bwd), 1) if bwd else None,
+            "per_kernel": {k: round(v, 1) for k, v in util.items()}, "shape": info.get("shape"),
+            "source_digest": info["source_digest"], "git_sha": sha, "git_dirty_at_summarise": dirty,
+            "source": f"profiles/{tag}_infonce_pmc_mfma.csv (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE, "
+                      "profiles/infonce_probe.py)"}
+
+json.dump(traffic, open(traffic_path, "w"), indent=1)
+for name in ("bench_kt.json", "bench_cfg4_kt.json"):
+    path = os.path.join(src, name)
+    if os.path.exists(path):
+        with open(path) as f, open(os.path.join(here, f"{tag}_{name.replace('_kt', '_under_rocprof')}"), "w") as g:
+            g.write(f.read())

@@ -84,3 +84,75 @@ def test_cfg2_full_batch_bpr_and_sampler(cfg2):
     ref = C.bpr_loss(ut.cpu().numpy(), it.cpu().numpy(), users.cpu().numpy(), items.cpu().numpy(), neg.cpu().numpy(), 2)
     assert float(sums[0]) / users.numel() == pytest.approx(ref, rel=1e-5)
     assert float(sums[4]) == 0.0
+
+
+def test_cfg2_horner_sum_is_the_path_the_bench_times(cfg2):
+    """bench.py's timed call: `lightgcn_propagate(graph, x0, 3, combine="sum")` without layer outputs — the
+    Horner branch (y = NULL, acc_in = x0) — every element against the C oracle's sum of layers
+    (lightgcn.py:21-27)."""
+    from recommendation_amd import functional as Fn
+    g, x0 = cfg2["graph"], cfg2["x0"]
+    with torch.no_grad():
+        got = Fn.lightgcn_propagate(g, x0, 3, combine="sum")
+    ref = C.lightgcn_propagate(g.rowptr_host, g.col.cpu().numpy(), g.val.cpu().numpy(), x0.cpu().numpy(), 3, "sum")
+    assert np.abs(got.cpu().numpy() - ref).max() <= 1e-5 * np.abs(ref).max()
+    # the other branch computes the same thing
+    with torch.no_grad():
+        other, _ = Fn.lightgcn_propagate(g, x0, 3, combine="sum", return_layers=True)
+    assert float((other - got).abs().max()) <= 2e-6 * float(got.abs().max())
+
+
+@pytest.fixture(scope="module")
+def cfg4():
+    import bench
+    import recommendation_amd as ra
+    dev = torch.device("cuda", 0)
+    wl = bench.WORKLOADS["cfg4"]
+    users, items = bench.synth_interactions_device(wl["users"], wl["items"], wl["edges"], bench.SEED, dev)
+    graph = ra.CsrGraph.bipartite_sym_norm(users, items, wl["users"], wl["items"], dev)     # library ingest
+    del users, items
+    n = wl["users"] + wl["items"]
+    x0 = torch.empty(n, 64, device=dev)
+    torch.nn.init.xavier_uniform_(x0, generator=torch.Generator(device=dev).manual_seed(0))
+    yield dict(graph=graph, x0=x0, n_u=wl["users"], n_i=wl["items"])
+    del graph, x0
+    torch.cuda.empty_cache()
+
+
+def test_cfg4_graph_three_layer_propagation(cfg4):
+    """BASELINE configs[3]'s graph (10M users x 1M items / 100M interactions, nnz = 200M) on one GPU, the
+    bench's timed call: every output element against the C oracle (lightgcn.py:21-27 / ncl.py:415-422
+    arithmetic in fp32), plus the size-independent properties: linearity and the row-sum identity."""
+    from recommendation_amd import functional as Fn
+    g, x0 = cfg4["graph"], cfg4["x0"]
+    assert g.nnz == 200_000_000 and g.n_rows == 11_000_000
+    with torch.no_grad():
+        got = Fn.lightgcn_propagate(g, x0, 3, combine="sum")
+    col_h, val_h, x_h = g.col.cpu().numpy(), g.val.cpu().numpy(), x0.cpu().numpy()
+    ref = C.lightgcn_propagate(g.rowptr_host, col_h, val_h, x_h, 3, "sum")
+    got_h = got.cpu().numpy()
+    assert np.abs(got_h - ref).max() <= 1e-5 * np.abs(ref).max()
+    # ~4K sampled rows at per-row tolerance (small rows are not hidden behind the global maximum)
+    rs = np.random.default_rng(4).integers(0, g.n_rows, 4096)
+    denom = np.abs(ref[rs]).max(1, keepdims=True) + 1e-12
+    assert (np.abs(got_h[rs] - ref[rs]) / denom).max() <= 2e-5
+    del ref, got_h, col_h, val_h, x_h
+    # linearity: P(a x + b z) = a P(x) + b P(z)
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    z = torch.randn(x0.shape, device="cuda", generator=gen) * x0.std()
+    with torch.no_grad():
+        pz = Fn.lightgcn_propagate(g, z, 3, combine="sum")
+        mix = Fn.lightgcn_propagate(g, 0.5 * x0 - 2.0 * z, 3, combine="sum")
+    lin = 0.5 * got - 2.0 * pz
+    assert float((mix - lin).abs().max()) <= 2e-5 * float(lin.abs().max())
+    del z, pz, mix, lin
+    # row-sum identity: A 1 = rowsum(val), and the operator is symmetric: 1^T A x = rowsum^T x
+    rows = torch.repeat_interleave(torch.arange(g.n_rows, device="cuda"), g.rowptr[1:] - g.rowptr[:-1])
+    rowsum = torch.zeros(g.n_rows, device="cuda", dtype=torch.float64).index_add_(0, rows, g.val.double())
+    del rows
+    with torch.no_grad():
+        ones = Fn.spmm(g, torch.ones_like(x0))
+        ax = Fn.spmm(g, x0)
+    assert float((ones[:, 0].double() - rowsum).abs().max()) <= 1e-5 * float(rowsum.max())
+    lhs, rhs = ax.double().sum(0), (rowsum.unsqueeze(1) * x0.double()).sum(0)
+    assert float((lhs - rhs).abs().max()) <= 1e-6 * float((rowsum.unsqueeze(1) * x0.double().abs()).sum(0).max())

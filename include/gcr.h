@@ -47,7 +47,7 @@ int32_t gcr_spmm_plan_fill_host(const int64_t* rowptr_host, int64_t n_rows, int3
                                 int64_t* desc_host, int32_t* long_row_host, int32_t* long_slot0_host);
 
 /* flags for gcr_spmm_csr_f32 */
-#define GCR_SPMM_ROW_L2NORM 1u /* y <- y / max(||y||_2, 1e-12) per row (sept.py:224, mhcn.py:441-457) */
+#define GCR_SPMM_ROW_L2NORM 1u /* y <- y / max(||y||_2, 1e-12) per row (sept.py:224, sept_social.py:373-374) */
 
 /*
  * y = epilogue( val_scale * A[keep] x )            A: CSR [n_rows, n_cols], x: [n_cols, d]
@@ -70,6 +70,22 @@ int32_t gcr_spmm_csr_f32(const int64_t* desc, int64_t n_parts,
                          float* y, const float* acc_in, float* acc_out, float acc_scale,
                          uint32_t flags, float* inv_norm_out, float* partials,
                          int64_t n_rows, int64_t n_cols, void* stream);
+
+/*
+ * The same product with TWO outputs from one launch:
+ *   y_raw  = val_scale * A[keep] x                     (fed to the next layer)
+ *   y_norm = y_raw / max(||y_raw||_2, 1e-12) per row   (appended to the layer list)
+ * replaces  user_embeddings_c1 = torch.sparse.mm(self.H_s, user_embeddings_c1);
+ *           norm_embeddings_c1 = F.normalize(user_embeddings_c1, p=2, dim=1)     univariate/mhcn.py:440-457
+ * (SEPT feeds the NORMALISED rows forward, sept.py:223-224: that is gcr_spmm_csr_f32 with
+ * GCR_SPMM_ROW_L2NORM).  inv_norm_out (optional, [n_rows]) as above.  y_raw != y_norm.
+ */
+int32_t gcr_spmm_csr_dual_f32(const int64_t* desc, int64_t n_parts,
+                              const int32_t* long_row, const int32_t* long_slot0, int64_t n_long_rows,
+                              const int64_t* rowptr, const int32_t* col, const float* val,
+                              const uint32_t* keep_bits, float val_scale,
+                              const float* x, int32_t d, float* y_raw, float* y_norm, float* inv_norm_out,
+                              float* partials, int64_t n_rows, int64_t n_cols, void* stream);
 
 /* Counts structural errors of a CSR on the device (rowptr not monotone / not ending at nnz,
  * col outside [0, n_cols)); *n_errors_dev is a device int64 the caller zeroes and reads back. */

@@ -350,8 +350,251 @@ def gen_grace():
     print("wrote grace.npz", {k: float(v) for k, v in out.items() if k.startswith("loss_257_0.2")})
 
 
+def _lift_class_methods(path, class_name, method_names, extra_ns=None, top_level=()):
+    """Methods of one reference class (and optionally top-level defs) as a throw-away class whose
+    bodies are the reference's own AST nodes, executed unchanged (the module itself stops at an import of
+    an absent package: tensorflow / torch_geometric)."""
+    tree = ast.parse(open(path).read())
+    methods, tops = [], []
+    for node in tree.body:
+        if isinstance(node, ast.ClassDef) and node.name == class_name:
+            methods = [sub for sub in node.body if isinstance(sub, ast.FunctionDef) and sub.name in method_names]
+        if isinstance(node, (ast.FunctionDef, ast.ClassDef)) and node.name in top_level:
+            tops.append(node)
+    assert {m.name for m in methods} == set(method_names), (class_name, [m.name for m in methods])
+    import scipy.sparse as sp
+    ns = {"torch": torch, "F": F, "nn": torch.nn, "np": np, "sp": sp, "device": torch.device("cpu")}
+    ns.update(extra_ns or {})
+    exec(compile(ast.Module(body=tops, type_ignores=[]), path, "exec"), ns)
+    fn_ns = dict(ns)
+    exec(compile(ast.Module(body=methods, type_ignores=[]), path, "exec"), fn_ns)
+    cls = type("Lifted" + class_name, (), {m.name: fn_ns[m.name] for m in methods})
+    return cls, ns
+
+
+def _csr_dict(prefix, m):
+    m = m.tocsr().astype(np.float32)
+    m.sum_duplicates()
+    m.sort_indices()
+    return {f"{prefix}_indptr": m.indptr.astype(np.int64), f"{prefix}_indices": m.indices.astype(np.int64),
+            f"{prefix}_data": m.data.astype(np.float32), f"{prefix}_shape": np.array(m.shape, dtype=np.int64)}
+
+
+def gen_mhcn():
+    """tests/golden/mhcn.npz: univariate/mhcn.py's own MHCN.build_hyper_adj_mats (:340-368), the channel layer
+    loop of MHCN.forward (:422-478: raw product fed forward, normalised copy summed) with self_gating /
+    channel_attention (:404-420) and hierarchical_self_supervision (:480-506), lifted from the AST (the module
+    imports tensorflow, which is absent) and run unchanged on a seeded social + interaction graph.  The
+    torch.randperm draws of the self-supervision are recorded so that the test can replay them."""
+    import scipy.sparse as sp
+    path = os.path.join(REF, "univariate", "mhcn.py")
+    names = {"build_hyper_adj_mats", "self_gating", "self_supervised_gating", "channel_attention", "forward",
+             "hierarchical_self_supervision", "sparse_mx_to_torch_sparse_tensor"}
+    cls, ns = _lift_class_methods(path, "MHCN", names, top_level=("TFGraphInterface", "Graph"))
+    rng = np.random.default_rng(77)
+    n_u, n_i, d, n_layers = 60, 45, 64, 2
+    # directed social relations with a good share of reciprocal pairs, so that every motif has members
+    s_r, s_c = rng.integers(0, n_u, 420), rng.integers(0, n_u, 420)
+    keep = s_r != s_c
+    s_r, s_c = s_r[keep], s_c[keep]
+    s_r, s_c = np.concatenate([s_r, s_c[:150]]), np.concatenate([s_c, s_r[:150]])
+    pairs = np.unique(np.stack([s_r, s_c], 1), axis=0)
+    s_r, s_c = pairs[:, 0], pairs[:, 1]
+    S = sp.csr_matrix((np.ones(len(s_r), dtype=np.float32), (s_r, s_c)), shape=(n_u, n_u), dtype=np.float32)
+    y_r = np.concatenate([np.arange(n_u), rng.integers(0, n_u, 500)])
+    y_c = np.concatenate([rng.integers(0, n_i, n_u), rng.integers(0, n_i, 500)])
+    ypairs = np.unique(np.stack([y_r, y_c], 1), axis=0)
+    y_r, y_c = ypairs[:, 0], ypairs[:, 1]
+    Y = sp.csr_matrix((np.ones(len(y_r), dtype=np.float32), (y_r, y_c)), shape=(n_u, n_i), dtype=np.float32)
+
+    m = cls()
+    m.social_data = types.SimpleNamespace(get_social_mat=lambda: S)
+    m.data = types.SimpleNamespace(interaction_mat=Y, user_num=n_u, item_num=n_i)
+    H = m.build_hyper_adj_mats()
+    H = [sp.csr_matrix(h) for h in H]
+    R = ns["Graph"].normalize_graph_mat(Y)
+    g = torch.Generator().manual_seed(7)
+
+    def xav(*shape):
+        t = torch.empty(*shape)
+        torch.nn.init.xavier_uniform_(t, generator=g)
+        return t
+
+    m.n_layers, m.n_channel, m.emb_size, m.ss_rate = n_layers, 4, d, 0.01
+    m.user_embeddings = xav(n_u, d).requires_grad_(True)
+    m.item_embeddings = xav(n_i, d).requires_grad_(True)
+    m.gating_weights = {str(c + 1): xav(d, d) for c in range(4)}
+    m.gating_bias = {str(c + 1): 0.05 * torch.randn(1, d, generator=g) for c in range(4)}
+    m.sgating_weights = {str(c + 1): xav(d, d) for c in range(4)}
+    m.sgating_bias = {str(c + 1): 0.05 * torch.randn(1, d, generator=g) for c in range(4)}
+    m.attention = xav(1, d)
+    m.attention_mat = xav(d, d)
+    m.H_s, m.H_j, m.H_p = (m.sparse_mx_to_torch_sparse_tensor(h) for h in H)
+    m.R = m.sparse_mx_to_torch_sparse_tensor(R)
+
+    # record the permutations the self-supervision draws (torch.randperm(n, device=cpu))
+    perms = []
+    real_randperm = torch.randperm
+
+    def recording_randperm(n, **kw):
+        p = real_randperm(n, generator=g)
+        perms.append(p.numpy().copy())
+        return p
+
+    u_idx = torch.from_numpy(rng.integers(0, n_u, 32))
+    v_idx = torch.from_numpy(rng.integers(0, n_i, 32))
+    j_idx = torch.from_numpy(rng.integers(0, n_i, 32))
+    torch.randperm = recording_randperm
+    try:
+        bu, bp, bn, ss_loss, fu, fi = m.forward(u_idx, v_idx, j_idx)
+    finally:
+        torch.randperm = real_randperm
+    wu = torch.randn(n_u, d, generator=g)
+    wi = torch.randn(n_i, d, generator=g)
+    ((fu * wu).sum() + (fi * wi).sum() + ss_loss).backward()
+    out = {"S_row": s_r.astype(np.int64), "S_col": s_c.astype(np.int64), "Y_row": y_r.astype(np.int64),
+           "Y_col": y_c.astype(np.int64), "n_users": n_u, "n_items": n_i, "n_layers": n_layers, "ss_rate": 0.01,
+           "user_emb": m.user_embeddings.detach().numpy(), "item_emb": m.item_embeddings.detach().numpy(),
+           "attention": m.attention.numpy(), "attention_mat": m.attention_mat.numpy(),
+           "u_idx": u_idx.numpy(), "v_idx": v_idx.numpy(), "j_idx": j_idx.numpy(),
+           "perms": np.stack(perms), "wu": wu.numpy(), "wi": wi.numpy(),
+           "final_user": fu.detach().numpy(), "final_item": fi.detach().numpy(), "ss_loss": np.float32(ss_loss.item()),
+           "batch_user": bu.detach().numpy(), "batch_pos": bp.detach().numpy(), "batch_neg": bn.detach().numpy(),
+           "grad_user": m.user_embeddings.grad.numpy(), "grad_item": m.item_embeddings.grad.numpy()}
+    for c in range(4):
+        out[f"gw{c + 1}"], out[f"gb{c + 1}"] = m.gating_weights[str(c + 1)].numpy(), m.gating_bias[str(c + 1)].numpy()
+        out[f"sgw{c + 1}"], out[f"sgb{c + 1}"] = m.sgating_weights[str(c + 1)].numpy(), m.sgating_bias[str(c + 1)].numpy()
+    for name, h in zip(("H_s", "H_j", "H_p"), H):
+        out.update(_csr_dict(name, h))
+    out.update(_csr_dict("R", sp.csr_matrix(R)))
+    np.savez_compressed(os.path.join(OUT, "mhcn.npz"), **out)
+    print("wrote mhcn.npz: nnz", [h.nnz for h in H], "ss_loss", float(ss_loss), "perms", len(perms))
+
+
+def gen_sept_social():
+    """tests/golden/sept_social.npz: univariate/sept_social.py's SEPT.encoder / social_encoder (:370-385: SUM of the
+    row-normalised layers), get_social_related_views (:361-368), label_prediction / generate_pesudo_labels /
+    neighbor_discrimination (:393-420), lifted from the AST (the module imports tensorflow) and run unchanged."""
+    import scipy.sparse as sp
+    from scipy.sparse import eye
+    path = os.path.join(REF, "univariate", "sept_social.py")
+    names = {"encoder", "social_encoder", "get_social_related_views", "label_prediction", "sampling",
+             "generate_pesudo_labels", "neighbor_discrimination"}
+    cls, ns = _lift_class_methods(path, "SEPT", names, extra_ns={"eye": eye}, top_level=("TFGraphInterface", "Graph"))
+    rng = np.random.default_rng(99)
+    n_u, n_i, d, n_layers = 50, 40, 64, 2
+    s_r, s_c = rng.integers(0, n_u, 300), rng.integers(0, n_u, 300)
+    keep = s_r != s_c
+    s_r, s_c = s_r[keep], s_c[keep]
+    s_r, s_c = np.concatenate([s_r, s_c[:120]]), np.concatenate([s_c, s_r[:120]])
+    pairs = np.unique(np.stack([s_r, s_c], 1), axis=0)
+    s_r, s_c = pairs[:, 0], pairs[:, 1]
+    S = sp.csr_matrix((np.ones(len(s_r), dtype=np.float32), (s_r, s_c)), shape=(n_u, n_u), dtype=np.float32)
+    bi = S.multiply(S)                                   # Relation.get_birectional_social_mat (:141-144)
+    y_r = np.concatenate([np.arange(n_u), rng.integers(0, n_u, 400)])
+    y_c = np.concatenate([rng.integers(0, n_i, n_u), rng.integers(0, n_i, 400)])
+    ypairs = np.unique(np.stack([y_r, y_c], 1), axis=0)
+    y_r, y_c = ypairs[:, 0], ypairs[:, 1]
+    Y = sp.csr_matrix((np.ones(len(y_r), dtype=np.float32), (y_r, y_c)), shape=(n_u, n_i), dtype=np.float32)
+    n = n_u + n_i
+    adj = sp.bmat([[None, Y], [Y.T, None]], format="csr", dtype=np.float32)
+    norm_adj = ns["Graph"].normalize_graph_mat(adj)
+
+    m = cls()
+    m.data = types.SimpleNamespace(user_num=n_u, item_num=n_i)
+    m.social_data = types.SimpleNamespace(normalize_graph_mat=ns["Graph"].normalize_graph_mat)
+    m.instance_cnt = 5
+    social_mat, sharing_mat = m.get_social_related_views(bi, Y)
+    to_t = ns["TFGraphInterface"].convert_sparse_mat_to_tensor
+    g = torch.Generator().manual_seed(13)
+    ego = torch.empty(n, d)
+    torch.nn.init.xavier_uniform_(ego, generator=g)
+    ego.requires_grad_(True)
+    rec_u, rec_i = m.encoder(ego, to_t(norm_adj), n_layers)
+    wgt = torch.randn(n, d, generator=g)
+    (torch.cat([rec_u, rec_i]) * wgt).sum().backward()
+    enc_grad = ego.grad.clone()
+    users = ego.detach()[:n_u].clone().requires_grad_(True)
+    friend = m.social_encoder(users, to_t(social_mat), n_layers)
+    sharing = m.social_encoder(users, to_t(sharing_mat), n_layers)
+    u_idx = torch.from_numpy(rng.integers(0, n_u, 64))
+    m.aug_user_embeddings = (rec_u.detach() + 0.1 * torch.randn(n_u, d, generator=g))
+    social_pred = m.label_prediction(friend.detach(), u_idx)
+    sharing_pred = m.label_prediction(sharing.detach(), u_idx)
+    f_pos = m.generate_pesudo_labels(sharing_pred, social_pred)
+    emb_in = friend.detach().clone().requires_grad_(True)
+    loss = m.neighbor_discrimination(f_pos, emb_in, u_idx)
+    loss.backward()
+    out = {"n_users": n_u, "n_items": n_i, "n_layers": n_layers, "ego": ego.detach().numpy(), "w": wgt.numpy(),
+           "rec_user": rec_u.detach().numpy(), "rec_item": rec_i.detach().numpy(), "enc_grad": enc_grad.numpy(),
+           "friend_view": friend.detach().numpy(), "sharing_view": sharing.detach().numpy(),
+           "u_idx": u_idx.numpy(), "aug_user": m.aug_user_embeddings.numpy(), "positive": f_pos.numpy(),
+           "nd_loss": np.float32(loss.item()), "nd_grad": emb_in.grad.numpy(),
+           "S_row": s_r.astype(np.int64), "S_col": s_c.astype(np.int64),
+           "Y_row": y_r.astype(np.int64), "Y_col": y_c.astype(np.int64)}
+    out.update(_csr_dict("norm_adj", sp.csr_matrix(norm_adj)))
+    out.update(_csr_dict("social", sp.csr_matrix(social_mat)))
+    out.update(_csr_dict("sharing", sp.csr_matrix(sharing_mat)))
+    np.savez_compressed(os.path.join(OUT, "sept_social.npz"), **out)
+    print("wrote sept_social.npz: nd_loss", float(loss), "positives", tuple(f_pos.shape))
+
+
+def gen_buir():
+    """tests/golden/buir.npz: univariate/buir.py's LGCN_Encoder.sparse_dropout (:300-309) and the forward that
+    consumes it (:311-326), the module imported as-is; the Bernoulli draw (`torch.rand(nnz)`) is recorded so
+    that the test can hand the same keep mask to the HIP path."""
+    import buir
+    rng = np.random.default_rng(31)
+    train = seeded_triples(rng, 40, 30, 350, 0)
+    data = buir.Interaction({}, train, [])
+    d, n_layers, rate = 64, 2, 0.3
+    torch.manual_seed(17)
+    enc = buir.LGCN_Encoder(data, d, n_layers, rate, drop_flag=True)
+    adj = enc.sparse_norm_adj.coalesce() if not enc.sparse_norm_adj.is_coalesced() else enc.sparse_norm_adj
+    nnz = enc.sparse_norm_adj._nnz()
+    draws = []
+    real_rand = torch.rand
+
+    def recording_rand(*a, **kw):
+        r = real_rand(*a, **kw)
+        draws.append(r.numpy().copy())
+        return r
+
+    torch.rand = recording_rand
+    try:
+        dropped = enc.sparse_dropout(enc.sparse_norm_adj, rate, nnz)
+    finally:
+        torch.rand = real_rand
+    x = torch.cat([enc.embedding_dict["user_emb"], enc.embedding_dict["item_emb"]], 0).detach()
+    xr = x.clone().requires_grad_(True)
+    layers = [xr]
+    e = xr
+    for _ in range(n_layers):                      # buir.py:315-320 on the dropped operator
+        e = torch.sparse.mm(dropped, e)
+        layers.append(e)
+    final = torch.stack(layers, dim=1).mean(dim=1)
+    wgt = torch.randn(x.shape, generator=torch.Generator().manual_seed(3))
+    (final * wgt).sum().backward()
+    idx = enc.sparse_norm_adj._indices().numpy()
+    dc = dropped.coalesce()
+    np.savez_compressed(os.path.join(OUT, "buir.npz"), rate=rate, n_layers=n_layers, n_users=data.user_num,
+                        n_items=data.item_num, adj_row=idx[0].astype(np.int64), adj_col=idx[1].astype(np.int64),
+                        adj_val=enc.sparse_norm_adj._values().numpy(), rand=draws[0],
+                        keep=np.floor(1 - rate + draws[0]).astype(bool),
+                        dropped_row=dc.indices()[0].numpy(), dropped_col=dc.indices()[1].numpy(),
+                        dropped_val=dc.values().numpy(), x=x.numpy(), w=wgt.numpy(),
+                        final=final.detach().numpy(), grad=xr.grad.numpy())
+    print("wrote buir.npz: nnz", nnz, "kept", int(np.floor(1 - rate + draws[0]).sum()))
+
+
 if __name__ == "__main__":
-    if "--grace" in sys.argv:
+    if "--mhcn" in sys.argv:
+        gen_mhcn()
+    elif "--sept-social" in sys.argv:
+        gen_sept_social()
+    elif "--buir" in sys.argv:
+        gen_buir()
+    elif "--grace" in sys.argv:
         gen_grace()
     elif "--rownorm" in sys.argv:
         gen_rownorm()

@@ -555,3 +555,123 @@ def kmeans_lloyd(x, init_centroids, niter=20):
         nz = cnt > 0
         cent[nz] = sums[nz] / cnt[nz, None]
     return cent, assign(cent)
+
+
+# --------------------------------------------------------------------------
+# MHCN / sept_social / BUIR (univariate/): multi-channel layer loop, motif adjacency, dropout rescale
+# pinned by tests/golden/{mhcn,sept_social,buir}.npz (oracle/gen_golden.py --mhcn / --sept-social / --buir)
+# --------------------------------------------------------------------------
+
+
+def csr_to_dense(indptr, indices, data, shape):
+    out = np.zeros(tuple(int(s) for s in shape), dtype=F64)
+    rows = np.repeat(np.arange(len(indptr) - 1), np.diff(indptr))
+    np.add.at(out, (rows, np.asarray(indices)), np.asarray(data, dtype=F64))
+    return out
+
+
+def mhcn_motif_adjacency(S, Y):
+    """univariate/mhcn.py:340-368 `build_hyper_adj_mats` on dense 0/1 matrices S [U,U] (social, directed) and
+    Y [U,I] (interactions): the ten triangle-motif adjacencies A1..A10, then H_s = rownorm(A1+..+A7),
+    H_j = rownorm(A8+A9), H_p = rownorm(A10 * (A10 > 3)).  `*` is the element-wise product, `@` the matrix one."""
+    S, Y = np.asarray(S, dtype=F64), np.asarray(Y, dtype=F64)
+    B = S * S.T
+    U = S - B
+    C1 = (U @ U) * U.T
+    A1 = C1 + C1.T
+    C2 = (B @ U) * U.T + (U @ B) * U.T + (U @ U) * B
+    A2 = C2 + C2.T
+    C3 = (B @ B) * U + (B @ U) * B + (U @ B) * B
+    A3 = C3 + C3.T
+    A4 = (B @ B) * B
+    C5 = (U @ U) * U + (U @ U.T) * U + (U.T @ U) * U
+    A5 = C5 + C5.T
+    A6 = (U @ B) * U + (B @ U.T) * U.T + (U.T @ U) * B
+    A7 = (U.T @ B) * U.T + (B @ U) * U + (U @ U.T) * B
+    YY = Y @ Y.T
+    A8 = YY * B
+    A9 = YY * U
+    A9 = A9 + A9.T
+    A10 = YY - A8 - A9
+
+    def rownorm(h):
+        rs = h.sum(1, keepdims=True)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            out = h / rs
+        return np.where(h != 0, out, 0.0)        # scipy only touches stored non-zeros: empty rows stay empty
+
+    H_s = rownorm(A1 + A2 + A3 + A4 + A5 + A6 + A7)
+    H_j = rownorm(A8 + A9)
+    H_p = rownorm(A10 * (A10 > 3))
+    return H_s, H_j, H_p
+
+
+def _sigmoid64(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def mhcn_self_gating(em, w, b):
+    """mhcn.py:404-410: em * sigmoid(em @ W + b)."""
+    return em * _sigmoid64(em @ w + b)
+
+
+def mhcn_channel_attention(attention, attention_mat, *embs):
+    """mhcn.py:412-420: softmax over channels of sum(attention * (emb @ attention_mat), 1); mixed = sum_c score_c emb_c."""
+    w = np.stack([(attention * (e @ attention_mat)).sum(1) for e in embs])
+    w = w - w.max(0, keepdims=True)
+    score = np.exp(w) / np.exp(w).sum(0, keepdims=True)
+    return sum(score[c][:, None] * embs[c] for c in range(len(embs))), score
+
+
+def mhcn_layer_loop(H_s, H_j, H_p, R, user_emb, item_emb, gw, gb, attention, attention_mat, n_layers):
+    """mhcn.py:422-466 on dense operators: per layer the RAW products A x feed the next layer while their
+    row-normalised copies are appended and finally summed; items use R^T on the attention mix of the three
+    channels + simple/2, the simple channel uses R on the (raw) item embeddings."""
+    c = [mhcn_self_gating(user_emb, gw[k], gb[k]) for k in range(3)]
+    simple = mhcn_self_gating(user_emb, gw[3], gb[3])
+    items = np.asarray(item_emb, dtype=F64)
+    all_c = [[c[0]], [c[1]], [c[2]]]
+    all_simple, all_i = [simple], [items]
+    for _ in range(n_layers):
+        mixed, _ = mhcn_channel_attention(attention, attention_mat, *c)
+        mixed = mixed + simple / 2
+        for k, h in enumerate((H_s, H_j, H_p)):
+            c[k] = h @ c[k]
+            all_c[k].append(row_l2_normalize(c[k]))
+        new_items = R.T @ mixed
+        all_i.append(row_l2_normalize(new_items))
+        simple = R @ items
+        all_simple.append(row_l2_normalize(simple))
+        items = new_items
+    cs = [sum(a) for a in all_c]
+    final_user, _ = mhcn_channel_attention(attention, attention_mat, *cs)
+    final_user = final_user + sum(all_simple) / 2
+    return final_user, sum(all_i)
+
+
+def mhcn_hierarchical_self_supervision(em, adj, perms):
+    """mhcn.py:480-506 with the three torch.randperm draws passed in (row_shuffle, row_column_shuffle twice)."""
+    edge = adj @ em
+    score = lambda a, b: (a * b).sum(1)      # noqa: E731
+    pos = score(em, edge)
+    neg1 = score(em[perms[0]], edge)
+    neg2 = score(edge[perms[1]], em)
+    local = (-np.log(_sigmoid64(pos - neg1)) - np.log(_sigmoid64(neg1 - neg2))).sum()
+    graph = edge.mean(0, keepdims=True)
+    pos = score(edge, graph)
+    neg1 = score(edge[perms[2]], graph)
+    return (-np.log(_sigmoid64(pos - neg1))).sum() + local
+
+
+def neighbor_discrimination(positive, emb, aug_emb, temperature=0.1):
+    """univariate/sept_social.py:408-420 on the already selected rows: emb = emb[unique_u],
+    aug_emb = aug_user_embeddings[unique_u], positive int [B', k]."""
+    e, a = row_l2_normalize(emb), row_l2_normalize(aug_emb)
+    pos = (e[:, None, :] * a[np.asarray(positive)]).sum(2)
+    ttl = e @ a.T
+    return -np.log(np.exp(pos / temperature).sum(1) / np.exp(ttl / temperature).sum(1)).sum()
+
+
+def sparse_dropout_values(val, keep, rate):
+    """univariate/buir.py:300-309: kept non-zeros (dropout_mask = floor(1 - rate + rand)) times 1 / (1 - rate)."""
+    return np.asarray(val, dtype=F64) * np.asarray(keep, dtype=F64) * (1.0 / (1.0 - rate))

@@ -12,7 +12,15 @@ namespace {
 __global__ __launch_bounds__(256) void probe_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst,
                                                          int64_t n4) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {       // four 16-B loads in flight per lane before the stores
+    const float4 v0 = src[i], v1 = src[i + stride], v2 = src[i + 2 * stride], v3 = src[i + 3 * stride];
+    dst[i] = v0;
+    dst[i + stride] = v1;
+    dst[i + 2 * stride] = v2;
+    dst[i + 3 * stride] = v3;
+  }
+  for (; i < n4; i += stride) dst[i] = src[i];
 }
 
 __global__ __launch_bounds__(256) void probe_read_kernel(const float4* __restrict__ src, int64_t n4,

@@ -36,6 +36,7 @@ struct Epilogue {
   float acc_scale;
   uint32_t flags;
   float* inv_norm_out;
+  float* y_raw;          // second output under ROW_L2NORM: the product before the row normalise (mhcn.py:440-442)
 };
 
 template <int NV, bool D64>
@@ -44,6 +45,14 @@ __device__ __forceinline__ void store_row(const Epilogue& ep, int64_t row, int d
 #pragma unroll
   for (int v = 0; v < NV; ++v) yv[v] = acc[v] * ep.val_scale;
   if (ep.flags & GCR_SPMM_ROW_L2NORM) {
+    if (ep.y_raw != nullptr) {
+      const int64_t rb = row * (int64_t)d;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int c = lane + 64 * v;
+        if (D64 || c < d) ep.y_raw[rb + c] = yv[v];
+      }
+    }
     float ss = 0.f;
 #pragma unroll
     for (int v = 0; v < NV; ++v) ss = fmaf(yv[v], yv[v], ss);
@@ -284,7 +293,32 @@ extern "C" int32_t gcr_spmm_csr_f32(const int64_t* desc, int64_t n_parts, const 
   GCR_CHECK_ARG(y != nullptr || acc_out != nullptr);
   GCR_CHECK_ARG(n_long_rows == 0 || (long_row != nullptr && long_slot0 != nullptr && partials != nullptr));
   GCR_CHECK_ARG((flags & ~GCR_SPMM_ROW_L2NORM) == 0);
-  Epilogue ep{val_scale, y, acc_in, acc_out, acc_scale, flags, inv_norm_out};
+  Epilogue ep{val_scale, y, acc_in, acc_out, acc_scale, flags, inv_norm_out, nullptr};
+  hipStream_t s = (hipStream_t)stream;
+#define GCR_GO(NV, D64) \
+  return launch_spmm<NV, D64>(desc, n_parts, long_row, long_slot0, n_long_rows, rowptr, col, val, keep_bits, x, d, ep, partials, s)
+  if (d == 64) GCR_GO(1, true);
+  if (d <= 64) GCR_GO(1, false);
+  if (d <= 128) GCR_GO(2, false);
+  if (d <= 192) GCR_GO(3, false);
+  GCR_GO(4, false);
+#undef GCR_GO
+}
+
+extern "C" int32_t gcr_spmm_csr_dual_f32(const int64_t* desc, int64_t n_parts, const int32_t* long_row,
+                                         const int32_t* long_slot0, int64_t n_long_rows, const int64_t* rowptr,
+                                         const int32_t* col, const float* val, const uint32_t* keep_bits,
+                                         float val_scale, const float* x, int32_t d, float* y_raw, float* y_norm,
+                                         float* inv_norm_out, float* partials, int64_t n_rows, int64_t n_cols,
+                                         void* stream) {
+  GCR_CHECK_ARG(n_parts >= 0 && n_long_rows >= 0 && n_rows >= 0 && n_cols >= 0);
+  GCR_CHECK_ARG(n_parts < (1ll << 31) - 4 && n_rows < (1ll << 31) && n_cols < (1ll << 31));
+  GCR_CHECK_ARG(d >= 1 && d <= 256);
+  if (n_rows == 0 || n_parts == 0) return GCR_OK;
+  GCR_CHECK_ARG(desc != nullptr && rowptr != nullptr && x != nullptr && y_raw != nullptr && y_norm != nullptr);
+  GCR_CHECK_ARG(y_raw != y_norm);
+  GCR_CHECK_ARG(n_long_rows == 0 || (long_row != nullptr && long_slot0 != nullptr && partials != nullptr));
+  Epilogue ep{val_scale, y_norm, nullptr, nullptr, 1.0f, GCR_SPMM_ROW_L2NORM, inv_norm_out, y_raw};
   hipStream_t s = (hipStream_t)stream;
 #define GCR_GO(NV, D64) \
   return launch_spmm<NV, D64>(desc, n_parts, long_row, long_slot0, n_long_rows, rowptr, col, val, keep_bits, x, d, ep, partials, s)

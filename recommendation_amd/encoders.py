@@ -132,13 +132,17 @@ class LightGCN(nn.Module):
         return Fn.split_rows(x, nu)
 
 
-def sept_encoder(emb, adj: CsrGraph, n_layers: int):
-    """univariate/sept.py:220-226: emb_k = normalize(A emb_{k-1}) per layer, mean over K+1."""
-    all_embs, e = [emb], emb
+def sept_encoder(emb, adj: CsrGraph, n_layers: int, combine: str = "mean"):
+    """emb_k = normalize(A emb_{k-1}) per layer (the NORMALISED rows feed the next layer), then
+    combine='mean': univariate/sept.py:220-226; combine='sum': univariate/sept_social.py:370-385
+    (`encoder` on the bipartite operator, `social_encoder` on the U x U social / sharing views)."""
+    if combine not in ("mean", "sum"):
+        raise ValueError("combine must be 'mean' or 'sum'")
+    acc, e = emb, emb
     for _ in range(n_layers):
         e = Fn.spmm_l2norm(adj, e)
-        all_embs.append(e)
-    return torch.stack(all_embs, dim=0).mean(0)
+        acc = acc + e
+    return acc / (n_layers + 1) if combine == "mean" else acc
 
 
 def load_data(train_path, test_path, device=None):
@@ -164,22 +168,31 @@ def multi_stream_spmm(graphs, xs, streams=None, l2norm=False):
     """BASELINE config 5 (univariate/mhcn.py:440-456): the per-layer SpMMs over independent operators
     (H_s, H_j, H_p, R^T, R) launched on separate HIP streams so that they fill the chip together and
     can hide each other's tails / a concurrent all-gather.  Returns the outputs in order; the caller's
-    current stream waits for all of them (event join).  Autograd-aware (each op is `spmm` /
-    `spmm_l2norm`)."""
+    current stream waits for all of them (event join).  Autograd-aware.
+
+    l2norm: False -> A x (`spmm`); True -> normalize(A x) only (SEPT-style, `spmm_l2norm`);
+    "dual" -> the pair (A x, normalize(A x)) per operator (`spmm_l2norm_dual`) — what MHCN's layer loop
+    needs: mhcn.py:440-442 feeds the RAW product to the next layer and appends the normalised copy to
+    the layer list.  A per-operator sequence of those values is accepted too."""
     cur = torch.cuda.current_stream()
     if streams is None:
         streams = [torch.cuda.Stream() for _ in graphs]
+    modes = list(l2norm) if isinstance(l2norm, (list, tuple)) else [l2norm] * len(graphs)
     start = torch.cuda.Event()
     start.record(cur)
     outs = []
-    for g, x, s in zip(graphs, xs, streams):
+    for g, x, s, mode in zip(graphs, xs, streams, modes):
         s.wait_event(start)
         with torch.cuda.stream(s):
-            outs.append(Fn.spmm_l2norm(g, x) if l2norm else Fn.spmm(g, x))
+            if mode == "dual":
+                outs.append(Fn.spmm_l2norm_dual(g, x))
+            else:
+                outs.append(Fn.spmm_l2norm(g, x) if mode else Fn.spmm(g, x))
             x.record_stream(s)
     for s, o in zip(streams, outs):
         done = torch.cuda.Event()
         done.record(s)
         cur.wait_event(done)
-        o.record_stream(cur)
+        for t in (o if isinstance(o, tuple) else (o,)):
+            t.record_stream(cur)
     return outs

@@ -78,16 +78,43 @@ class _SpMM(torch.autograd.Function):
         return dx, None, None, None, None
 
 
-def spmm(graph: CsrGraph, x, keep_bits=None, keep_bits_t=None, val_scale=1.0):
+def spmm(graph: CsrGraph, x, keep_bits=None, keep_bits_t=None, val_scale=1.0, mask_symmetric=False):
     """Drop-in for `torch.sparse.mm(A, x)` (ncl.py:419 and the 13 other call sites of SURVEY §2.3
     S1), differentiable w.r.t. x: backward is the same kernel on A^T.  `keep_bits` is an edge-
-    dropout bitmap in A's non-zero order, `keep_bits_t` the same mask in A^T's order (only
-    needed for backward through an asymmetric graph / mask)."""
-    if keep_bits is not None and keep_bits_t is None and graph.symmetric is False and x.requires_grad:
-        raise ValueError("backward through a masked asymmetric graph needs keep_bits_t")
+    dropout bitmap in A's non-zero order, `keep_bits_t` the SAME mask in A^T's non-zero order.
+
+    The backward computes (A o M)^T dy, so it needs the transposed mask even when A itself is
+    symmetric: gcl.py:22-25 / buir.py:300-309 draw every stored (directed) non-zero independently, so
+    M is not symmetric although A is.  For a symmetric graph `graph.mirror_perm()` maps each
+    non-zero (r, c) to the position of (c, r): `edge_mask_bits(nnz, pe, seed, dev, edge_id=mirror)`
+    (or `mirror_bits`) is the transposed mask.  Pass mask_symmetric=True only when (r, c) and (c, r)
+    really share one draw (an undirected-edge mask); then keep_bits serves both directions."""
     if keep_bits is not None and keep_bits_t is None:
-        keep_bits_t = keep_bits
+        if mask_symmetric and graph.symmetric:
+            keep_bits_t = keep_bits
+        elif x.requires_grad and torch.is_grad_enabled():
+            raise ValueError("backward through a masked graph needs keep_bits_t (the mask in A^T's non-zero order); "
+                             "for a symmetric graph build it with graph.mirror_perm(), or pass mask_symmetric=True "
+                             "if the mask itself is symmetric")
     return _SpMM.apply(x, graph, keep_bits, keep_bits_t, float(val_scale))
+
+
+def mirror_bits(keep_bits, mirror, nnz):
+    """The bitmap `keep_bits` re-ordered by `mirror` (int64 [nnz]): bit e of the result = bit mirror[e] of
+    the input — the transposed mask of a symmetric graph for masks that are not functions of a counter
+    (e.g. a recorded draw).  Small one-off index plumbing (torch)."""
+    shifts = torch.arange(32, device=keep_bits.device, dtype=torch.int32)
+    flat = ((keep_bits.unsqueeze(1) >> shifts) & 1).reshape(-1)[:nnz]
+    return pack_bits(flat[mirror].bool())
+
+
+def pack_bits(keep_bool):
+    """bool [nnz] -> little-endian int32 bitmap (bit e of word e // 32)."""
+    n = keep_bool.numel()
+    pad = (-n) % 32
+    b = torch.cat([keep_bool.to(torch.int64), torch.zeros(pad, dtype=torch.int64, device=keep_bool.device)]).view(-1, 32)
+    w = (b << torch.arange(32, device=b.device, dtype=torch.int64)).sum(1)
+    return (w & 0xFFFFFFFF).to(torch.int64).where(w < 2 ** 31, w - 2 ** 32).to(torch.int32)
 
 
 class _Propagate(torch.autograd.Function):
@@ -161,7 +188,7 @@ def lightgcn_propagate(graph: CsrGraph, x0, n_layers: int, combine: str = "mean"
 
 
 class _NormProp(torch.autograd.Function):
-    """One SEPT/MHCN layer: y = normalize(A x) row-wise (sept.py:223-224); saves y and 1/||Ax||."""
+    """One SEPT layer: y = normalize(A x) row-wise (sept.py:223-224); saves y and 1/||Ax||."""
 
     @staticmethod
     def forward(ctx, x, graph):
@@ -184,9 +211,73 @@ class _NormProp(torch.autograd.Function):
 
 
 def spmm_l2norm(graph: CsrGraph, x):
-    """`F.normalize(torch.sparse.mm(adj, emb), dim=1)` (sept.py:223-224, mhcn.py:440-457) in one kernel."""
+    """`F.normalize(torch.sparse.mm(adj, emb), dim=1)` in one kernel, for encoders that feed the NORMALISED
+    rows to the next layer (sept.py:223-224, sept_social.py:373-374,382-383).  MHCN feeds the raw product
+    forward and only keeps the normalised copy: use `spmm_l2norm_dual` there."""
     _lib.require_cuda(x)
     return _NormProp.apply(x, graph)
+
+
+def spmm_dual_into(graph: CsrGraph, x, y_raw, y_norm, inv_norm_out=None, keep_bits=None, val_scale=1.0):
+    """Raw launch of gcr_spmm_csr_dual_f32: y_raw = A x and y_norm = normalize(A x) from one pass."""
+    _lib.require_cuda(x, y_raw, y_norm, inv_norm_out, keep_bits)
+    x = x.contiguous()
+    _check_dense(x, graph.n_cols, "x")
+    d = x.shape[1]
+    for t, nm in ((y_raw, "y_raw"), (y_norm, "y_norm")):
+        _check_dense(t, graph.n_rows, nm)
+        if t.shape[1] != d or not t.is_contiguous():
+            raise ValueError(f"{nm} must be contiguous [{graph.n_rows}, {d}]")
+    if y_raw.data_ptr() == y_norm.data_ptr():
+        raise ValueError("y_raw and y_norm must be different buffers")
+    if keep_bits is not None and (keep_bits.dtype != torch.int32 or keep_bits.numel() * 32 < graph.nnz):
+        raise ValueError("keep_bits must be an int32 bitmap with >= nnz bits")
+    if inv_norm_out is not None and (inv_norm_out.dtype != torch.float32 or inv_norm_out.numel() != graph.n_rows):
+        raise ValueError("inv_norm_out must be float32 [n_rows]")
+    p = graph.plan
+    rc = _lib.lib().gcr_spmm_csr_dual_f32(
+        _lib.dptr(p.desc), p.n_parts, _lib.dptr(p.long_row), _lib.dptr(p.long_slot0), p.n_long,
+        _lib.dptr(graph.rowptr), _lib.dptr(graph.col), _lib.dptr(graph.val), _lib.dptr(keep_bits), float(val_scale),
+        _lib.dptr(x), d, _lib.dptr(y_raw), _lib.dptr(y_norm), _lib.dptr(inv_norm_out), _lib.dptr(graph.workspace(d)),
+        graph.n_rows, graph.n_cols, _lib.cur_stream(x.device))
+    _lib.check(rc, "gcr_spmm_csr_dual_f32")
+    return y_raw, y_norm
+
+
+class _NormPropDual(torch.autograd.Function):
+    """One MHCN channel layer: (z, n) = (A x, normalize(A x)) from one launch (univariate/mhcn.py:440-442:
+    the RAW product feeds the next layer, the normalised copy joins the layer list)."""
+
+    @staticmethod
+    def forward(ctx, x, graph):
+        z = torch.empty(graph.n_rows, x.shape[1], dtype=torch.float32, device=x.device)
+        n = torch.empty_like(z)
+        inv = torch.empty(graph.n_rows, dtype=torch.float32, device=x.device)
+        spmm_dual_into(graph, x, z, n, inv)
+        ctx.graph = graph
+        ctx.save_for_backward(n, inv)
+        return z, n
+
+    @staticmethod
+    def backward(ctx, gz, gn):
+        n, inv = ctx.saved_tensors
+        # dz = gz + (gn - n <n, gn>) / max(||z||, eps); rows clamped by eps have inv = 1e12 and n = 0
+        dz = None
+        if gn is not None:
+            dz = (gn - n * (n * gn).sum(1, keepdim=True)) * inv.unsqueeze(1)
+        if gz is not None:
+            dz = gz if dz is None else dz + gz
+        gt = ctx.graph.t
+        dx = torch.empty(gt.n_rows, dz.shape[1], dtype=torch.float32, device=dz.device)
+        spmm_into(gt, dz.contiguous(), y=dx)
+        return dx, None
+
+
+def spmm_l2norm_dual(graph: CsrGraph, x):
+    """(torch.sparse.mm(adj, emb), F.normalize(torch.sparse.mm(adj, emb), p=2, dim=1)) in one kernel —
+    the MHCN layer step (univariate/mhcn.py:440-457), differentiable w.r.t. x through both outputs."""
+    _lib.require_cuda(x)
+    return _NormPropDual.apply(x, graph)
 
 
 class _SplitRows(torch.autograd.Function):

@@ -124,6 +124,24 @@ class CsrGraph:
                                nnz_per_part=self.plan.nnz_per_part, validate=False, transpose=self)
         return self._t
 
+    def mirror_perm(self):
+        """Symmetric operators only: int64 [nnz], mirror[e] = position of the non-zero (c, r) for the non-zero
+        e = (r, c) — the nnz -> transpose-nnz map that lets a per-non-zero edge mask be handed to the
+        backward pass in A^T's order (`functional.spmm(keep_bits_t=...)`).  Duplicate pairs (the raw
+        multigraph of ncl.py:74-85) are matched copy by copy.  One-off index plumbing, cached."""
+        if not self.symmetric:
+            raise ValueError("mirror_perm() is for symmetric graphs; an asymmetric graph has graph.t.perm_from_transpose")
+        m = getattr(self, "_mirror", None)
+        if m is None:
+            rows = torch.repeat_interleave(torch.arange(self.n_rows, device=self.device), self.rowptr[1:] - self.rowptr[:-1])
+            cols = self.col.to(torch.int64)
+            by_rc = torch.argsort(rows * self.n_cols + cols, stable=True)     # k-th copy of (r, c)
+            by_cr = torch.argsort(cols * self.n_rows + rows, stable=True)     # k-th copy whose transpose is (r, c)
+            m = torch.empty_like(by_rc)
+            m[by_rc] = by_cr
+            self._mirror = m
+        return m
+
     # -- constructors ---------------------------------------------------------------------
     @classmethod
     def from_coo(cls, row, col, val, n_rows, n_cols, device, coalesce=False, symmetric=False, **kw):

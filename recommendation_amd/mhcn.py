@@ -1,0 +1,109 @@
+"""Host-side mirror of univariate/mhcn.py's multi-channel encoder (BASELINE config 5) on the HIP ops.
+
+  MHCNEncoder.propagate         mhcn.py:422-466  five SpMMs per layer over H_s, H_j, H_p [U x U], R^T [I x U],
+                                                 R [U x I]: the RAW product feeds the next layer, its row-
+                                                 normalised copy is appended and summed (gcr_spmm_csr_dual_f32),
+                                                 the five launches on separate HIP streams
+  hierarchical_self_supervision mhcn.py:480-506  edge embeddings = one more SpMM per channel
+  self_gating / channel_attention mhcn.py:404-420 dense [U, d] x [d, d] products: plain library GEMMs (torch)
+
+The operators are CsrGraph handles (graph.py); `build_hyper_graphs` makes them from the social and
+interaction lists (motif adjacency, mhcn.py:340-368, on the device: graph_ops.py).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import functional as Fn
+from .encoders import multi_stream_spmm
+from .graph import CsrGraph
+
+
+class MHCNEncoder(nn.Module):
+    """Parameters and forward of univariate/mhcn.py's MHCN (:370-478) with the reference's attribute names.
+    h_s, h_j, h_p: CsrGraph [U, U] (row-normalised motif adjacencies); r: CsrGraph [U, I] (row-normalised
+    interaction matrix, `Graph.normalize_graph_mat`, mhcn.py:401)."""
+
+    def __init__(self, h_s: CsrGraph, h_j: CsrGraph, h_p: CsrGraph, r: CsrGraph, emb_size=64, n_layers=2,
+                 ss_rate=0.01, concurrent=True):
+        super().__init__()
+        self.H_s, self.H_j, self.H_p, self.R = h_s, h_j, h_p, r
+        self.user_num, self.item_num = r.n_rows, r.n_cols
+        self.emb_size, self.n_layers, self.ss_rate, self.n_channel = emb_size, n_layers, ss_rate, 4
+        dev = r.device
+        xav = nn.init.xavier_uniform_
+        self.user_embeddings = nn.Parameter(xav(torch.empty(self.user_num, emb_size, device=dev)))
+        self.item_embeddings = nn.Parameter(xav(torch.empty(self.item_num, emb_size, device=dev)))
+        self.gating_weights, self.gating_bias = nn.ParameterDict(), nn.ParameterDict()
+        self.sgating_weights, self.sgating_bias = nn.ParameterDict(), nn.ParameterDict()
+        for c in range(1, self.n_channel + 1):
+            self.gating_weights[str(c)] = nn.Parameter(xav(torch.empty(emb_size, emb_size, device=dev)))
+            self.gating_bias[str(c)] = nn.Parameter(torch.zeros(1, emb_size, device=dev))
+            self.sgating_weights[str(c)] = nn.Parameter(xav(torch.empty(emb_size, emb_size, device=dev)))
+            self.sgating_bias[str(c)] = nn.Parameter(torch.zeros(1, emb_size, device=dev))
+        self.attention = nn.Parameter(xav(torch.empty(1, emb_size, device=dev)))
+        self.attention_mat = nn.Parameter(xav(torch.empty(emb_size, emb_size, device=dev)))
+        self._streams = [torch.cuda.Stream(device=dev) for _ in range(5)] if (concurrent and dev.type == "cuda") else None
+
+    # -- dense pieces (mhcn.py:404-420) ---------------------------------------------------------
+    def self_gating(self, em, channel):
+        return em * torch.sigmoid(em @ self.gating_weights[str(channel)] + self.gating_bias[str(channel)])
+
+    def self_supervised_gating(self, em, channel):
+        return em * torch.sigmoid(em @ self.sgating_weights[str(channel)] + self.sgating_bias[str(channel)])
+
+    def channel_attention(self, *channel_embeddings):
+        logits = torch.stack([(self.attention * (e @ self.attention_mat)).sum(1) for e in channel_embeddings])
+        score = torch.softmax(logits, dim=0)
+        mixed = sum(score[k].unsqueeze(1) * e for k, e in enumerate(channel_embeddings))
+        return mixed, score
+
+    # -- the layer loop (mhcn.py:422-466) -------------------------------------------------------
+    def _five_spmm(self, c1, c2, c3, mixed, items):
+        graphs = [self.H_s, self.H_j, self.H_p, self.R.t, self.R]
+        xs = [c1, c2, c3, mixed, items]
+        if self._streams is not None:
+            return multi_stream_spmm(graphs, xs, self._streams, l2norm="dual")
+        return [Fn.spmm_l2norm_dual(g, x) for g, x in zip(graphs, xs)]
+
+    def propagate(self):
+        """(final_user_embeddings [U, d], final_item_embeddings [I, d])."""
+        c1, c2, c3 = (self.self_gating(self.user_embeddings, k) for k in (1, 2, 3))
+        simple = self.self_gating(self.user_embeddings, 4)
+        items = self.item_embeddings
+        sums = [c1, c2, c3, simple, items]          # running sums of the layer lists (layer 0 = the inputs)
+        for _ in range(self.n_layers):
+            mixed, _ = self.channel_attention(c1, c2, c3)
+            mixed = mixed + simple / 2
+            (c1, n1), (c2, n2), (c3, n3), (new_items, n_i), (simple, n_s) = self._five_spmm(c1, c2, c3, mixed, items)
+            sums = [sums[0] + n1, sums[1] + n2, sums[2] + n3, sums[3] + n_s, sums[4] + n_i]
+            items = new_items
+        final_user, _ = self.channel_attention(sums[0], sums[1], sums[2])
+        return final_user + sums[3] / 2, sums[4]
+
+    def hierarchical_self_supervision(self, em, adj: CsrGraph, perms=None):
+        """mhcn.py:480-506.  perms: the three row permutations the reference draws with torch.randperm
+        (row_shuffle, row_column_shuffle x 2); None draws them on the device."""
+        n = em.shape[0]
+        if perms is None:
+            perms = [torch.randperm(n, device=em.device) for _ in range(3)]
+        edge = Fn.spmm(adj, em)
+        pos = (em * edge).sum(1)
+        neg1 = (em[perms[0]] * edge).sum(1)
+        neg2 = (edge[perms[1]] * em).sum(1)
+        local = (-torch.log(torch.sigmoid(pos - neg1)) - torch.log(torch.sigmoid(neg1 - neg2))).sum()
+        graph = edge.mean(0, keepdim=True)
+        pos = (edge * graph).sum(1)
+        neg1 = (edge[perms[2]] * graph).sum(1)
+        return (-torch.log(torch.sigmoid(pos - neg1))).sum() + local
+
+    def forward(self, u_idx, v_idx, neg_idx, perms=None):
+        """Same 6-tuple as mhcn.py:422-478: batch user / positive / negative rows, ss_loss, final embeddings.
+        perms: optional 9 row permutations (3 per channel) replaying the reference's randperm draws."""
+        final_user, final_item = self.propagate()
+        ss = 0
+        for c, adj in enumerate((self.H_s, self.H_j, self.H_p)):
+            p = None if perms is None else perms[3 * c:3 * c + 3]
+            ss = ss + self.hierarchical_self_supervision(self.self_supervised_gating(final_user, c + 1), adj, p)
+        return final_user[u_idx], final_item[v_idx], final_item[neg_idx], self.ss_rate * ss, final_user, final_item

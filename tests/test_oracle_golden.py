@@ -225,3 +225,70 @@ def test_grace_dual_branch_infonce(golden):
             for intra, keep in ((0, 0), (1, 0), (1, 1)):
                 got = O.grace_infonce(g[f"h1_{m}"], g[f"h2_{m}"], tau, bool(intra), bool(keep))
                 assert got == pytest.approx(float(g[f"loss_{m}_{tau}_{intra}_{keep}"]), rel=RT, abs=2e-6)
+
+
+# --------------------------------------------------------------------------- MHCN / sept_social / BUIR
+def _dense(z, name):
+    return O.csr_to_dense(z[f"{name}_indptr"], z[f"{name}_indices"], z[f"{name}_data"], z[f"{name}_shape"])
+
+
+def test_mhcn_motif_adjacency_and_layer_loop(golden):
+    """univariate/mhcn.py:340-368 and :422-506, outputs of the reference's own methods (tests/golden/mhcn.npz)."""
+    z = golden("mhcn.npz")
+    n_u, n_i = int(z["n_users"]), int(z["n_items"])
+    S = np.zeros((n_u, n_u))
+    S[z["S_row"], z["S_col"]] = 1.0
+    Y = np.zeros((n_u, n_i))
+    Y[z["Y_row"], z["Y_col"]] = 1.0
+    H = O.mhcn_motif_adjacency(S, Y)
+    for name, h in zip(("H_s", "H_j", "H_p"), H):
+        ref = _dense(z, name)
+        assert np.array_equal(h != 0, ref != 0), name          # integer structure: bit-exact
+        np.testing.assert_allclose(h, ref, rtol=2e-6, atol=1e-7)
+    R = _dense(z, "R")
+    gw = [z[f"gw{c}"].astype(np.float64) for c in (1, 2, 3, 4)]
+    gb = [z[f"gb{c}"].astype(np.float64) for c in (1, 2, 3, 4)]
+    fu, fi = O.mhcn_layer_loop(_dense(z, "H_s"), _dense(z, "H_j"), _dense(z, "H_p"), R, z["user_emb"].astype(np.float64),
+                               z["item_emb"], gw, gb, z["attention"].astype(np.float64),
+                               z["attention_mat"].astype(np.float64), int(z["n_layers"]))
+    np.testing.assert_allclose(fu, z["final_user"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(fi, z["final_item"], rtol=2e-5, atol=2e-6)
+    ss = 0.0
+    for c, name in enumerate(("H_s", "H_j", "H_p")):
+        em = O.mhcn_self_gating(fu, z[f"sgw{c + 1}"].astype(np.float64), z[f"sgb{c + 1}"].astype(np.float64))
+        ss += O.mhcn_hierarchical_self_supervision(em, _dense(z, name), z["perms"][3 * c:3 * c + 3])
+    assert float(z["ss_rate"]) * ss == pytest.approx(float(z["ss_loss"]), rel=2e-5)
+
+
+def test_sept_social_encoder_and_neighbor_discrimination(golden):
+    """univariate/sept_social.py:370-385 (sum of row-normalised layers) and :408-420."""
+    z = golden("sept_social.npz")
+    n_u = int(z["n_users"])
+    rp, ci, va = z["norm_adj_indptr"], z["norm_adj_indices"], z["norm_adj_data"]
+    final, _ = O.lgcn_encoder_forward(rp, ci, va, z["ego"], int(z["n_layers"]), combine="sum", layer_norm=True)
+    np.testing.assert_allclose(final[:n_u], z["rec_user"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(final[n_u:], z["rec_item"], rtol=2e-5, atol=2e-6)
+    for name, key in (("social", "friend_view"), ("sharing", "sharing_view")):
+        v, _ = O.lgcn_encoder_forward(z[f"{name}_indptr"], z[f"{name}_indices"], z[f"{name}_data"], z["ego"][:n_u],
+                                      int(z["n_layers"]), combine="sum", layer_norm=True)
+        np.testing.assert_allclose(v, z[key], rtol=2e-5, atol=2e-6)
+    uniq = np.unique(z["u_idx"])
+    loss = O.neighbor_discrimination(z["positive"], z["friend_view"][uniq], z["aug_user"][uniq])
+    assert loss == pytest.approx(float(z["nd_loss"]), rel=2e-5)
+
+
+def test_buir_sparse_dropout(golden):
+    """univariate/buir.py:300-309 + the forward that consumes it (:311-326)."""
+    z = golden("buir.npz")
+    rate, n = float(z["rate"]), int(z["n_users"]) + int(z["n_items"])
+    assert np.array_equal(z["keep"], np.floor(1 - rate + z["rand"]).astype(bool))
+    vals = O.sparse_dropout_values(z["adj_val"], z["keep"], rate)
+    # the reference's dropped operator, coalesced, equals the kept entries with rescaled values
+    got = np.zeros((n, n))
+    np.add.at(got, (z["adj_row"], z["adj_col"]), vals)
+    ref = np.zeros((n, n))
+    np.add.at(ref, (z["dropped_row"], z["dropped_col"]), z["dropped_val"].astype(np.float64))
+    np.testing.assert_allclose(got, ref, rtol=1e-6, atol=1e-9)
+    rowptr, col, val, order = O.coo_to_csr_stable(z["adj_row"], z["adj_col"], z["adj_val"], n)
+    final, _ = O.lgcn_encoder_forward(rowptr, col, val * z["keep"][order] / (1 - rate), z["x"], int(z["n_layers"]), "mean")
+    np.testing.assert_allclose(final, z["final"], rtol=2e-5, atol=2e-6)

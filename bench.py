@@ -252,10 +252,10 @@ def infonce_roofline(Fn, x0, n_u, dev):
         0.1 * torch.randn(m, d, device=dev, generator=gen) * table.std()
     sa, sb = Fn.row_inv_norm(anchors), Fn.row_inv_norm(table)
     inv_tau = 10.0
-    lse = Fn.infonce_lse_raw(anchors, sa, table, sb, inv_tau, unit_rows=True)
+    lse = Fn.infonce_lse_raw(anchors, sa, table, sb, inv_tau)
     w = torch.ones(m, device=dev)
-    t_f = _event_ms(lambda: Fn.infonce_lse_raw(anchors, sa, table, sb, inv_tau, unit_rows=True), 10)
-    t_b = _event_ms(lambda: Fn.infonce_bwd_pair_raw(anchors, sa, table, sb, inv_tau, lse, w, None, None, unit_rows=True), 5)
+    t_f = _event_ms(lambda: Fn.infonce_lse_raw(anchors, sa, table, sb, inv_tau), 10)
+    t_b = _event_ms(lambda: Fn.infonce_bwd_pair_raw(anchors, sa, table, sb, inv_tau, lse, w, None, None), 5)
     flops = 2.0 * m * n_u * d
     from recommendation_amd import _lib
     engine = int(_lib.lib().gcr_infonce_engine(d))

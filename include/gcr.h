@@ -179,8 +179,8 @@ int32_t gcr_edge_mask_bits(int64_t nnz, float pe, uint64_t seed, const int64_t* 
  * accuracy on both engines: the f32 MFMA (v_mfma_f32_32x32x2_f32), or for d <= 128 the bf16 MFMA on
  * three error-free bf16 planes per operand (csrc/gcr_infonce.hip, "split-operand engine").
  * --------------------------------------------------------------------------------------------- */
-/* engine the InfoNCE / k-means kernels use for width d right now: 0 = f32 MFMA, 1 = split-operand bf16
- * (default for d <= 128; the environment variable GCR_INFONCE_ENGINE=f32 selects 0 everywhere) */
+/* engine the InfoNCE / k-means kernels use for width d by default: 0 = f32 MFMA, 1 = split-operand bf16
+ * (d <= 128); GCR_INFONCE_ENGINE_F32 in the flags of the _ex entry points selects 0 for one call */
 int32_t gcr_infonce_engine(int32_t d);
 
 
@@ -216,11 +216,10 @@ int32_t gcr_infonce_fwd_f32(const float* a, const float* a_scale, int64_t m,
  * same view.  Not combinable with col_sum.
  */
 #define GCR_INFONCE_EXCLUDE_DIAGONAL 1u
-/* GCR_INFONCE_UNIT_ROWS: the caller promises |a_scale[i] * a_i|_2 <= 1 and |b_scale[j] * b_j|_2 <= 1 (rows
- * normalised by the scales, as every InfoNCE call site of the reference does).  It allows the two-plane f16
- * engine (csrc/gcr_infonce.hip, "h2": f32 results, half the matrix-core work of the bf16 split) for d <= 64
- * and inv_tau <= 20; forward and backward of one problem must pass the same flags. */
-#define GCR_INFONCE_UNIT_ROWS 2u
+/* GCR_INFONCE_ENGINE_F32: run this problem on the f32 MFMA engine instead of the default (the split-operand
+ * bf16 engine for d <= 128).  The engine is an argument, never read from the environment; forward and
+ * backward of one problem must pass the same flag (the backward recomputes the forward's logits). */
+#define GCR_INFONCE_ENGINE_F32 4u
 int32_t gcr_infonce_fwd_ex_f32(const float* a, const float* a_scale, int64_t m,
                                const float* b, const float* b_scale, int64_t n, int32_t d,
                                float inv_tau, float* lse, float* col_sum, float col_bound,

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256, (D <= 64 ? 3 : 2)) void infonce_fwd_kernel(con
                                                              const float* __restrict__ b_scale, int64_t n_rows,
                                                              float scale2, int nsplit, int64_t tiles_per_split,
                                                              float2* __restrict__ part, float* __restrict__ col_sum,
-                                                             float col_bound2, int force_mask) {
+                                                             float col_bound2) {
   using S = Shape<D>;
   __shared__ __align__(16) float lds[2][kTileJ * S::STRIDE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256, (D <= 64 ? 3 : 2)) void infonce_fwd_kernel(con
 #pragma unroll
       for (int t = 0; t < S::NT; ++t) xr[t] = diag_offset(i0 + 32 * t + i32, tt * kTileJ, h);
       lse_update<S::NT, true, true>(acc, rows_left(n_rows, tt * kTileJ, h), m_run, l_run, xr);
-    } else if (force_mask || (tt + 1) * kTileJ > n_rows)   // only the table's ragged last tile pays for the row mask
+    } else if ((tt + 1) * kTileJ > n_rows)   // only the table's ragged last tile pays for the row mask
       lse_update<S::NT, true>(acc, rows_left(n_rows, tt * kTileJ, h), m_run, l_run);
     else
       lse_update<S::NT, false>(acc, 64, m_run, l_run);
@@ -379,7 +379,7 @@ __device__ __forceinline__ void score_tile_b3(const unsigned char* __restrict__ 
   }
 }
 
-template <int D, bool COLSUM, bool PIPE, bool EXD = false>
+template <int D, bool COLSUM, bool EXD = false>
 __global__ __launch_bounds__(256, 2) void infonce_fwd_b3_kernel(const float* __restrict__ a,
                                                                 const float* __restrict__ a_scale, int64_t m_rows,
                                                                 const float* __restrict__ b,
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256, 2) void infonce_fwd_b3_kernel(const float* __r
   };
   if (tile0 >= tile1) {
     // empty split (plan_fwd never makes one): fall through to the (kNegBig, 0) partial
-  } else if (PIPE) {
+  } else {
     // Software pipeline, interleaved by hand: the MFMAs of tile tt+1 alternate in program order with
     // the softmax VALU work of tile tt (branch-free: every tile before the split's last one is full)
     // and with the operand split of tile tt+2, one share of VALU "units" per MFMA slot, pinned by
@@ -546,20 +546,6 @@ __global__ __launch_bounds__(256, 2) void infonce_fwd_b3_kernel(const float* __r
     } else {
       epilogue_any(acc_a, last);
     }
-  } else {
-    stage_load<D>(b, b_scale, n_rows, tile0 * kTileJ, tid, regs);
-    stage_store_b3<D>(lds[0], tid, regs);
-    __syncthreads();
-    for (int64_t tt = tile0; tt < tile1; ++tt) {
-      const int cur = (int)((tt - tile0) & 1);
-      const int64_t nxt = tt + 1 < tile1 ? tt + 1 : tt;
-      stage_load<D>(b, b_scale, n_rows, nxt * kTileJ, tid, regs);
-      f32x16 acc[S::NT];
-      score_tile_b3<D, S::NT>(lds[cur], i32, h, bq, acc);
-      epilogue_any(acc, tt);
-      stage_store_b3<D>(lds[cur ^ 1], tid, regs);
-      __syncthreads();
-    }
   }
 
 #pragma unroll
@@ -572,416 +558,13 @@ __global__ __launch_bounds__(256, 2) void infonce_fwd_b3_kernel(const float* __r
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// Two-plane f16 engine ("h2") for UNIT-NORM operands (the caller's promise, GCR_INFONCE_UNIT_ROWS:
-// |a_scale[i] * a_i| <= 1 and |b_scale[j] * b_j| <= 1, every InfoNCE call site of the reference
-// normalises; 1/tau <= 20).  f16 has 11 significant bits, so x = hi + lo with hi = f16(x),
-// lo = f16(x - hi) leaves a residual of 2^-24 |x| and a product needs THREE terms (hi*hi + hi*lo +
-// lo*hi; lo*lo is 2^-24): half the matrix-core work of the bf16 split.  f16's exponent range is what
-// the promise is for: the stationary operand (<= 1/tau * log2 e <= 29) is scaled by 2^4, the streamed
-// one (<= 1) by 2^8, the residual plane by a further 2^11 so that it is a normal number again, and a
-// value below 2^-13 after scaling goes entirely into the residual plane (no f16 sub-normals anywhere).
-// The two cross terms accumulate separately (they carry the 2^11) and are folded in with one FMA per
-// score: s = (acc_hi + 2^-11 acc_lo) * 2^-12.  Per-product error 3 * 2^-24, i.e. <= 5e-6 on a log2-domain
-// logit in the worst case (all of a row's mass aligned, 1/tau = 20), the size of the f32 engine's own
-// accumulation error; the parity tests run on it with the tolerances of the other two engines.
-// ------------------------------------------------------------------------------------------
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-constexpr float kH2ScaleA = 16.0f, kH2ScaleB = 256.0f, kH2LoScale = 2048.0f;
-constexpr float kH2LoInv = 1.0f / 2048.0f, kH2OutInv = 1.0f / 4096.0f;
-
-__device__ __forceinline__ unsigned pack_f16(float lo, float hi) {
-  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){lo, hi}, f16x2));       // RNE
-}
-
-// two (already scaled) f32 -> packed f16 pair of the hi plane and of the 2^11-scaled residual plane
-__device__ __forceinline__ void split2h(float a, float b, unsigned& hi, unsigned& lo) {
-  const float ah = fabsf(a) >= 0x1p-13f ? a : 0.f, bh = fabsf(b) >= 0x1p-13f ? b : 0.f;   // never an f16 sub-normal
-  hi = pack_f16(ah, bh);
-  const f16x2 hv = __builtin_bit_cast(f16x2, hi);
-  lo = pack_f16((a - (float)hv[0]) * kH2LoScale, (b - (float)hv[1]) * kH2LoScale);
-}
-
-template <int D>
-__device__ __forceinline__ void stage_store_h2_one(unsigned char* __restrict__ tile, int tid, const float4& v, int u) {
-  using S = ShapeB3<D>;
-  const int idx = tid + 256 * u;
-  const int row = idx / (D / 4), c4 = idx % (D / 4);
-  unsigned h0, l0, h1, l1;
-  split2h(v.x * kH2ScaleB, v.y * kH2ScaleB, h0, l0);
-  split2h(v.z * kH2ScaleB, v.w * kH2ScaleB, h1, l1);
-  unsigned char* p = tile + row * S::ROWB + c4 * 8;
-  *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
-  *reinterpret_cast<uint2*>(p + S::PLANE) = make_uint2(l0, l1);
-}
-
-template <int D>
-__device__ __forceinline__ void load_stationary_h2(const float* __restrict__ a, const float* __restrict__ a_scale,
-                                                   int64_t m_rows, int64_t row, int h, float mult,
-                                                   u32x4 (&frag)[2][ShapeB3<D>::KC]) {
-  using S = ShapeB3<D>;
-  const bool valid = row < m_rows;
-  const float s = valid ? (a_scale != nullptr ? a_scale[row] : 1.0f) * mult * kH2ScaleA : 0.f;
-  const float* p = a + (valid ? row : 0) * D + h * S::KH;
-#pragma unroll
-  for (int c = 0; c < S::KC; ++c) {
-    const float4 v0 = valid ? *reinterpret_cast<const float4*>(p + 8 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 v1 = valid ? *reinterpret_cast<const float4*>(p + 8 * c + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    unsigned q[2][4];
-    split2h(v0.x * s, v0.y * s, q[0][0], q[1][0]);
-    split2h(v0.z * s, v0.w * s, q[0][1], q[1][1]);
-    split2h(v1.x * s, v1.y * s, q[0][2], q[1][2]);
-    split2h(v1.z * s, v1.w * s, q[0][3], q[1][3]);
-#pragma unroll
-    for (int pl = 0; pl < 2; ++pl) frag[pl][c] = (u32x4){q[pl][0], q[pl][1], q[pl][2], q[pl][3]};
-  }
-}
-
-__device__ __forceinline__ f32x16 mfma_f16(u32x4 a, u32x4 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-}
-
-// S^T tile in log2 units (the same value wherever it is called from: forward and both backward passes)
-template <int D, int NT>
-__device__ __forceinline__ void score_tile_h2(const unsigned char* __restrict__ tile, int i32, int h,
-                                              const u32x4 (&bq)[NT][2][ShapeB3<D>::KC], f32x16 (&acc)[NT]) {
-  using S = ShapeB3<D>;
-  f32x16 lo[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = lo[t][r] = 0.f;
-  const unsigned char* base = tile + i32 * S::ROWB + h * (S::KH * 2);
-#pragma unroll
-  for (int c = 0; c < S::KC; ++c) {
-    const u32x4 ah = *reinterpret_cast<const u32x4*>(base + 16 * c);
-    const u32x4 al = *reinterpret_cast<const u32x4*>(base + S::PLANE + 16 * c);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) lo[t] = mfma_f16(al, bq[t][0][c], lo[t]);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) lo[t] = mfma_f16(ah, bq[t][1][c], lo[t]);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = mfma_f16(ah, bq[t][0][c], acc[t]);
-  }
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = fmaf(lo[t][r], kH2LoInv, acc[t][r]) * kH2OutInv;
-}
-
-// forward on the h2 engine: the b3 forward's software pipeline with two planes / three terms per k-chunk
-template <int D, bool EXD>
-__global__ __launch_bounds__(256, 2) void infonce_fwd_h2_kernel(const float* __restrict__ a,
-                                                                const float* __restrict__ a_scale, int64_t m_rows,
-                                                                const float* __restrict__ b,
-                                                                const float* __restrict__ b_scale, int64_t n_rows,
-                                                                float scale2, int nsplit, int64_t tiles_per_split,
-                                                                float2* __restrict__ part) {
-  using S = ShapeB3<D>;
-  __shared__ __align__(16) unsigned char lds[2][2 * S::PLANE];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int i32 = lane & 31, h = lane >> 5;
-  const int64_t mblk = blockIdx.x / nsplit;
-  const int split = blockIdx.x % nsplit;
-  const int64_t i0 = (mblk * 4 + wave) * (32 * S::NT);
-  u32x4 bq[S::NT][2][S::KC];
-#pragma unroll
-  for (int t = 0; t < S::NT; ++t) load_stationary_h2<D>(a, a_scale, m_rows, i0 + 32 * t + i32, h, scale2, bq[t]);
-  float m_run[S::NT], l_run[S::NT];
-#pragma unroll
-  for (int t = 0; t < S::NT; ++t) {
-    m_run[t] = kNegBig;
-    l_run[t] = 0.f;
-  }
-  const int64_t total_tiles = (n_rows + kTileJ - 1) / kTileJ;
-  const int64_t tile0 = (int64_t)split * tiles_per_split;
-  const int64_t tile1 = min(total_tiles, tile0 + tiles_per_split);
-  float4 regs[S::NLD];
-  auto stage_all = [&](unsigned char* out) {
-#pragma unroll
-    for (int u = 0; u < S::NLD; ++u) stage_store_h2_one<D>(out, tid, regs[u], u);
-  };
-  auto epilogue_any = [&](const f32x16 (&acc)[S::NT], int64_t tt) {
-    int xr[S::NT];
-#pragma unroll
-    for (int t = 0; t < S::NT; ++t) xr[t] = EXD ? diag_offset(i0 + 32 * t + i32, tt * kTileJ, h) : -1;
-    lse_update<S::NT, true, EXD>(acc, rows_left(n_rows, tt * kTileJ, h), m_run, l_run, xr);
-  };
-  if (tile0 < tile1) {
-    constexpr int NS = 3 * S::KC * S::NT;                          // MFMA slots per step
-    constexpr int NU = 26 * S::NT + S::NLD;                        // VALU micro-units per step
-    const int64_t last = tile1 - 1;
-    f32x16 hi_b[S::NT], lo_b[S::NT], hi_a[S::NT], lo_a[S::NT];
-    stage_load<D>(b, b_scale, n_rows, tile0 * kTileJ, tid, regs);
-    stage_all(lds[0]);
-    stage_load<D>(b, b_scale, n_rows, min(tile0 + 1, last) * kTileJ, tid, regs);
-    __syncthreads();
-    score_tile_h2<D, S::NT>(lds[0], i32, h, bq, hi_a);             // hi_a = finished scores of tile0
-    stage_all(lds[1]);
-    __syncthreads();
-    // one step: MFMAs of tile tt+1 (lds[nb]) into (hi_n, lo_n); `cur` holds tile tt either finished
-    // (FIRST) or still as its (hi_c, lo_c) accumulator pair, folded by the first micro-units
-    auto step = [&](auto first_tag, f32x16 (&cur)[S::NT], f32x16 (&lo_c)[S::NT], f32x16 (&hi_n)[S::NT],
-                    f32x16 (&lo_n)[S::NT], int64_t tt, int nb) {
-      constexpr bool FIRST = decltype(first_tag)::value;
-      stage_load<D>(b, b_scale, n_rows, min(tt + 2, last) * kTileJ, tid, regs);
-      const unsigned char* base = lds[nb] + i32 * S::ROWB + h * (S::KH * 2);
-      unsigned char* out = lds[nb ^ 1];
-      float tmax[S::NT], m_new[S::NT], sum[S::NT];
-      int xr[S::NT];
-      if (EXD) {
-#pragma unroll
-        for (int t = 0; t < S::NT; ++t) xr[t] = diag_offset(i0 + 32 * t + i32, tt * kTileJ, h);
-      }
-      auto micro = [&](int m) {
-        const int u = m / S::NT, t = m % S::NT;
-        if (m >= 26 * S::NT) {
-          stage_store_h2_one<D>(out, tid, regs[m - 26 * S::NT], m - 26 * S::NT);
-        } else if (u < 4) {                          // fold the cross terms: log2-domain scores of 4 registers
-          if (!FIRST) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) cur[t][4 * u + e] = fmaf(lo_c[t][4 * u + e], kH2LoInv, cur[t][4 * u + e]) * kH2OutInv;
-          }
-          if (EXD) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) cur[t][4 * u + e] = (xr[t] == e + 8 * u) ? -INFINITY : cur[t][4 * u + e];
-          }
-        } else if (u < 8) {
-          const int g = u - 4;
-          const float x = fmaxf(fmaxf(cur[t][4 * g], cur[t][4 * g + 1]), fmaxf(cur[t][4 * g + 2], cur[t][4 * g + 3]));
-          tmax[t] = g == 0 ? x : fmaxf(tmax[t], x);
-        } else if (u == 8) {
-          m_new[t] = fmaxf(m_run[t], tmax[t]);
-          sum[t] = 0.f;
-        } else if (u < 25) {
-          sum[t] += __builtin_amdgcn_exp2f(cur[t][u - 9] - m_new[t]);
-        } else {
-          l_run[t] = l_run[t] * __builtin_amdgcn_exp2f(m_run[t] - m_new[t]) + sum[t];
-          m_run[t] = m_new[t];
-        }
-      };
-      u32x4 ap[2][2];
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl) ap[0][pl] = *reinterpret_cast<const u32x4*>(base + pl * S::PLANE);
-#pragma unroll
-      for (int c = 0; c < S::KC; ++c) {
-        if (c + 1 < S::KC) {
-#pragma unroll
-          for (int pl = 0; pl < 2; ++pl)
-            ap[(c + 1) & 1][pl] = *reinterpret_cast<const u32x4*>(base + pl * S::PLANE + 16 * (c + 1));
-        }
-#pragma unroll
-        for (int term = 0; term < 3; ++term) {
-#pragma unroll
-          for (int t = 0; t < S::NT; ++t) {
-            const int slot = (c * 3 + term) * S::NT + t;
-            f32x16& dst = term == 2 ? hi_n[t] : lo_n[t];
-            f32x16 cin = dst;
-            if (c == 0 && term != 1) {
-#pragma unroll
-              for (int r = 0; r < 16; ++r) cin[r] = 0.f;
-            }
-            // term 0: lo(table) * hi(anchor), 1: hi * lo, 2: hi * hi  (same order as score_tile_h2)
-            dst = mfma_f16(ap[c & 1][term == 0 ? 1 : 0], bq[t][term == 1 ? 1 : 0][c], cin);
-#pragma unroll
-            for (int u = slot * NU / NS; u < (slot + 1) * NU / NS; ++u) micro(u);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < S::NT; ++t) asm volatile("" : "+v"(m_run[t]), "+v"(l_run[t]));
-      __syncthreads();
-    };
-    auto fold = [&](f32x16 (&hi)[S::NT], const f32x16 (&lo)[S::NT]) {
-#pragma unroll
-      for (int t = 0; t < S::NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) hi[t][r] = fmaf(lo[t][r], kH2LoInv, hi[t][r]) * kH2OutInv;
-    };
-    // tile0's scores are finished in hi_a; from then on the accumulator pairs alternate (b, a, b, ...)
-    int64_t tt = tile0;
-    bool cur_is_a = true, cur_finished = true;
-    if (tt < last) {
-      step(std::true_type{}, hi_a, lo_a, hi_b, lo_b, tt, 1);
-      ++tt;
-      cur_is_a = false;
-      cur_finished = false;
-    }
-    for (; tt + 2 <= last; tt += 2) {
-      step(std::false_type{}, hi_b, lo_b, hi_a, lo_a, tt, 0);
-      step(std::false_type{}, hi_a, lo_a, hi_b, lo_b, tt + 1, 1);
-    }
-    if (tt < last) {                                   // cur = (hi_b, lo_b), lds[(tt+1-tile0)&1] holds tile tt+1
-      step(std::false_type{}, hi_b, lo_b, hi_a, lo_a, tt, 0);
-      ++tt;
-      cur_is_a = true;
-    }
-    if (cur_finished) {
-      epilogue_any(hi_a, last);
-    } else if (cur_is_a) {
-      fold(hi_a, lo_a);
-      epilogue_any(hi_a, last);
-    } else {
-      fold(hi_b, lo_b);
-      epilogue_any(hi_b, last);
-    }
-  }
-#pragma unroll
-  for (int t = 0; t < S::NT; ++t) {
-    const float m_o = __shfl_xor(m_run[t], 32, 64), l_o = __shfl_xor(l_run[t], 32, 64);
-    const float m = fmaxf(m_run[t], m_o);
-    const float l = l_run[t] * __builtin_amdgcn_exp2f(m_run[t] - m) + l_o * __builtin_amdgcn_exp2f(m_o - m);
-    const int64_t row = i0 + 32 * t + i32;
-    if (h == 0 && row < m_rows) part[(int64_t)split * m_rows + row] = make_float2(m, l);
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// Experimental forward of the bf16 split on the 16x16x32 MFMA shape (GCR_INFONCE_MFMA=16; measurement
-// only).  Same LDS image, same planes and terms; a wave still covers 64 anchors x 32 table rows per tile, as
-// 4 x 2 accumulator tiles of 16 x 16: lane (n = lane & 15, g = lane >> 4) holds anchor n of each of the four
-// anchor sub-tiles and table rows 4g .. 4g+3 of each 16-row half; K is split over the four lane groups
-// (group g owns features [g d/4, (g+1) d/4)).  MI355X_MICROARCH.md measures a higher sustained clock for this
-// shape under load.
-// ------------------------------------------------------------------------------------------
-typedef float f32x4v __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ f32x4v mfma16_bf16(u32x4 a, u32x4 b, f32x4v c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-
-template <int D>
-__global__ __launch_bounds__(256, 2) void infonce_fwd_b3m16_kernel(const float* __restrict__ a,
-                                                                   const float* __restrict__ a_scale, int64_t m_rows,
-                                                                   const float* __restrict__ b,
-                                                                   const float* __restrict__ b_scale, int64_t n_rows,
-                                                                   float scale2, int nsplit, int64_t tiles_per_split,
-                                                                   float2* __restrict__ part) {
-  using S = ShapeB3<D>;
-  constexpr int KG = D / 4, KC = KG / 8;                       // features per lane group, 8-feature chunks of them
-  __shared__ __align__(16) unsigned char lds[2][3 * S::PLANE];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n16 = lane & 15, g = lane >> 4;
-  const int64_t mblk = blockIdx.x / nsplit;
-  const int split = blockIdx.x % nsplit;
-  const int64_t i0 = (mblk * 4 + wave) * 64;
-  u32x4 bq[4][3][KC];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int64_t row = i0 + 16 * t + n16;
-    const bool valid = row < m_rows;
-    const float sc = valid ? (a_scale != nullptr ? a_scale[row] : 1.0f) * scale2 : 0.f;
-    const float* p = a + (valid ? row : 0) * D + g * KG;
-#pragma unroll
-    for (int c = 0; c < KC; ++c) {
-      const float4 v0 = valid ? *reinterpret_cast<const float4*>(p + 8 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
-      const float4 v1 = valid ? *reinterpret_cast<const float4*>(p + 8 * c + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-      unsigned q[3][4];
-      split3(v0.x * sc, v0.y * sc, q[0][0], q[1][0], q[2][0]);
-      split3(v0.z * sc, v0.w * sc, q[0][1], q[1][1], q[2][1]);
-      split3(v1.x * sc, v1.y * sc, q[0][2], q[1][2], q[2][2]);
-      split3(v1.z * sc, v1.w * sc, q[0][3], q[1][3], q[2][3]);
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) bq[t][pl][c] = (u32x4){q[pl][0], q[pl][1], q[pl][2], q[pl][3]};
-    }
-  }
-  float m_run[4], l_run[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    m_run[t] = kNegBig;
-    l_run[t] = 0.f;
-  }
-  const int64_t total_tiles = (n_rows + kTileJ - 1) / kTileJ;
-  const int64_t tile0 = (int64_t)split * tiles_per_split;
-  const int64_t tile1 = min(total_tiles, tile0 + tiles_per_split);
-  float4 regs[S::NLD];
-  if (tile0 < tile1) {
-    stage_load<D>(b, b_scale, n_rows, tile0 * kTileJ, tid, regs);
-    stage_store_b3<D>(lds[0], tid, regs);
-  }
-  __syncthreads();
-  constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
-  for (int64_t tt = tile0; tt < tile1; ++tt) {
-    const int cur = (int)((tt - tile0) & 1);
-    const int64_t nxt = tt + 1 < tile1 ? tt + 1 : tt;
-    stage_load<D>(b, b_scale, n_rows, nxt * kTileJ, tid, regs);
-    f32x4v acc[4][2];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int rs = 0; rs < 2; ++rs) acc[t][rs] = (f32x4v){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int rs = 0; rs < 2; ++rs) {
-      const unsigned char* base = lds[cur] + (16 * rs + n16) * S::ROWB + g * (KG * 2);
-#pragma unroll
-      for (int c = 0; c < KC; ++c) {
-        u32x4 ap[3];
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) ap[pl] = *reinterpret_cast<const u32x4*>(base + pl * S::PLANE + 16 * c);
-#pragma unroll
-        for (int term = 0; term < 6; ++term)
-#pragma unroll
-          for (int t = 0; t < 4; ++t) acc[t][rs] = mfma16_bf16(ap[TA[term]], bq[t][TB[term]][c], acc[t][rs]);
-      }
-    }
-    const int64_t rem = n_rows - tt * kTileJ;                  // rows of this tile that exist
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      float v[8];
-#pragma unroll
-      for (int rs = 0; rs < 2; ++rs)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[4 * rs + r] = (16 * rs + 4 * g + r < rem) ? acc[t][rs][r] : -INFINITY;
-      float tmax = v[0];
-#pragma unroll
-      for (int r = 1; r < 8; ++r) tmax = fmaxf(tmax, v[r]);
-      const float m_new = fmaxf(m_run[t], tmax);
-      float sum = 0.f;
-#pragma unroll
-      for (int r = 0; r < 8; ++r) sum += __builtin_amdgcn_exp2f(v[r] - m_new);
-      l_run[t] = l_run[t] * __builtin_amdgcn_exp2f(m_run[t] - m_new) + sum;
-      m_run[t] = m_new;
-    }
-    stage_store_b3<D>(lds[cur ^ 1], tid, regs);
-    __syncthreads();
-  }
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    float m = m_run[t], l = l_run[t];
-#pragma unroll
-    for (int off = 16; off <= 32; off <<= 1) {                  // merge the four lane groups
-      const float m_o = __shfl_xor(m, off, 64), l_o = __shfl_xor(l, off, 64);
-      const float mm = fmaxf(m, m_o);
-      l = l * __builtin_amdgcn_exp2f(m - mm) + l_o * __builtin_amdgcn_exp2f(m_o - mm);
-      m = mm;
-    }
-    const int64_t row = i0 + 16 * t + n16;
-    if (g == 0 && row < m_rows) part[(int64_t)split * m_rows + row] = make_float2(m, l);
-  }
-}
-
-// engine selection: GCR_INFONCE_ENGINE = f32 | b3 (read per call so that A/B rounds interleave
-// in-process); d = 256 stays on the f32 engine (its three operand planes would not fit the registers)
-// Default: b3 for d <= 128, where forward AND backward have it (the backward must recompute the
-// forward's logits with the forward's engine, or sum_j P_ij = 1 only holds to ~1e-6 and
-// near-cancelling gradients lose digits).
-// h2 (two-plane f16) needs the caller's unit-rows promise, 1/tau <= 20 and d <= 64; GCR_INFONCE_ENGINE=b3 or
-// f32 switches it off
-bool use_h2(int d, float inv_tau, bool unit_rows) {
-  if (!unit_rows || d > 64 || !(inv_tau > 0.f && inv_tau <= 20.0f)) return false;
-  const char* e = getenv("GCR_INFONCE_ENGINE");
-  if (e != nullptr && (e[0] == 'f' || e[0] == 'b')) return false;
-  return e != nullptr && e[0] == 'h';
-}
-
-bool use_b3(int d) {
-  if (d > 128) return false;
-  const char* e = getenv("GCR_INFONCE_ENGINE");
-  if (e != nullptr && e[0] == 'f') return false;
-  return true;
-}
+// Engine selection.  Default: the split-operand bf16 engine for d <= 128, where forward AND backward have
+// it; d = 256 stays on the f32 MFMA (its three operand planes would not fit the registers).  The flag
+// GCR_INFONCE_ENGINE_F32 of the _ex entry points forces the f32 MFMA.  The choice is an ARGUMENT, never
+// read from the environment: the host wrapper resolves it once per forward and hands the same flag to
+// the backward (which must recompute the forward's logits with the forward's engine, or sum_j P_ij = 1
+// only holds to ~1e-6 and near-cancelling gradients lose digits).
+bool use_b3(int d, bool force_f32 = false) { return d <= 128 && !force_f32; }
 
 // natural-log LSE of the scaled logits from the per-split (max2, sum2) partials
 __global__ void infonce_merge_kernel(const float2* __restrict__ part, int nsplit, int64_t m_rows,
@@ -1068,24 +651,19 @@ struct FwdPlan {
 //  * many row blocks: several rounds are unavoidable, so make them short: <= 320 tiles per block and
 //    >= 3 rounds (100K x 100K: 95 TF at 782 blocks, 119 TF at 3128; scripts/perf_infonce_ab.py);
 //  * never fewer than 16 tiles per block (anchor prologue + partial merge dominate below that).
-// GCR_INFONCE_BLOCKS overrides the block target; read per call so A/B rounds interleave in-process.
 FwdPlan plan_fwd(int64_t m, int64_t n, int anchors_per_block, int64_t resident) {
   FwdPlan p;
   p.m_blocks = (m + anchors_per_block - 1) / anchors_per_block;
   const int64_t total_tiles = (n + kTileJ - 1) / kTileJ;
-  const char* env_blocks = getenv("GCR_INFONCE_BLOCKS");
-  const int64_t env_v = env_blocks ? atoll(env_blocks) : 0;
   int64_t nsplit;
-  if (env_v > 0) {
-    nsplit = (env_v + p.m_blocks - 1) / p.m_blocks;
-  } else if (p.m_blocks * 2 <= resident) {
+  if (p.m_blocks * 2 <= resident) {
     nsplit = resident / p.m_blocks;
   } else {
     nsplit = (total_tiles + 319) / 320;
     if (p.m_blocks * nsplit < 3 * resident) nsplit = (3 * resident + p.m_blocks - 1) / p.m_blocks;
   }
   const int64_t max_split = total_tiles / 16 > 0 ? total_tiles / 16 : 1;
-  if (env_v <= 0 && nsplit > max_split) nsplit = max_split;
+  if (nsplit > max_split) nsplit = max_split;
   if (nsplit > total_tiles) nsplit = total_tiles;
   if (nsplit < 1) nsplit = 1;
   p.tiles_per_split = (total_tiles + nsplit - 1) / nsplit;
@@ -1303,9 +881,7 @@ __device__ __forceinline__ void stage_store_b3t_one(unsigned char* __restrict__ 
   }
 }
 
-// H2: the score tile on the two-plane f16 engine (exactly infonce_fwd_h2_kernel's logits; ILV only); the
-// second product stays on the bf16 planes.
-template <int D, bool ILV, bool EXD = false, bool H2 = false>
+template <int D, bool ILV, bool EXD = false>
 __global__ __launch_bounds__(256, 2) void infonce_bwd_b3_kernel(
     const float* __restrict__ x, const float* __restrict__ x_scale, int64_t mx, const float* __restrict__ y,
     const float* __restrict__ y_scale, int64_t ny, float scale2, float out_scale, const float* __restrict__ lse_x,
@@ -1327,17 +903,7 @@ __global__ __launch_bounds__(256, 2) void infonce_bwd_b3_kernel(
   const int64_t row_i = (mblk * 4 + wave) * 32 + i32;
 
   u32x4 bq[1][3][S::KC];
-  if (H2) {
-    u32x4 t2[2][S::KC];
-    load_stationary_h2<D>(x, x_scale, mx, row_i, h, scale2, t2);
-#pragma unroll
-    for (int c = 0; c < S::KC; ++c) {
-      bq[0][0][c] = t2[0][c];
-      bq[0][1][c] = t2[1][c];
-    }
-  } else {
-    load_stationary_b3<D>(x, x_scale, mx, row_i, h, scale2, bq[0]);
-  }
+  load_stationary_b3<D>(x, x_scale, mx, row_i, h, scale2, bq[0]);
   const bool on_x = row_i < mx && w_x != nullptr;
   const float wl = on_x ? w_x[row_i] : 0.f;
   const float lse2l = on_x ? lse_x[row_i] * kLog2e : 1.0e30f;    // disabled term: exp2(-huge) = 0, never 0 * inf
@@ -1373,7 +939,7 @@ __global__ __launch_bounds__(256, 2) void infonce_bwd_b3_kernel(
     // MFMAs with the operand split + LDS stores of the NEXT tile (loaded one iteration earlier: two
     // staging register sets); phase 2 (exposed) forms P and splits its first 16 rows; phase 3
     // alternates the G MFMAs of rows 0-15 with the split of rows 16-31, then issues those of rows 16-31.
-    constexpr int NP = 4 * S::NLD, NS1 = (H2 ? 3 : 6) * S::KC, NG = B::CT * 6;
+    constexpr int NP = 4 * S::NLD, NS1 = 6 * S::KC, NG = B::CT * 6;
     constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
     float4 ra[S::NLD], rb[S::NLD];
     float lse_a = 0.f, w_a = 0.f, lse_b = 0.f, w_b = 0.f;
@@ -1403,16 +969,8 @@ __global__ __launch_bounds__(256, 2) void infonce_bwd_b3_kernel(
           split3(st[u].z, st[u].w, sb[u][0], sb[u][1], sb[u][2]);
         } else if (k == 2) {
           unsigned char* p = out + row * S::ROWB + c4 * 8;
-          if (H2) {                                  // row-major planes for the score product: hi, scaled residual
-            unsigned h0, l0, h1, l1;
-            split2h(st[u].x * kH2ScaleB, st[u].y * kH2ScaleB, h0, l0);
-            split2h(st[u].z * kH2ScaleB, st[u].w * kH2ScaleB, h1, l1);
-            *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
-            *reinterpret_cast<uint2*>(p + S::PLANE) = make_uint2(l0, l1);
-          } else {
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint2*>(p + pl * S::PLANE) = make_uint2(sa[u][pl], sb[u][pl]);
-          }
+          for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint2*>(p + pl * S::PLANE) = make_uint2(sa[u][pl], sb[u][pl]);
           if (u == 0 && tid < kTileJ) {
             st_lse[cur ^ 1][tid] = st_l;
             st_w[cur ^ 1][tid] = st_w_v;
@@ -1431,37 +989,7 @@ __global__ __launch_bounds__(256, 2) void infonce_bwd_b3_kernel(
       };
       // phase 1: S^T tile (the forward's MFMA order) + staging of the next tile
       f32x16 acc;
-      if (H2) {
-        const unsigned char* base = lds[cur] + i32 * S::ROWB + h * (S::KH * 2);
-        f32x16 lo;
-        u32x4 ap[2][2];
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) ap[0][pl] = *reinterpret_cast<const u32x4*>(base + pl * S::PLANE);
-#pragma unroll
-        for (int c = 0; c < S::KC; ++c) {
-          if (c + 1 < S::KC) {
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl)
-              ap[(c + 1) & 1][pl] = *reinterpret_cast<const u32x4*>(base + pl * S::PLANE + 16 * (c + 1));
-          }
-#pragma unroll
-          for (int term = 0; term < 3; ++term) {          // score_tile_h2's order: lo*hi, hi*lo, hi*hi
-            const int slot = c * 3 + term;
-            f32x16& dst = term == 2 ? acc : lo;
-            f32x16 cin = dst;
-            if (c == 0 && term != 1) {
-#pragma unroll
-              for (int r = 0; r < 16; ++r) cin[r] = 0.f;
-            }
-            dst = mfma_f16(ap[c & 1][term == 0 ? 1 : 0], bq[0][term == 1 ? 1 : 0][c], cin);
-#pragma unroll
-            for (int pi = slot * NP / NS1; pi < (slot + 1) * NP / NS1; ++pi) part(pi);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = fmaf(lo[r], kH2LoInv, acc[r]) * kH2OutInv;
-      } else {
+      {
         const unsigned char* base = lds[cur] + i32 * S::ROWB + h * (S::KH * 2);
         u32x4 ap[2][3];
 #pragma unroll
@@ -1550,7 +1078,6 @@ __global__ __launch_bounds__(256, 2) void infonce_bwd_b3_kernel(
 #pragma unroll
       for (int u = 0; u < S::NLD; ++u) {
         stage_store_b3t_one<D>(lds[0], tid, ra[u], u);
-        if (H2) stage_store_h2_one<D>(lds[0], tid, ra[u], u);     // row-major planes 0 / 1 become hi / residual
       }
       if (tid < kTileJ) {
         st_lse[0][tid] = lse_a;
@@ -1710,83 +1237,36 @@ FwdPlan plan_bwd(int64_t mx, int64_t ny) {
   return plan_bwd_rows(mx, ny, D, BwdShape<D>::ROWS_PER_BLOCK);
 }
 
+int32_t reduce_splits(const FwdPlan& p, const float* gpart, int64_t mx, int d, float* g, hipStream_t s) {
+  if (p.nsplit <= 1) return GCR_OK;
+  const int64_t n4 = mx * d / 4;
+  const int64_t want = (n4 + 255) / 256;
+  hipLaunchKernelGGL(bwd_reduce_kernel, dim3((unsigned)(want > 4096 ? 4096 : want)), dim3(256), 0, s, gpart, p.nsplit,
+                     n4, g);
+  return GCR_LAUNCH_STATUS();
+}
+
 template <int D>
 int32_t launch_bwd(const float* x, const float* x_scale, int64_t mx, const float* y, const float* y_scale, int64_t ny,
                    float inv_tau, const float* lse_x, const float* w_x, const float* lse_y, const float* w_y, float* g,
-                   void* workspace, bool exd, bool unit, hipStream_t s) {
-  if constexpr (D <= 64) {
-    if (use_h2(D, inv_tau, unit)) {
+                   void* workspace, bool exd, bool force_f32, hipStream_t s) {
+  if constexpr (D <= 128) {
+    if (use_b3(D, force_f32)) {
+      // d <= 64: double-buffered, hand-interleaved; d = 128: single-buffered (one tile with its transposed
+      // copy is 54 KB of LDS)
+      constexpr bool ILV = D <= 64;
       const FwdPlan p = plan_bwd_rows(mx, ny, D, BwdB3<D>::ROWS_PER_BLOCK);
       float* gpart = p.nsplit == 1 ? g : reinterpret_cast<float*>(workspace);
+      const dim3 grid((unsigned)(p.m_blocks * p.nsplit));
       if (exd)
-        hipLaunchKernelGGL((infonce_bwd_b3_kernel<D, true, true, true>), dim3((unsigned)(p.m_blocks * p.nsplit)), dim3(256),
-                           0, s, x, x_scale, mx, y, y_scale, ny, inv_tau * kLog2e, inv_tau, lse_x, w_x, lse_y, w_y,
-                           p.nsplit, p.tiles_per_split, gpart);
+        hipLaunchKernelGGL((infonce_bwd_b3_kernel<D, ILV, true>), grid, dim3(256), 0, s, x, x_scale, mx, y, y_scale, ny,
+                           inv_tau * kLog2e, inv_tau, lse_x, w_x, lse_y, w_y, p.nsplit, p.tiles_per_split, gpart);
       else
-        hipLaunchKernelGGL((infonce_bwd_b3_kernel<D, true, false, true>), dim3((unsigned)(p.m_blocks * p.nsplit)),
-                           dim3(256), 0, s, x, x_scale, mx, y, y_scale, ny, inv_tau * kLog2e, inv_tau, lse_x, w_x, lse_y,
-                           w_y, p.nsplit, p.tiles_per_split, gpart);
+        hipLaunchKernelGGL((infonce_bwd_b3_kernel<D, ILV, false>), grid, dim3(256), 0, s, x, x_scale, mx, y, y_scale, ny,
+                           inv_tau * kLog2e, inv_tau, lse_x, w_x, lse_y, w_y, p.nsplit, p.tiles_per_split, gpart);
       int32_t st = GCR_LAUNCH_STATUS();
       if (st != GCR_OK) return st;
-      if (p.nsplit > 1) {
-        const int64_t n4 = mx * D / 4;
-        const int64_t want = (n4 + 255) / 256;
-        hipLaunchKernelGGL(bwd_reduce_kernel, dim3((unsigned)(want > 4096 ? 4096 : want)), dim3(256), 0, s, gpart,
-                           p.nsplit, n4, g);
-        return GCR_LAUNCH_STATUS();
-      }
-      return GCR_OK;
-    }
-    if (use_b3(D)) {
-      const FwdPlan p = plan_bwd_rows(mx, ny, D, BwdB3<D>::ROWS_PER_BLOCK);
-      float* gpart = p.nsplit == 1 ? g : reinterpret_cast<float*>(workspace);
-      const char* ie = getenv("GCR_INFONCE_BWD_ILV");   // A/B knob (d <= 64)
-      if (exd)
-        hipLaunchKernelGGL((infonce_bwd_b3_kernel<D, true, true>), dim3((unsigned)(p.m_blocks * p.nsplit)), dim3(256), 0,
-                           s, x, x_scale, mx, y, y_scale, ny, inv_tau * kLog2e, inv_tau, lse_x, w_x, lse_y, w_y, p.nsplit,
-                           p.tiles_per_split, gpart);
-      else if (ie != nullptr && ie[0] == '0')
-        hipLaunchKernelGGL((infonce_bwd_b3_kernel<D, false>), dim3((unsigned)(p.m_blocks * p.nsplit)), dim3(256), 0, s,
-                           x, x_scale, mx, y, y_scale, ny, inv_tau * kLog2e, inv_tau, lse_x, w_x, lse_y, w_y, p.nsplit,
-                           p.tiles_per_split, gpart);
-      else
-        hipLaunchKernelGGL((infonce_bwd_b3_kernel<D, true>), dim3((unsigned)(p.m_blocks * p.nsplit)), dim3(256), 0, s,
-                           x, x_scale, mx, y, y_scale, ny, inv_tau * kLog2e, inv_tau, lse_x, w_x, lse_y, w_y, p.nsplit,
-                           p.tiles_per_split, gpart);
-      int32_t st = GCR_LAUNCH_STATUS();
-      if (st != GCR_OK) return st;
-      if (p.nsplit > 1) {
-        const int64_t n4 = mx * D / 4;
-        const int64_t want = (n4 + 255) / 256;
-        hipLaunchKernelGGL(bwd_reduce_kernel, dim3((unsigned)(want > 4096 ? 4096 : want)), dim3(256), 0, s, gpart,
-                           p.nsplit, n4, g);
-        return GCR_LAUNCH_STATUS();
-      }
-      return GCR_OK;
-    }
-  }
-  if constexpr (D == 128) {
-    if (use_b3(D)) {                    // single-buffered, un-pipelined variant of the bf16-split backward
-      const FwdPlan p = plan_bwd_rows(mx, ny, D, BwdB3<D>::ROWS_PER_BLOCK);
-      float* gpart = p.nsplit == 1 ? g : reinterpret_cast<float*>(workspace);
-      if (exd)
-        hipLaunchKernelGGL((infonce_bwd_b3_kernel<D, false, true>), dim3((unsigned)(p.m_blocks * p.nsplit)), dim3(256), 0,
-                           s, x, x_scale, mx, y, y_scale, ny, inv_tau * kLog2e, inv_tau, lse_x, w_x, lse_y, w_y, p.nsplit,
-                           p.tiles_per_split, gpart);
-      else
-        hipLaunchKernelGGL((infonce_bwd_b3_kernel<D, false>), dim3((unsigned)(p.m_blocks * p.nsplit)), dim3(256), 0, s,
-                           x, x_scale, mx, y, y_scale, ny, inv_tau * kLog2e, inv_tau, lse_x, w_x, lse_y, w_y, p.nsplit,
-                           p.tiles_per_split, gpart);
-      int32_t st = GCR_LAUNCH_STATUS();
-      if (st != GCR_OK) return st;
-      if (p.nsplit > 1) {
-        const int64_t n4 = mx * D / 4;
-        const int64_t want = (n4 + 255) / 256;
-        hipLaunchKernelGGL(bwd_reduce_kernel, dim3((unsigned)(want > 4096 ? 4096 : want)), dim3(256), 0, s, gpart,
-                           p.nsplit, n4, g);
-        return GCR_LAUNCH_STATUS();
-      }
-      return GCR_OK;
+      return reduce_splits(p, gpart, mx, D, g, s);
     }
   }
   const FwdPlan p = plan_bwd<D>(mx, ny);
@@ -1803,94 +1283,51 @@ int32_t launch_bwd(const float* x, const float* x_scale, int64_t mx, const float
     int32_t st = GCR_LAUNCH_STATUS();
     if (st != GCR_OK) return st;
   }
-  if (p.nsplit > 1) {
-    const int64_t n4 = mx * D / 4;
-    const int64_t want = (n4 + 255) / 256;
-    hipLaunchKernelGGL(bwd_reduce_kernel, dim3((unsigned)(want > 4096 ? 4096 : want)), dim3(256), 0, s, gpart,
-                       p.nsplit, n4, g);
-    return GCR_LAUNCH_STATUS();
-  }
-  return GCR_OK;
+  return reduce_splits(p, gpart, mx, D, g, s);
 }
 
 int anchors_per_block_for(int d) { return d <= 128 ? 256 : 128; }
 
 template <int D>
 int32_t launch_fwd(const float* a, const float* a_scale, int64_t m, const float* b, const float* b_scale, int64_t n,
-                   float inv_tau, float* lse, float* col_sum, float col_bound, void* workspace, bool exd, bool unit,
+                   float inv_tau, float* lse, float* col_sum, float col_bound, void* workspace, bool exd, bool force_f32,
                    hipStream_t s) {
   float2* part = reinterpret_cast<float2*>(workspace);
-  if constexpr (D <= 64) {
-    if (col_sum == nullptr && use_h2(D, inv_tau, unit)) {
-      const FwdPlan p = plan_fwd(m, n, ShapeB3<D>::ANCHORS_PER_BLOCK, 512);
-      const dim3 grid((unsigned)(p.m_blocks * p.nsplit));
-      if (exd)
-        hipLaunchKernelGGL((infonce_fwd_h2_kernel<D, true>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale, n,
-                           inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part);
-      else
-        hipLaunchKernelGGL((infonce_fwd_h2_kernel<D, false>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale, n,
-                           inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part);
-      int32_t st = GCR_LAUNCH_STATUS();
-      if (st != GCR_OK) return st;
-      hipLaunchKernelGGL(infonce_merge_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, part, p.nsplit, m, lse);
-      return GCR_LAUNCH_STATUS();
-    }
-  }
-  if constexpr (D <= 128) {
-    if (use_b3(D)) {
-      const FwdPlan p = plan_fwd(m, n, ShapeB3<D>::ANCHORS_PER_BLOCK, 512);
-      const dim3 grid((unsigned)(p.m_blocks * p.nsplit));
-      const char* pe = getenv("GCR_INFONCE_PIPE");   // A/B knob
-      const bool pipe = !(pe != nullptr && pe[0] == '0');
-      const float cb2 = col_sum != nullptr ? col_bound * kLog2e : 0.f;
-      if (col_sum != nullptr) {
-        hipError_t err = hipMemsetAsync(col_sum, 0, sizeof(float) * (size_t)n, s);
-        if (err != hipSuccess) return gcr_hip_status(err);
-      }
-#define GCR_B3(CS, PP)                                                                                              \
-  hipLaunchKernelGGL((infonce_fwd_b3_kernel<D, CS, PP>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale, n,       \
-                     inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part, col_sum, cb2)
-      const char* me = getenv("GCR_INFONCE_MFMA");    // measurement knob: the 16x16x32 shape
-      if constexpr (D == 64 || D == 32) {
-        if (me != nullptr && me[0] == '1' && me[1] == '6' && !exd && col_sum == nullptr) {
-          hipLaunchKernelGGL((infonce_fwd_b3m16_kernel<D>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale, n,
-                             inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part);
-          int32_t st16 = GCR_LAUNCH_STATUS();
-          if (st16 != GCR_OK) return st16;
-          hipLaunchKernelGGL(infonce_merge_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, part, p.nsplit, m, lse);
-          return GCR_LAUNCH_STATUS();
-        }
-      }
-      if (exd) {
-        hipLaunchKernelGGL((infonce_fwd_b3_kernel<D, false, true, true>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale,
-                           n, inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part, col_sum, cb2);
-      } else if (col_sum != nullptr) {
-        if (pipe) GCR_B3(true, true); else GCR_B3(true, false);
-      } else {
-        if (pipe) GCR_B3(false, true); else GCR_B3(false, false);
-      }
-#undef GCR_B3
-      int32_t st = GCR_LAUNCH_STATUS();
-      if (st != GCR_OK) return st;
-      hipLaunchKernelGGL(infonce_merge_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, part, p.nsplit, m, lse);
-      return GCR_LAUNCH_STATUS();
-    }
-  }
-  const FwdPlan p = plan_fwd(m, n, Shape<D>::ANCHORS_PER_BLOCK, D <= 64 ? 768 : 512);
-  const dim3 grid((unsigned)(p.m_blocks * p.nsplit));
-  const char* fm = getenv("GCR_INFONCE_FORCE_MASK");   // A/B knob
-  const int force_mask = fm != nullptr && fm[0] == '1';
-  if (exd) {
-    hipLaunchKernelGGL((infonce_fwd_kernel<D, false, true>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale, n,
-                       inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part, col_sum, 0.f, force_mask);
-  } else if (col_sum != nullptr) {
+  if (col_sum != nullptr) {
     hipError_t err = hipMemsetAsync(col_sum, 0, sizeof(float) * (size_t)n, s);
     if (err != hipSuccess) return gcr_hip_status(err);
-    hipLaunchKernelGGL((infonce_fwd_kernel<D, true>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale, n,
-                       inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part, col_sum, col_bound * kLog2e, force_mask);
-  } else {
-    hipLaunchKernelGGL((infonce_fwd_kernel<D, false>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale, n,
-                       inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part, col_sum, 0.f, force_mask);
+  }
+  FwdPlan p;
+  bool launched = false;
+  if constexpr (D <= 128) {
+    if (use_b3(D, force_f32)) {
+      p = plan_fwd(m, n, ShapeB3<D>::ANCHORS_PER_BLOCK, 512);
+      const dim3 grid((unsigned)(p.m_blocks * p.nsplit));
+      const float cb2 = col_sum != nullptr ? col_bound * kLog2e : 0.f;
+      if (exd)
+        hipLaunchKernelGGL((infonce_fwd_b3_kernel<D, false, true>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale, n,
+                           inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part, col_sum, cb2);
+      else if (col_sum != nullptr)
+        hipLaunchKernelGGL((infonce_fwd_b3_kernel<D, true, false>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale, n,
+                           inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part, col_sum, cb2);
+      else
+        hipLaunchKernelGGL((infonce_fwd_b3_kernel<D, false, false>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale, n,
+                           inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part, col_sum, cb2);
+      launched = true;
+    }
+  }
+  if (!launched) {
+    p = plan_fwd(m, n, Shape<D>::ANCHORS_PER_BLOCK, D <= 64 ? 768 : 512);
+    const dim3 grid((unsigned)(p.m_blocks * p.nsplit));
+    if (exd)
+      hipLaunchKernelGGL((infonce_fwd_kernel<D, false, true>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale, n,
+                         inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part, col_sum, 0.f);
+    else if (col_sum != nullptr)
+      hipLaunchKernelGGL((infonce_fwd_kernel<D, true>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale, n,
+                         inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part, col_sum, col_bound * kLog2e);
+    else
+      hipLaunchKernelGGL((infonce_fwd_kernel<D, false>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale, n,
+                         inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part, col_sum, 0.f);
   }
   int32_t st = GCR_LAUNCH_STATUS();
   if (st != GCR_OK) return st;
@@ -2325,9 +1762,9 @@ extern "C" int32_t gcr_infonce_fwd_ex_f32(const float* a, const float* a_scale, 
                                           float* col_sum, float col_bound, void* workspace, uint32_t flags,
                                           void* stream) {
   GCR_CHECK_ARG(m >= 0 && n >= 1);
-  GCR_CHECK_ARG((flags & ~(uint32_t)(GCR_INFONCE_EXCLUDE_DIAGONAL | GCR_INFONCE_UNIT_ROWS)) == 0);
+  GCR_CHECK_ARG((flags & ~(uint32_t)(GCR_INFONCE_EXCLUDE_DIAGONAL | GCR_INFONCE_ENGINE_F32)) == 0);
   const bool exd = (flags & GCR_INFONCE_EXCLUDE_DIAGONAL) != 0;
-  const bool unit = (flags & GCR_INFONCE_UNIT_ROWS) != 0;
+  const bool force_f32 = (flags & GCR_INFONCE_ENGINE_F32) != 0;
   GCR_CHECK_ARG(!(exd && col_sum != nullptr));
   if (!dim_supported(d)) return GCR_EUNSUPPORTED;
   if (m == 0) return GCR_OK;
@@ -2335,10 +1772,10 @@ extern "C" int32_t gcr_infonce_fwd_ex_f32(const float* a, const float* a_scale, 
   GCR_CHECK_ARG(m < (1ll << 40) && n < (1ll << 40));
   hipStream_t s = (hipStream_t)stream;
   switch (d) {
-    case 32: return launch_fwd<32>(a, a_scale, m, b, b_scale, n, inv_tau, lse, col_sum, col_bound, workspace, exd, unit, s);
-    case 64: return launch_fwd<64>(a, a_scale, m, b, b_scale, n, inv_tau, lse, col_sum, col_bound, workspace, exd, unit, s);
-    case 128: return launch_fwd<128>(a, a_scale, m, b, b_scale, n, inv_tau, lse, col_sum, col_bound, workspace, exd, unit, s);
-    default: return launch_fwd<256>(a, a_scale, m, b, b_scale, n, inv_tau, lse, col_sum, col_bound, workspace, exd, unit, s);
+    case 32: return launch_fwd<32>(a, a_scale, m, b, b_scale, n, inv_tau, lse, col_sum, col_bound, workspace, exd, force_f32, s);
+    case 64: return launch_fwd<64>(a, a_scale, m, b, b_scale, n, inv_tau, lse, col_sum, col_bound, workspace, exd, force_f32, s);
+    case 128: return launch_fwd<128>(a, a_scale, m, b, b_scale, n, inv_tau, lse, col_sum, col_bound, workspace, exd, force_f32, s);
+    default: return launch_fwd<256>(a, a_scale, m, b, b_scale, n, inv_tau, lse, col_sum, col_bound, workspace, exd, force_f32, s);
   }
 }
 
@@ -2392,9 +1829,9 @@ extern "C" int32_t gcr_infonce_bwd_ex_f32(const float* x, const float* x_scale, 
                                           const float* lse_x, const float* w_x, const float* lse_y, const float* w_y,
                                           float* g, void* workspace, uint32_t flags, void* stream) {
   GCR_CHECK_ARG(mx >= 0 && ny >= 1);
-  GCR_CHECK_ARG((flags & ~(uint32_t)(GCR_INFONCE_EXCLUDE_DIAGONAL | GCR_INFONCE_UNIT_ROWS)) == 0);
+  GCR_CHECK_ARG((flags & ~(uint32_t)(GCR_INFONCE_EXCLUDE_DIAGONAL | GCR_INFONCE_ENGINE_F32)) == 0);
   const bool exd = (flags & GCR_INFONCE_EXCLUDE_DIAGONAL) != 0;
-  const bool unit = (flags & GCR_INFONCE_UNIT_ROWS) != 0;
+  const bool force_f32 = (flags & GCR_INFONCE_ENGINE_F32) != 0;
   if (!dim_supported(d)) return GCR_EUNSUPPORTED;
   if (mx == 0) return GCR_OK;
   GCR_CHECK_ARG(x != nullptr && y != nullptr && g != nullptr);
@@ -2402,10 +1839,10 @@ extern "C" int32_t gcr_infonce_bwd_ex_f32(const float* x, const float* x_scale, 
   GCR_CHECK_ARG(workspace != nullptr || gcr_infonce_bwd_workspace_bytes(mx, ny, d) == 0);
   hipStream_t s = (hipStream_t)stream;
   switch (d) {
-    case 32: return launch_bwd<32>(x, x_scale, mx, y, y_scale, ny, inv_tau, lse_x, w_x, lse_y, w_y, g, workspace, exd, unit, s);
-    case 64: return launch_bwd<64>(x, x_scale, mx, y, y_scale, ny, inv_tau, lse_x, w_x, lse_y, w_y, g, workspace, exd, unit, s);
-    case 128: return launch_bwd<128>(x, x_scale, mx, y, y_scale, ny, inv_tau, lse_x, w_x, lse_y, w_y, g, workspace, exd, unit, s);
-    default: return launch_bwd<256>(x, x_scale, mx, y, y_scale, ny, inv_tau, lse_x, w_x, lse_y, w_y, g, workspace, exd, unit, s);
+    case 32: return launch_bwd<32>(x, x_scale, mx, y, y_scale, ny, inv_tau, lse_x, w_x, lse_y, w_y, g, workspace, exd, force_f32, s);
+    case 64: return launch_bwd<64>(x, x_scale, mx, y, y_scale, ny, inv_tau, lse_x, w_x, lse_y, w_y, g, workspace, exd, force_f32, s);
+    case 128: return launch_bwd<128>(x, x_scale, mx, y, y_scale, ny, inv_tau, lse_x, w_x, lse_y, w_y, g, workspace, exd, force_f32, s);
+    default: return launch_bwd<256>(x, x_scale, mx, y, y_scale, ny, inv_tau, lse_x, w_x, lse_y, w_y, g, workspace, exd, force_f32, s);
   }
 }
 

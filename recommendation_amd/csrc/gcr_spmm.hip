@@ -17,8 +17,6 @@
 //     wave in flight; at 8 waves/SIMD that is >= 128 KiB per CU;
 //   * long rows: chunk partial sums go to a workspace and are added in chunk order by
 //     spmm_long_rows (deterministic; no float atomics).
-#include <stdlib.h>
-
 #include "gcr_common.h"
 
 namespace {
@@ -83,12 +81,11 @@ __global__ __launch_bounds__(256) void spmm_parts(const int64_t* __restrict__ de
                                                   const float* __restrict__ val,
                                                   const uint32_t* __restrict__ keep_bits,
                                                   const float* __restrict__ x, int d, Epilogue ep,
-                                                  float* __restrict__ partials, int xcd_chunk) {
+                                                  float* __restrict__ partials) {
   const int lane = threadIdx.x & 63;
-  // xcd_chunk > 0 (A/B knob GCR_SPMM_XCD=1): workgroups go round-robin over the 8 XCDs; give XCD k the
-  // k-th contiguous eighth of the partitions instead of every eighth block
-  const unsigned blk = xcd_chunk > 0 ? (blockIdx.x % 8u) * (unsigned)xcd_chunk + blockIdx.x / 8u : blockIdx.x;
-  const int64_t part = (int64_t)__builtin_amdgcn_readfirstlane((int)(blk * 4u + (threadIdx.x >> 6)));
+  // workgroups go round-robin over the 8 XCDs, so neighbouring partitions (cheap user rows, expensive item
+  // rows) are mixed on every XCD; giving each XCD one contiguous eighth was measured slower
+  const int64_t part = (int64_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));
   if (part >= n_parts) return;
   const int64_t nnz0 = desc[4 * part + 0];
   const int64_t nnz1 = desc[4 * part + 1];
@@ -247,17 +244,11 @@ int32_t launch_spmm(const int64_t* desc, int64_t n_parts, const int32_t* long_ro
                     int64_t n_long, const int64_t* rowptr, const int32_t* col, const float* val,
                     const uint32_t* keep_bits, const float* x, int d, const Epilogue& ep, float* partials,
                     hipStream_t stream) {
-  unsigned blocks = (unsigned)((n_parts + 3) / 4);
-  const char* xe = getenv("GCR_SPMM_XCD");
-  int xcd_chunk = 0;
-  if (xe != nullptr && xe[0] == '1' && blocks >= 64) {
-    xcd_chunk = (int)((blocks + 7) / 8);
-    blocks = (unsigned)xcd_chunk * 8u;
-  }
+  const unsigned blocks = (unsigned)((n_parts + 3) / 4);
   if (blocks > 0) {
 #define GCR_SPMM_LAUNCH(HV, MK)                                                                             \
   hipLaunchKernelGGL((spmm_parts<NV, D64, HV, MK, unroll_for<NV>()>), dim3(blocks), dim3(256), 0, stream, desc, n_parts, \
-                     rowptr, col, val, keep_bits, x, d, ep, partials, xcd_chunk)
+                     rowptr, col, val, keep_bits, x, d, ep, partials)
     if (val != nullptr) {
       if (keep_bits != nullptr) GCR_SPMM_LAUNCH(true, true);
       else GCR_SPMM_LAUNCH(true, false);

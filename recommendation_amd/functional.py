@@ -471,10 +471,21 @@ def row_inv_norm(x, eps=1e-12):
 
 
 INFONCE_EXCLUDE_DIAGONAL = 1
-INFONCE_UNIT_ROWS = 2
+INFONCE_ENGINE_F32 = 4
+
+# "auto": the library default (split-operand bf16 engine for d <= 128, f32 MFMA for d = 256); "f32": force
+# the f32 MFMA.  Read ONCE per forward (`_resolve_engine`); the backward reuses what the forward ran on.
+INFONCE_ENGINE = "auto"
 
 
-def infonce_lse_raw(a, a_scale, b, b_scale, inv_tau, col_bound=None, exclude_diagonal=False, unit_rows=False):
+def _resolve_engine(engine=None):
+    e = INFONCE_ENGINE if engine is None else engine
+    if e not in ("auto", "f32"):
+        raise ValueError("InfoNCE engine must be 'auto' or 'f32'")
+    return INFONCE_ENGINE_F32 if e == "f32" else 0
+
+
+def infonce_lse_raw(a, a_scale, b, b_scale, inv_tau, col_bound=None, exclude_diagonal=False, engine_flag=None):
     """lse[i] = log sum_j exp(inv_tau * a_scale[i] b_scale[j] <a_i, b_j>) (no autograd).
     col_bound (an upper bound of every logit, e.g. inv_tau for unit rows): also return the column
     logsumexp over the anchors [N] from the same pass (float atomics) as a second value.
@@ -489,7 +500,7 @@ def infonce_lse_raw(a, a_scale, b, b_scale, inv_tau, col_bound=None, exclude_dia
                                         float(inv_tau), _lib.dptr(lse), _lib.dptr(col_sum),
                                         float(col_bound) if col_bound is not None else 0.0, _lib.dptr(ws),
                                         (INFONCE_EXCLUDE_DIAGONAL if exclude_diagonal else 0) |
-                                        (INFONCE_UNIT_ROWS if unit_rows else 0),
+                                        (_resolve_engine() if engine_flag is None else engine_flag),
                                         _lib.cur_stream(a.device)), "gcr_infonce_fwd_ex_f32")
     if col_bound is None:
         return lse
@@ -505,7 +516,7 @@ def pos_logit_raw(a, a_scale, b, b_scale, pos, scale):
     return out
 
 
-def _infonce_bwd_raw(x, x_scale, y, y_scale, inv_tau, lse_x, w_x, lse_y, w_y, exclude_diagonal=False, unit_rows=False):
+def _infonce_bwd_raw(x, x_scale, y, y_scale, inv_tau, lse_x, w_x, lse_y, w_y, exclude_diagonal=False, engine_flag=None):
     """g = inv_tau * sum_j P_ij yhat_j (see gcr_infonce_bwd_f32): gradient w.r.t. the scaled rows of x."""
     L = _lib.lib()
     mx, d = x.shape
@@ -516,16 +527,17 @@ def _infonce_bwd_raw(x, x_scale, y, y_scale, inv_tau, lse_x, w_x, lse_y, w_y, ex
                                         d, float(inv_tau), _lib.dptr(lse_x), _lib.dptr(w_x), _lib.dptr(lse_y),
                                         _lib.dptr(w_y), _lib.dptr(g), _lib.dptr(ws),
                                         (INFONCE_EXCLUDE_DIAGONAL if exclude_diagonal else 0) |
-                                        (INFONCE_UNIT_ROWS if unit_rows else 0), _lib.cur_stream(x.device)),
+                                        (_resolve_engine() if engine_flag is None else engine_flag),
+                                        _lib.cur_stream(x.device)),
                "gcr_infonce_bwd_ex_f32")
     return g
 
 
-def infonce_bwd_pair_raw(a, sa, b, sb, inv_tau, lse_a, w_a, lse_b, w_b, exclude_diagonal=False, unit_rows=False):
+def infonce_bwd_pair_raw(a, sa, b, sb, inv_tau, lse_a, w_a, lse_b, w_b, exclude_diagonal=False, engine_flag=None):
     """Both input gradients of the softmax part: (ga, gb) w.r.t. the scaled rows of a and b.  (lse_a, w_a) is
     the row side (anchors' forward lse and upstream dL/dlse), (lse_b, w_b) the column side; either may be None."""
-    ga = _infonce_bwd_raw(a, sa, b, sb, inv_tau, lse_a, w_a, lse_b, w_b, exclude_diagonal, unit_rows)
-    gb = _infonce_bwd_raw(b, sb, a, sa, inv_tau, lse_b, w_b, lse_a, w_a, exclude_diagonal, unit_rows)
+    ga = _infonce_bwd_raw(a, sa, b, sb, inv_tau, lse_a, w_a, lse_b, w_b, exclude_diagonal, engine_flag)
+    gb = _infonce_bwd_raw(b, sb, a, sa, inv_tau, lse_b, w_b, lse_a, w_a, exclude_diagonal, engine_flag)
     return ga, gb
 
 
@@ -544,17 +556,17 @@ class _InfoNCEStats(torch.autograd.Function):
         # is also the path for un-normalised inputs — and for the split-operand engine, whose MFMA
         # work is cheap enough that the second pass costs no more than the column-sum epilogue
         # (11.6 vs 11.6 ms at 100K x 100K, 0.49 vs 0.65 ms at 20K x 20K; scripts/perf_infonce_sym.py)
-        one_pass = want_col and normalize and inv_tau <= 40.0 and not COL_DETERMINISTIC and not exd and \
-            _lib.lib().gcr_infonce_engine(a_p.shape[1]) == 0
+        eng = _resolve_engine()                  # once per problem: the backward runs on the same engine
+        on_f32 = eng == INFONCE_ENGINE_F32 or _lib.lib().gcr_infonce_engine(a_p.shape[1]) == 0
+        one_pass = want_col and normalize and inv_tau <= 40.0 and not COL_DETERMINISTIC and not exd and on_f32
         if one_pass:
-            lse, col = infonce_lse_raw(a_p, sa, b_p, sb, inv_tau, col_bound=inv_tau * 1.0001)
+            lse, col = infonce_lse_raw(a_p, sa, b_p, sb, inv_tau, col_bound=inv_tau * 1.0001, engine_flag=eng)
         else:
-            # normalised rows are unit rows: the library may then take the two-plane f16 engine
-            lse = infonce_lse_raw(a_p, sa, b_p, sb, inv_tau, exclude_diagonal=exd, unit_rows=normalize)
-            col = infonce_lse_raw(b_p, sb, a_p, sa, inv_tau, exclude_diagonal=exd, unit_rows=normalize) if want_col else None
+            lse = infonce_lse_raw(a_p, sa, b_p, sb, inv_tau, exclude_diagonal=exd, engine_flag=eng)
+            col = infonce_lse_raw(b_p, sb, a_p, sa, inv_tau, exclude_diagonal=exd, engine_flag=eng) if want_col else None
         pl = pos_logit_raw(a_p, sa, b_p, sb, pos, inv_tau)
         ctx.save_for_backward(a_p, b_p, pos, sa, sb, lse, col)
-        ctx.inv_tau, ctx.d, ctx.exd, ctx.unit = inv_tau, a.shape[1], exd, bool(normalize)
+        ctx.inv_tau, ctx.d, ctx.exd, ctx.eng = inv_tau, a.shape[1], exd, eng
         if want_col:
             return lse, pl, col
         return lse, pl
@@ -572,9 +584,9 @@ class _InfoNCEStats(torch.autograd.Function):
         ga = gb = None
         stream = _lib.cur_stream(a.device)
         if need_a:
-            ga = _infonce_bwd_raw(a, sa, b, sb, inv_tau, lse_r, g_lse, col_r, g_col, ctx.exd, ctx.unit)
+            ga = _infonce_bwd_raw(a, sa, b, sb, inv_tau, lse_r, g_lse, col_r, g_col, ctx.exd, ctx.eng)
         if need_b:
-            gb = _infonce_bwd_raw(b, sb, a, sa, inv_tau, col_r, g_col, lse_r, g_lse, ctx.exd, ctx.unit)
+            gb = _infonce_bwd_raw(b, sb, a, sa, inv_tau, col_r, g_col, lse_r, g_lse, ctx.exd, ctx.eng)
         if g_pos is not None and (need_a or need_b):
             _lib.check(L.gcr_infonce_pos_bwd_f32(_lib.dptr(a), _lib.dptr(sa), _lib.dptr(b), _lib.dptr(sb), _lib.dptr(pos),
                                                  _lib.dptr(g_pos.contiguous().float()), a.shape[0], b.shape[0], a.shape[1],

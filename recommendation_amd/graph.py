@@ -12,7 +12,6 @@ partial-sum workspace [n_slots, d].
 from __future__ import annotations
 
 import ctypes
-import os
 
 import numpy as np
 import torch
@@ -48,10 +47,6 @@ class SpmmPlan:
         _lib.check(L.gcr_spmm_plan_fill_host(rowptr_host.ctypes.data, n_rows, nnz_per_part, desc.ctypes.data,
                                              long_row.ctypes.data, long_slot0.ctypes.data), "gcr_spmm_plan_fill_host")
         self.nnz_per_part = nnz_per_part
-        stride = int(os.environ.get("GCR_SPMM_INTERLEAVE", "0"))      # A/B knob: issue order of the partitions
-        if stride > 1 and self.n_parts > stride:
-            order = np.argsort(np.arange(self.n_parts) % stride, kind="stable")
-            desc[: self.n_parts] = desc[: self.n_parts][order]
         self.desc_host = desc[: self.n_parts]
         self.desc = torch.from_numpy(desc).to(device)
         self.long_row = torch.from_numpy(long_row).to(device)

@@ -57,8 +57,12 @@ class NCLModel:
             if user_emb is None or item_emb is None:
                 user_emb, item_emb, _ = self.model()
             user_emb, item_emb = user_emb.detach(), item_emb.detach()
+            # ncl.py:350-351 clamps `self.k = min(self.k, max(2, n // 39))` and KEEPS it: the item k-means
+            # inherits the users' clamp and, from the second e_step on, the users inherit the items'
             self.user_centroids, self.user_2cluster = run_kmeans(user_emb.contiguous(), self.k, seed=self.seed)
+            self.k = int(self.user_centroids.shape[0])
             self.item_centroids, self.item_2cluster = run_kmeans(item_emb.contiguous(), self.k, seed=self.seed + 1)
+            self.k = int(self.item_centroids.shape[0])
 
     # ncl.py:358-367
     def ssl_layer_loss(self, context, initial, user, item):
@@ -71,8 +75,12 @@ class NCLModel:
                                 self.proto_reg, self.batch_size)
 
     def train_step(self, batch, optimizer):
-        """One iteration of the loop body ncl.py:311-329."""
+        """One iteration of the loop body ncl.py:311-329.  A batch with an unfilled negative slot (-1, the
+        sampler's 100-trial bail-out) is skipped like the reference does (ncl.py:113: it is never yielded);
+        returns None then."""
         user_idx, pos_idx, neg_idx = batch
+        if bool((torch.as_tensor(neg_idx) < 0).any()):
+            return None
         rec_user_emb, rec_item_emb, emb_list = self.model()
         user_emb, pos_emb, neg_emb = rec_user_emb[user_idx], rec_item_emb[pos_idx], rec_item_emb[neg_idx]
         rec_loss = Ls.bpr_loss(user_emb, pos_emb, neg_emb)
@@ -94,10 +102,10 @@ class NCLModel:
             self.e_step()
             batches = next_batch_pairwise(self.data, self.batch_size, seed=self.seed, epoch=epoch)
             for n, batch in enumerate(batches):
-                rec, ssl, proto, total = self.train_step(batch, optimizer)
-                if (n + 1) % 100 == 0:
-                    print(f"Batch {n + 1}: Rec_loss={rec.item():.4f}, ssl_loss={ssl.item():.4f}, "
-                          f"Proto_loss={proto.item():.4f}, Total_loss={total.item():.4f}")
+                out = self.train_step(batch, optimizer)
+                if out is not None and n % 100 == 99:
+                    names = ("Rec_loss", "ssl_loss", "Proto_loss", "Total_loss")
+                    print(f"Batch {n + 1}: " + ", ".join(f"{k}={float(v):.4f}" for k, v in zip(names, out)))
         self.model.eval()
         with torch.no_grad():
             self.user_emb, self.item_emb, _ = self.model()
@@ -110,7 +118,12 @@ class NCLModel:
         metrics = ranking_evaluation(self.data.test_set, self.test(), self.topN)
         print("Detailed TopN Evaluation :")
         print("".join(metrics))
-        return {k: float(v) for m in metrics[1:] if ":" in m for k, v in [m.split(":", 1)]}
+        result = {}
+        for line in metrics[1:]:          # "Hit Ratio:0.1234\n" ... of the last cut-off, as the reference returns
+            name, sep, value = line.partition(":")
+            if sep:
+                result[name] = float(value)
+        return result
 
     def predict(self, u):
         uid = self.data.get_user_id(u)

@@ -26,7 +26,7 @@ for (m, d) in [(100_000, 64), (20_000, 64)]:
     res = {}
     for rnd in range(5):
         for eng in ("f32", "b3"):
-            os.environ["GCR_INFONCE_ENGINE"] = eng
+            Fn.INFONCE_ENGINE = "f32" if eng == "f32" else "auto"
             for name, fn in (("one-pass", one), ("two-pass", two)):
                 if rnd == 0:
                     out = fn()

@@ -255,12 +255,24 @@ def infonce_roofline(Fn, x0, n_u, dev):
     lse = Fn.infonce_lse_raw(anchors, sa, table, sb, inv_tau)
     w = torch.ones(m, device=dev)
     t_f = _event_ms(lambda: Fn.infonce_lse_raw(anchors, sa, table, sb, inv_tau), 10)
-    t_b = _event_ms(lambda: Fn.infonce_bwd_pair_raw(anchors, sa, table, sb, inv_tau, lse, w, None, None), 5)
     flops = 2.0 * m * n_u * d
     from recommendation_amd import _lib
     engine = int(_lib.lib().gcr_infonce_engine(d))
     mult = 6 if engine == 1 else 1                       # bf16 split: six bf16 MFMA products per f32 product
     peak = BF16_MFMA_PEAK_TF if engine == 1 else FP32_MFMA_PEAK_TF
+
+    def leg(kernel, t_ms, units):
+        return {"kernel": kernel, "avg_launch_ms": round(t_ms, 4), "flops_alg_per_launch": units * flops,
+                "achieved_alg": round(units * flops / t_ms / 1e9, 1), "achieved": round(mult * units * flops / t_ms / 1e9, 1),
+                "frac": round(mult * units * flops / t_ms / 1e9 / peak, 4), "mfma_busy_pct": None}
+
+    # training path of a row-softmax loss (ncl.py:358-367): flash-style forward (lse + weighted row sum, the
+    # anchor-side gradient is a scale of it) and ONE backward launch for the table side
+    t_b = _event_ms(lambda: Fn._infonce_bwd_raw(table, sb, anchors, sa, inv_tau, None, None, lse, w), 5)
+    fwd_o = None
+    if Fn.infonce_fwd_o_supported(d):
+        t_fo = _event_ms(lambda: Fn.infonce_fwd_o_raw(anchors, sa, table, sb, inv_tau), 5)
+        fwd_o = leg("infonce_fwdo_b3_kernel<64> (score + softmax-weighted row sum, 2 MFMA products per pair)", t_fo, 2)
     out = {
         "bound": "mfma", "kernel": "infonce_fwd_b3_kernel<64>" if engine == 1 else "infonce_fwd_kernel<64>",
         "engine": "split-operand bf16 MFMA (3 planes per f32 operand, 6 products per f32 product, f32 accumulate)"
@@ -271,15 +283,15 @@ def infonce_roofline(Fn, x0, n_u, dev):
         "peak": peak, "unit": "TFLOP/s", "frac": round(mult * flops / t_f / 1e9 / peak, 4),
         "note": "achieved = MFMA flops issued (6 x algorithmic on the bf16 split) / launch time; peak = dense bf16 MFMA",
         "mfma_busy_pct": None,
-        "bwd": {"kernel": "infonce_bwd2 (both input gradients from one recomputed score tile)",
-                "avg_launch_ms": round(t_b, 4), "flops_alg_per_launch": 3 * flops,
-                "achieved_alg": round(3 * flops / t_b / 1e9, 1), "achieved": round(mult * 3 * flops / t_b / 1e9, 1),
-                "frac": round(mult * 3 * flops / t_b / 1e9 / peak, 4), "mfma_busy_pct": None},
+        "fwd_o": fwd_o,
+        "bwd": leg("infonce_bwd_b3_kernel<64> (table-side gradient: score recomputed once + one product)", t_b, 2),
     }
     pmc = _committed_pmc("infonce", infonce_source_digest())
     if pmc:
         out["mfma_busy_pct"] = pmc.get("fwd_mfma_busy_pct")
         out["bwd"]["mfma_busy_pct"] = pmc.get("bwd_mfma_busy_pct")
+        if out["fwd_o"] is not None:
+            out["fwd_o"]["mfma_busy_pct"] = pmc.get("fwdo_mfma_busy_pct")
         out["mfma_busy_source"] = pmc.get("source")
     return out
 

@@ -226,6 +226,23 @@ int32_t gcr_infonce_fwd_ex_f32(const float* a, const float* a_scale, int64_t m,
                                void* workspace, uint32_t flags, void* stream);
 
 /*
+ * Forward WITH the softmax-weighted row sum (flash-attention forward), one pass:
+ *   lse[i] = log sum_j exp(s_ij),    o[i, :] = sum_j exp(s_ij - lse[i]) * (b_scale[j] * b_j)      o: [m, d]
+ * For the row-softmax losses (ncl.py:125-130 InfoNCE, ncl.py:358-375 ssl_layer_loss / ProtoNCE_loss,
+ * ssl4rec.py:25-30) the gradient w.r.t. the scaled anchor row is  dL/dlse[i] * inv_tau * o[i, :]  (plus the
+ * positive-logit term), so training needs no backward pass over the M x N tile for the anchor side: the
+ * backward (gcr_infonce_bwd_f32 with the table stationary) recomputes the score tile once, not twice.
+ * Split-operand engine only: d in {32, 64, 128} and no GCR_INFONCE_ENGINE_F32 (gcr_infonce_fwd_o_supported
+ * tells; GCR_EUNSUPPORTED otherwise — the caller then uses gcr_infonce_fwd_ex_f32 + two backward calls).
+ * flags: GCR_INFONCE_EXCLUDE_DIAGONAL as above.
+ */
+int32_t gcr_infonce_fwd_o_supported(int32_t d, uint32_t flags);
+int64_t gcr_infonce_fwd_o_workspace_bytes(int64_t m, int64_t n, int32_t d);
+int32_t gcr_infonce_fwd_o_f32(const float* a, const float* a_scale, int64_t m,
+                              const float* b, const float* b_scale, int64_t n, int32_t d,
+                              float inv_tau, float* lse, float* o, void* workspace, uint32_t flags, void* stream);
+
+/*
  * out[i] = scale * a_scale[i] * b_scale[p] * <a_i, b_p>, p = pos[i] (pos == NULL: p = i) — the
  * positive logit (the diagonal of ncl.py:129 / gcl.py:32-34, `(norm_cu * norm_iu).sum(1) / t`
  * ncl.py:363).  An out-of-range pos yields NaN for that row.  Any d.

@@ -138,10 +138,12 @@ if pmc:
     info_path = os.path.join(root, "gpurun_out", "pmc_probe_infonce.json")
     if util and os.path.exists(info_path):
         info = json.load(open(info_path))
-        fwd = [v for k, v in util.items() if "infonce_fwd" in k]
+        fwd = [v for k, v in util.items() if "infonce_fwd_" in k]
+        fwdo = [v for k, v in util.items() if "infonce_fwdo_" in k]
         bwd = [v for k, v in util.items() if "infonce_bwd" in k]
         traffic["infonce"] = {
             "fwd_mfma_busy_pct": round(max(fwd), 1) if fwd else None, "bwd_mfma_busy_pct": round(max(bwd), 1) if bwd else None,
+            "fwdo_mfma_busy_pct": round(max(fwdo), 1) if fwdo else None,
             "per_kernel": {k: round(v, 1) for k, v in util.items()}, "shape": info.get("shape"),
             "source_digest": info["source_digest"], "git_sha": sha, "git_dirty_at_summarise": dirty,
             "source": f"profiles/{tag}_infonce_pmc_mfma.csv (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE, "

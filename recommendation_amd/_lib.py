@@ -43,6 +43,9 @@ SIGNATURES = {
     "gcr_infonce_fwd_workspace_bytes": (c_int64, [c_int64, c_int64, c_int32]),
     "gcr_infonce_fwd_f32": (c_int32, [_P, _P, c_int64, _P, _P, c_int64, c_int32, c_float, _P, _P, c_float, _P, _P]),
     "gcr_infonce_fwd_ex_f32": (c_int32, [_P, _P, c_int64, _P, _P, c_int64, c_int32, c_float, _P, _P, c_float, _P, c_uint32, _P]),
+    "gcr_infonce_fwd_o_supported": (c_int32, [c_int32, c_uint32]),
+    "gcr_infonce_fwd_o_workspace_bytes": (c_int64, [c_int64, c_int64, c_int32]),
+    "gcr_infonce_fwd_o_f32": (c_int32, [_P, _P, c_int64, _P, _P, c_int64, c_int32, c_float, _P, _P, _P, c_uint32, _P]),
     "gcr_pos_logit_f32": (c_int32, [_P, _P, _P, _P, _P, c_int64, c_int64, c_int32, c_float, _P, _P]),
     "gcr_infonce_bwd_workspace_bytes": (c_int64, [c_int64, c_int64, c_int32]),
     "gcr_infonce_bwd_f32": (c_int32, [_P, _P, c_int64, _P, _P, c_int64, c_int32, c_float, _P, _P, _P, _P, _P, _P, _P]),

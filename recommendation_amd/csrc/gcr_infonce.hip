@@ -1174,6 +1174,296 @@ __global__ __launch_bounds__(256, 2) void infonce_bwd_b3_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Forward WITH the softmax-weighted row sum ("fwd_o", flash-attention forward):
+//   lse[i] = log sum_j exp(s_ij),   o[i, :] = sum_j softmax_j(s_i.)_j * yhat_j
+// in one pass over the streamed rows (online max, deferred rescale).  For a row-softmax loss the
+// gradient w.r.t. the stationary side is then  dL/dxhat_i = dL/dlse_i * inv_tau * o[i, :]  — no
+// backward pass over the M x N tile for that side; the backward recomputes the score tile ONCE
+// (streamed-side gradient) instead of twice.  Same tile engine as infonce_bwd_b3_kernel: score
+// MFMAs in the forward's order (bitwise the forward's logits), P split in registers, second product
+// against the transposed planes.  The two lane halves of a stationary row hold different streamed
+// rows of the same k-chunk, so they share one running maximum (one cross-half shuffle per tile).
+// Rescaling the accumulators is deferred while no logit exceeds the reference point by more than
+// 2^kDefer (wave-uniform branch): after the first tiles it almost never runs.
+// ------------------------------------------------------------------------------------------
+constexpr float kDefer = 8.0f;
+
+template <int D, bool ILV, bool EXD = false>
+__global__ __launch_bounds__(256, 2) void infonce_fwdo_b3_kernel(
+    const float* __restrict__ x, const float* __restrict__ x_scale, int64_t mx, const float* __restrict__ y,
+    const float* __restrict__ y_scale, int64_t ny, float scale2, int nsplit, int64_t tiles_per_split,
+    float2* __restrict__ part, float* __restrict__ opart) {
+  using S = ShapeB3<D>;
+  using B = BwdB3<D>;
+  constexpr int NBUF = D <= 64 ? 2 : 1;
+  static_assert(NBUF == 2 || !ILV, "the interleaved loop is double-buffered");
+  __shared__ __align__(16) unsigned char lds[NBUF][B::TILE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i32 = lane & 31, h = lane >> 5;
+  const int64_t mblk = blockIdx.x / nsplit;
+  const int split = blockIdx.x % nsplit;
+  const int64_t row_i = (mblk * 4 + wave) * 32 + i32;
+
+  u32x4 bq[1][3][S::KC];
+  load_stationary_b3<D>(x, x_scale, mx, row_i, h, scale2, bq[0]);
+  float m_run = kNegBig, l_run = 0.f;
+  f32x16 gacc[B::CT];
+#pragma unroll
+  for (int c = 0; c < B::CT; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gacc[c][r] = 0.f;
+
+  const int64_t total_tiles = (ny + kTileJ - 1) / kTileJ;
+  const int64_t tile0 = (int64_t)split * tiles_per_split;
+  const int64_t tile1 = min(total_tiles, tile0 + tiles_per_split);
+
+  // scores (log2 domain) -> un-normalised probabilities relative to the running reference point
+  auto softmax_p = [&](f32x16& acc, int64_t tt) {
+    const int64_t j0 = tt * kTileJ;
+    if (EXD || j0 + kTileJ > ny) {                       // wave-uniform: ragged last tile / excluded diagonal
+      const int xr = EXD ? diag_offset(row_i, j0, h) : -1;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          const bool dead = (j0 + acc_row(r, h) >= ny) || (EXD && xr == e + 8 * g);
+          acc[r] = dead ? -INFINITY : acc[r];
+        }
+    }
+    float tmax = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
+#pragma unroll
+    for (int g = 1; g < 4; ++g)
+      tmax = fmaxf(tmax, fmaxf(fmaxf(acc[4 * g], acc[4 * g + 1]), fmaxf(acc[4 * g + 2], acc[4 * g + 3])));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));        // both halves of a stationary row agree
+    if (__any(tmax > m_run + kDefer)) {
+      const float m_new = fmaxf(m_run, tmax);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+#pragma unroll
+      for (int c = 0; c < B::CT; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gacc[c][r] *= alpha;
+      m_run = m_new;
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc[r] = __builtin_amdgcn_exp2f(acc[r] - m_run);
+      sum += acc[r];
+    }
+    l_run += sum;
+  };
+
+  if constexpr (ILV) {
+    constexpr int NP = 4 * S::NLD, NS1 = 6 * S::KC, NG = B::CT * 6;
+    constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+    float4 ra[S::NLD], rb[S::NLD];
+    const int64_t last = tile1 - 1;
+    auto load_tile = [&](int64_t t, float4 (&r)[S::NLD]) { stage_load<D>(y, y_scale, ny, min(t, last) * kTileJ, tid, r); };
+    auto step = [&](int64_t tt, int cur, const float4 (&st)[S::NLD], float4 (&ld)[S::NLD]) {
+      load_tile(tt + 2, ld);
+      unsigned char* out = lds[cur ^ 1];
+      unsigned sa[S::NLD][3], sb[S::NLD][3];
+      auto stage_part = [&](int pi) {
+        const int u = pi / 4, k = pi % 4;
+        const int idx = tid + 256 * u;
+        const int row = idx / (D / 4), c4 = idx % (D / 4);
+        if (k == 0) {
+          split3(st[u].x, st[u].y, sa[u][0], sa[u][1], sa[u][2]);
+        } else if (k == 1) {
+          split3(st[u].z, st[u].w, sb[u][0], sb[u][1], sb[u][2]);
+        } else if (k == 2) {
+          unsigned char* p = out + row * S::ROWB + c4 * 8;
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint2*>(p + pl * S::PLANE) = make_uint2(sa[u][pl], sb[u][pl]);
+        } else {
+          unsigned short* q = reinterpret_cast<unsigned short*>(out + 3 * S::PLANE + (4 * c4) * B::RT + row * 2);
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {
+            unsigned short* qq = q + pl * (B::TPLANE / 2);
+            qq[0] = (unsigned short)(sa[u][pl] & 0xffffu);
+            qq[B::RT / 2] = (unsigned short)(sa[u][pl] >> 16);
+            qq[2 * (B::RT / 2)] = (unsigned short)(sb[u][pl] & 0xffffu);
+            qq[3 * (B::RT / 2)] = (unsigned short)(sb[u][pl] >> 16);
+          }
+        }
+      };
+      // phase 1: S^T tile (the forward's MFMA order) + staging of the next tile
+      f32x16 acc;
+      {
+        const unsigned char* base = lds[cur] + i32 * S::ROWB + h * (S::KH * 2);
+        u32x4 ap[2][3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) ap[0][pl] = *reinterpret_cast<const u32x4*>(base + pl * S::PLANE);
+#pragma unroll
+        for (int c = 0; c < S::KC; ++c) {
+          if (c + 1 < S::KC) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+              ap[(c + 1) & 1][pl] = *reinterpret_cast<const u32x4*>(base + pl * S::PLANE + 16 * (c + 1));
+          }
+#pragma unroll
+          for (int term = 0; term < 6; ++term) {
+            const int slot = c * 6 + term;
+            f32x16 cin = acc;
+            if (slot == 0) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) cin[r] = 0.f;
+            }
+            acc = mfma_bf16(ap[c & 1][TA[term]], bq[0][TB[term]][c], cin);
+#pragma unroll
+            for (int pi = slot * NP / NS1; pi < (slot + 1) * NP / NS1; ++pi) stage_part(pi);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+      // phase 2: online softmax, first half of P split
+      softmax_p(acc, tt);
+      unsigned pq[2][3][4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) split3(acc[2 * e], acc[2 * e + 1], pq[0][0][e], pq[0][1][e], pq[0][2][e]);
+      __builtin_amdgcn_sched_barrier(0);
+      // phase 3: O^T[c][i] += yhat[j][c] * P[j][i]
+      const unsigned char* tbase = lds[cur] + 3 * S::PLANE + i32 * B::RT + 8 * h;
+      auto load_ya = [&](int grp, u32x4 (&ya)[3]) {     // grp = kc * CT + c
+        const int kc = grp / B::CT, c = grp % B::CT;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          const unsigned char* p = tbase + pl * B::TPLANE + (32 * c) * B::RT + 32 * kc;
+          const uint2 lo = *reinterpret_cast<const uint2*>(p);
+          const uint2 hi = *reinterpret_cast<const uint2*>(p + 16);
+          ya[pl] = (u32x4){lo.x, lo.y, hi.x, hi.y};
+        }
+      };
+      u32x4 ya[2][3];
+      load_ya(0, ya[0]);
+#pragma unroll
+      for (int grp = 0; grp < 2 * B::CT; ++grp) {
+        const int kc = grp / B::CT, c = grp % B::CT;
+        if (grp + 1 < 2 * B::CT) load_ya(grp + 1, ya[(grp + 1) & 1]);
+        u32x4 pp[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) pp[pl] = (u32x4){pq[kc][pl][0], pq[kc][pl][1], pq[kc][pl][2], pq[kc][pl][3]};
+#pragma unroll
+        for (int term = 0; term < 6; ++term) {
+          gacc[c] = mfma_bf16(ya[grp & 1][TA[term]], pp[TB[term]], gacc[c]);
+          if (kc == 0) {                                   // split of rows 16-31 under the MFMAs of rows 0-15
+            const int slot = c * 6 + term;
+#pragma unroll
+            for (int e = slot * 4 / NG; e < (slot + 1) * 4 / NG; ++e)
+              split3(acc[8 + 2 * e], acc[8 + 2 * e + 1], pq[1][0][e], pq[1][1][e], pq[1][2][e]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __syncthreads();
+    };
+    if (tile0 < tile1) {
+      load_tile(tile0, ra);
+#pragma unroll
+      for (int u = 0; u < S::NLD; ++u) stage_store_b3t_one<D>(lds[0], tid, ra[u], u);
+      load_tile(tile0 + 1, ra);
+    }
+    __syncthreads();
+    for (int64_t tt = tile0; tt < tile1; tt += 2) {
+      step(tt, 0, ra, rb);
+      if (tt + 1 < tile1) step(tt + 1, 1, rb, ra);
+    }
+  } else {
+    float4 regs[S::NLD];
+    if (tile0 < tile1) {
+      stage_load<D>(y, y_scale, ny, tile0 * kTileJ, tid, regs);
+#pragma unroll
+      for (int u = 0; u < S::NLD; ++u) stage_store_b3t_one<D>(lds[0], tid, regs[u], u);
+    }
+    __syncthreads();
+    for (int64_t tt = tile0; tt < tile1; ++tt) {
+      const int cur = (int)((tt - tile0) & 1);
+      const bool more = tt + 1 < tile1;
+      if (more) stage_load<D>(y, y_scale, ny, (tt + 1) * kTileJ, tid, regs);
+      f32x16 acc[1];
+      score_tile_b3<D, 1>(lds[cur % NBUF], i32, h, bq, acc);
+      softmax_p(acc[0], tt);
+      const unsigned char* tbase = lds[cur % NBUF] + 3 * S::PLANE + i32 * B::RT + 8 * h;
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc) {
+        u32x4 pp[3];
+        {
+          unsigned q[3][4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) split3(acc[0][8 * kc + 2 * e], acc[0][8 * kc + 2 * e + 1], q[0][e], q[1][e], q[2][e]);
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) pp[pl] = (u32x4){q[pl][0], q[pl][1], q[pl][2], q[pl][3]};
+        }
+#pragma unroll
+        for (int c = 0; c < B::CT; ++c) {
+          u32x4 ya[3];
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {
+            const unsigned char* p = tbase + pl * B::TPLANE + (32 * c) * B::RT + 32 * kc;
+            const uint2 lo = *reinterpret_cast<const uint2*>(p);
+            const uint2 hi = *reinterpret_cast<const uint2*>(p + 16);
+            ya[pl] = (u32x4){lo.x, lo.y, hi.x, hi.y};
+          }
+          gacc[c] = mfma_bf16(ya[2], pp[0], gacc[c]);
+          gacc[c] = mfma_bf16(ya[0], pp[2], gacc[c]);
+          gacc[c] = mfma_bf16(ya[1], pp[1], gacc[c]);
+          gacc[c] = mfma_bf16(ya[1], pp[0], gacc[c]);
+          gacc[c] = mfma_bf16(ya[0], pp[1], gacc[c]);
+          gacc[c] = mfma_bf16(ya[0], pp[0], gacc[c]);
+        }
+      }
+      if (NBUF == 1) __syncthreads();          // every wave is done reading the only buffer
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < S::NLD; ++u) stage_store_b3t_one<D>(lds[(cur ^ 1) % NBUF], tid, regs[u], u);
+      }
+      __syncthreads();
+    }
+  }
+
+  // per-split partial: (reference point, sum of both halves) and the un-normalised O rows
+  const float l_o = __shfl_xor(l_run, 32, 64);
+  if (h == 0 && row_i < mx) part[(int64_t)split * mx + row_i] = make_float2(m_run, l_run + l_o);
+  float* gout = opart + (int64_t)split * mx * D;
+  if (row_i < mx) {
+#pragma unroll
+    for (int c = 0; c < B::CT; ++c)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 v = make_float4(gacc[c][4 * g + 0], gacc[c][4 * g + 1], gacc[c][4 * g + 2], gacc[c][4 * g + 3]);
+        *reinterpret_cast<float4*>(gout + row_i * D + 32 * c + 8 * g + 4 * h) = v;
+      }
+  }
+}
+
+// lse and o from the per-split partials: o = sum_s O_s 2^(m_s - m) / sum_s l_s 2^(m_s - m)
+__global__ __launch_bounds__(256) void infonce_merge_o_kernel(const float2* __restrict__ part, const float* __restrict__ opart,
+                                                              int nsplit, int64_t m_rows, int d, float* __restrict__ lse,
+                                                              float* __restrict__ o) {
+  const int d4 = d / 4;
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= m_rows * d4) return;
+  const int64_t i = k / d4;
+  const int c = (int)(k % d4);
+  float m = kNegBig;
+  for (int s = 0; s < nsplit; ++s) m = fmaxf(m, part[(int64_t)s * m_rows + i].x);
+  float l = 0.f;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s = 0; s < nsplit; ++s) {
+    const float2 p = part[(int64_t)s * m_rows + i];
+    const float w = __builtin_amdgcn_exp2f(p.x - m);
+    l += p.y * w;
+    const float4 v = reinterpret_cast<const float4*>(opart)[((int64_t)s * m_rows + i) * d4 + c];
+    acc.x += v.x * w; acc.y += v.y * w; acc.z += v.z * w; acc.w += v.w * w;
+  }
+  const float inv = l > 0.f ? 1.0f / l : 0.f;
+  reinterpret_cast<float4*>(o)[i * d4 + c] = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+  if (c == 0) lse[i] = (m + __log2f(l)) * kLn2;
+}
+
 // g[i, :] = sum over splits (fixed order) of the partial gradients
 __global__ __launch_bounds__(256) void bwd_reduce_kernel(const float* __restrict__ gpart, int nsplit, int64_t n4,
                                                          float* __restrict__ g) {
@@ -1332,6 +1622,29 @@ int32_t launch_fwd(const float* a, const float* a_scale, int64_t m, const float*
   int32_t st = GCR_LAUNCH_STATUS();
   if (st != GCR_OK) return st;
   hipLaunchKernelGGL(infonce_merge_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, part, p.nsplit, m, lse);
+  return GCR_LAUNCH_STATUS();
+}
+
+
+template <int D>
+int32_t launch_fwd_o(const float* a, const float* a_scale, int64_t m, const float* b, const float* b_scale, int64_t n,
+                     float inv_tau, float* lse, float* o, void* workspace, bool exd, hipStream_t s) {
+  constexpr bool ILV = D <= 64;
+  const FwdPlan p = plan_bwd_rows(m, n, D, BwdB3<D>::ROWS_PER_BLOCK);
+  float2* part = reinterpret_cast<float2*>(workspace);
+  float* opart = reinterpret_cast<float*>(part + (int64_t)p.nsplit * m);
+  const dim3 grid((unsigned)(p.m_blocks * p.nsplit));
+  if (exd)
+    hipLaunchKernelGGL((infonce_fwdo_b3_kernel<D, ILV, true>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale, n,
+                       inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part, opart);
+  else
+    hipLaunchKernelGGL((infonce_fwdo_b3_kernel<D, ILV, false>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale, n,
+                       inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part, opart);
+  int32_t st = GCR_LAUNCH_STATUS();
+  if (st != GCR_OK) return st;
+  const int64_t threads = m * (D / 4);
+  hipLaunchKernelGGL(infonce_merge_o_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, part, opart,
+                     p.nsplit, m, D, lse, o);
   return GCR_LAUNCH_STATUS();
 }
 
@@ -1776,6 +2089,33 @@ extern "C" int32_t gcr_infonce_fwd_ex_f32(const float* a, const float* a_scale, 
     case 64: return launch_fwd<64>(a, a_scale, m, b, b_scale, n, inv_tau, lse, col_sum, col_bound, workspace, exd, force_f32, s);
     case 128: return launch_fwd<128>(a, a_scale, m, b, b_scale, n, inv_tau, lse, col_sum, col_bound, workspace, exd, force_f32, s);
     default: return launch_fwd<256>(a, a_scale, m, b, b_scale, n, inv_tau, lse, col_sum, col_bound, workspace, exd, force_f32, s);
+  }
+}
+
+extern "C" int32_t gcr_infonce_fwd_o_supported(int32_t d, uint32_t flags) {
+  return (d == 32 || d == 64 || d == 128) && use_b3(d, (flags & GCR_INFONCE_ENGINE_F32) != 0) ? 1 : 0;
+}
+
+extern "C" int64_t gcr_infonce_fwd_o_workspace_bytes(int64_t m, int64_t n, int32_t d) {
+  if (m <= 0 || n <= 0 || !gcr_infonce_fwd_o_supported(d, 0)) return 0;
+  const FwdPlan p = plan_bwd_rows(m, n, d, 128);
+  return (int64_t)p.nsplit * m * ((int64_t)sizeof(float2) + (int64_t)d * (int64_t)sizeof(float));
+}
+
+extern "C" int32_t gcr_infonce_fwd_o_f32(const float* a, const float* a_scale, int64_t m, const float* b,
+                                         const float* b_scale, int64_t n, int32_t d, float inv_tau, float* lse,
+                                         float* o, void* workspace, uint32_t flags, void* stream) {
+  GCR_CHECK_ARG(m >= 0 && n >= 1);
+  GCR_CHECK_ARG((flags & ~(uint32_t)(GCR_INFONCE_EXCLUDE_DIAGONAL | GCR_INFONCE_ENGINE_F32)) == 0);
+  if (!gcr_infonce_fwd_o_supported(d, flags)) return GCR_EUNSUPPORTED;
+  if (m == 0) return GCR_OK;
+  GCR_CHECK_ARG(a != nullptr && b != nullptr && lse != nullptr && o != nullptr && workspace != nullptr);
+  const bool exd = (flags & GCR_INFONCE_EXCLUDE_DIAGONAL) != 0;
+  hipStream_t s = (hipStream_t)stream;
+  switch (d) {
+    case 32: return launch_fwd_o<32>(a, a_scale, m, b, b_scale, n, inv_tau, lse, o, workspace, exd, s);
+    case 64: return launch_fwd_o<64>(a, a_scale, m, b, b_scale, n, inv_tau, lse, o, workspace, exd, s);
+    default: return launch_fwd_o<128>(a, a_scale, m, b, b_scale, n, inv_tau, lse, o, workspace, exd, s);
   }
 }
 

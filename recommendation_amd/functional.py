@@ -507,6 +507,33 @@ def infonce_lse_raw(a, a_scale, b, b_scale, inv_tau, col_bound=None, exclude_dia
     return lse, torch.log(col_sum) + float(col_bound)
 
 
+# True: a row-softmax problem whose anchors need a gradient runs the flash-style forward (lse AND the
+# softmax-weighted row sum o in one pass, gcr_infonce_fwd_o_f32): the anchor-side gradient is then
+# dL/dlse * inv_tau * o and the backward recomputes the score tile once (table side) instead of twice.
+FWD_O = True
+
+
+def infonce_fwd_o_supported(d, engine_flag=0):
+    return bool(_lib.lib().gcr_infonce_fwd_o_supported(int(d), int(engine_flag)))
+
+
+def infonce_fwd_o_raw(a, a_scale, b, b_scale, inv_tau, exclude_diagonal=False, engine_flag=None):
+    """(lse [M], o [M, d]): lse[i] = log sum_j exp(s_ij), o[i] = sum_j softmax(s_i.)_j * (b_scale[j] b_j)
+    (no autograd)."""
+    L = _lib.lib()
+    m, d = a.shape
+    n = b.shape[0]
+    lse = torch.empty(m, dtype=torch.float32, device=a.device)
+    o = torch.empty(m, d, dtype=torch.float32, device=a.device)
+    ws = torch.empty(max(int(L.gcr_infonce_fwd_o_workspace_bytes(m, n, d)), 8) // 4, dtype=torch.float32, device=a.device)
+    _lib.check(L.gcr_infonce_fwd_o_f32(_lib.dptr(a), _lib.dptr(a_scale), m, _lib.dptr(b), _lib.dptr(b_scale), n, d,
+                                       float(inv_tau), _lib.dptr(lse), _lib.dptr(o), _lib.dptr(ws),
+                                       (INFONCE_EXCLUDE_DIAGONAL if exclude_diagonal else 0) |
+                                       (_resolve_engine() if engine_flag is None else engine_flag),
+                                       _lib.cur_stream(a.device)), "gcr_infonce_fwd_o_f32")
+    return lse, o
+
+
 def pos_logit_raw(a, a_scale, b, b_scale, pos, scale):
     m, d = a.shape
     out = torch.empty(m, dtype=torch.float32, device=a.device)
@@ -559,13 +586,18 @@ class _InfoNCEStats(torch.autograd.Function):
         eng = _resolve_engine()                  # once per problem: the backward runs on the same engine
         on_f32 = eng == INFONCE_ENGINE_F32 or _lib.lib().gcr_infonce_engine(a_p.shape[1]) == 0
         one_pass = want_col and normalize and inv_tau <= 40.0 and not COL_DETERMINISTIC and not exd and on_f32
-        if one_pass:
+        o = None
+        if FWD_O and not want_col and ctx.needs_input_grad[0] and a_p.shape[0] > 0 and \
+                infonce_fwd_o_supported(a_p.shape[1], eng):
+            lse, o = infonce_fwd_o_raw(a_p, sa, b_p, sb, inv_tau, exclude_diagonal=exd, engine_flag=eng)
+            col = None
+        elif one_pass:
             lse, col = infonce_lse_raw(a_p, sa, b_p, sb, inv_tau, col_bound=inv_tau * 1.0001, engine_flag=eng)
         else:
             lse = infonce_lse_raw(a_p, sa, b_p, sb, inv_tau, exclude_diagonal=exd, engine_flag=eng)
             col = infonce_lse_raw(b_p, sb, a_p, sa, inv_tau, exclude_diagonal=exd, engine_flag=eng) if want_col else None
         pl = pos_logit_raw(a_p, sa, b_p, sb, pos, inv_tau)
-        ctx.save_for_backward(a_p, b_p, pos, sa, sb, lse, col)
+        ctx.save_for_backward(a_p, b_p, pos, sa, sb, lse, col, o)
         ctx.inv_tau, ctx.d, ctx.exd, ctx.eng = inv_tau, a.shape[1], exd, eng
         if want_col:
             return lse, pl, col
@@ -573,7 +605,7 @@ class _InfoNCEStats(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_lse, g_pos, g_col=None):
-        a, b, pos, sa, sb, lse, col = ctx.saved_tensors
+        a, b, pos, sa, sb, lse, col, o = ctx.saved_tensors
         L = _lib.lib()
         inv_tau = ctx.inv_tau
         need_a, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
@@ -583,7 +615,10 @@ class _InfoNCEStats(torch.autograd.Function):
         col_r = col if g_col is not None else None
         ga = gb = None
         stream = _lib.cur_stream(a.device)
-        if need_a:
+        if need_a and o is not None:
+            # flash-style forward kept o[i] = sum_j softmax_ij bhat_j: the softmax part of dL/dahat_i is one scale
+            ga = o * (g_lse * inv_tau).unsqueeze(1) if g_lse is not None else torch.zeros_like(o)
+        elif need_a:
             ga = _infonce_bwd_raw(a, sa, b, sb, inv_tau, lse_r, g_lse, col_r, g_col, ctx.exd, ctx.eng)
         if need_b:
             gb = _infonce_bwd_raw(b, sb, a, sa, inv_tau, col_r, g_col, lse_r, g_lse, ctx.exd, ctx.eng)

@@ -298,3 +298,64 @@ def test_exponent_range_of_unnormalised_operands(Fn, sa, sb):
     ((ref_lse - s[torch.arange(m), torch.from_numpy(pos)]) * torch.from_numpy(w)).sum().backward()
     for got, want in ((at.grad, a64.grad.numpy()), (bt.grad, b64.grad.numpy())):
         np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-4, atol=1e-5 * np.abs(want).max())
+
+
+@pytest.mark.parametrize("m,n,d,exd", [(1, 1, 64, False), (70, 20, 64, False), (70, 33, 64, False), (129, 96, 64, False),
+                                       (300, 2049, 64, False), (70, 40000, 64, False), (257, 257, 64, True),
+                                       (64, 1000, 32, False), (97, 4100, 128, False), (200, 200, 128, True),
+                                       (2048, 50000, 64, False)])
+def test_flash_forward_lse_and_weighted_row_sum(Fn, engine, m, n, d, exd):
+    """gcr_infonce_fwd_o_f32: lse and o[i] = sum_j softmax_ij bhat_j from one pass (online max with deferred
+    rescale, per-split partials merged) against float64; the anchor-side gradient of a row-softmax loss is
+    dL/dlse * inv_tau * o."""
+    if engine != "b3":
+        assert not Fn.infonce_fwd_o_supported(d, Fn.INFONCE_ENGINE_F32)
+        pytest.skip("split-operand engine only; the f32 engine keeps the two-launch backward")
+    rng = np.random.default_rng(m * 7 + n)
+    a = (rng.standard_normal((m, d)) * 0.4).astype(np.float32)
+    b = (rng.standard_normal((n, d)) * 0.4).astype(np.float32)
+    if n > 300:
+        b[n // 2] = 3.0 * a[0]              # a late, dominant logit: forces a rescale deep into the stream
+    at, bt = _t(a), _t(b)
+    sa, sb = Fn.row_inv_norm(at), Fn.row_inv_norm(bt)
+    inv_tau = 10.0
+    lse, o = Fn.infonce_fwd_o_raw(at, sa, bt, sb, inv_tau, exclude_diagonal=exd)
+    an = a.astype(np.float64) / np.linalg.norm(a.astype(np.float64), axis=1, keepdims=True)
+    bn = b.astype(np.float64) / np.linalg.norm(b.astype(np.float64), axis=1, keepdims=True)
+    s = inv_tau * an @ bn.T
+    if exd:
+        s[np.arange(min(m, n)), np.arange(min(m, n))] = -np.inf
+    mx = s.max(1, keepdims=True)
+    p = np.exp(s - mx)
+    ref_lse = (mx + np.log(p.sum(1, keepdims=True)))[:, 0]
+    ref_o = (p / p.sum(1, keepdims=True)) @ bn
+    if exd and n == 1:
+        return
+    np.testing.assert_allclose(lse.cpu().numpy(), ref_lse, rtol=1e-5, atol=1e-5)
+    assert np.abs(o.cpu().numpy() - ref_o).max() <= 1e-5 * max(np.abs(ref_o).max(), 1e-3)
+    # the same lse as the plain forward (same MFMA sequence for the scores)
+    plain = Fn.infonce_lse_raw(at, sa, bt, sb, inv_tau, exclude_diagonal=exd)
+    assert float((plain - lse).abs().max()) <= 2e-6 * max(1.0, float(lse.abs().max()))
+
+
+@pytest.mark.parametrize("m,n,d", [(300, 2049, 64), (64, 500, 128), (40, 40, 32)])
+def test_flash_forward_path_gives_the_same_gradients(Fn, engine, monkeypatch, m, n, d):
+    """Row-softmax losses take the flash-style forward when the anchors need a gradient (FWD_O): both input
+    gradients equal the two-launch backward's and the float64 oracle's."""
+    rng = np.random.default_rng(n)
+    a = (rng.standard_normal((m, d)) * 0.4).astype(np.float32)
+    b = (rng.standard_normal((n, d)) * 0.4).astype(np.float32)
+    w = rng.standard_normal(m).astype(np.float32)
+    pos = rng.integers(0, n, m)
+    grads = {}
+    for flag in (True, False):
+        monkeypatch.setattr(Fn, "FWD_O", flag)
+        at, bt = _t(a, True), _t(b, True)
+        lse, pl = Fn.infonce_stats(at, bt, torch.from_numpy(pos).cuda(), 0.1, True)
+        ((lse - pl) * _t(w)).sum().backward()
+        grads[flag] = (at.grad.clone(), bt.grad.clone())
+    g1, g2 = O.infonce_grads(a, b, pos, 10.0, True, w.astype(np.float64))
+    for flag in (True, False):
+        _gclose(grads[flag][0], g1, rel=2e-4)
+        _gclose(grads[flag][1], g2, rel=2e-4)
+    assert float((grads[True][1] - grads[False][1]).abs().max()) == 0.0      # table side: the same launch

@@ -26,11 +26,32 @@ from . import functional as Fn
 from .graph import CsrGraph
 
 
-def _hip_spmm(graph, x, acc_in=None, acc_scale=1.0, want_y=True, keep_bits=None, val_scale=1.0):
-    y = torch.empty(graph.n_rows, x.shape[1], dtype=torch.float32, device=x.device) if want_y else None
+def _hip_spmm(graph, x, acc_in=None, acc_scale=1.0, want_y=True, keep_bits=None, val_scale=1.0, y_out=None):
+    """`y_out`: a caller-owned (pooled) buffer for y instead of a fresh allocation."""
+    y = None
+    if want_y:
+        y = y_out if y_out is not None else torch.empty(graph.n_rows, x.shape[1], dtype=torch.float32, device=x.device)
     acc = torch.empty(graph.n_rows, x.shape[1], dtype=torch.float32, device=x.device) if acc_in is not None else None
     Fn.spmm_into(graph, x, y=y, acc_in=acc_in, acc_out=acc, acc_scale=acc_scale, keep_bits=keep_bits, val_scale=val_scale)
     return y, acc
+
+
+class _Buffers:
+    """Per-graph pool of the collective staging buffers (the gathered table, the partial item sums, the
+    reduce-scatter output): allocated once per (tag, shape) and reused by every layer, every forward and every
+    backward — all on the caller's stream, and every collective is waited on before a call returns, so a
+    buffer is never rewritten while a previous use is still in flight."""
+
+    def __init__(self):
+        self._b = {}
+
+    def get(self, tag, rows, d, device):
+        key = (tag, rows, d, str(device))
+        t = self._b.get(key)
+        if t is None:
+            t = torch.empty(rows, d, dtype=torch.float32, device=device)
+            self._b[key] = t
+        return t
 
 
 def shard_bounds(n, world):
@@ -53,6 +74,7 @@ class ShardedBipartiteGraph:
         self.n_local_users, self.num_items = n_local_users, num_items
         self.items_per_rank, self.rank, self.world, self.group = items_per_rank, rank, world, group
         self.items_padded = items_per_rank * world
+        self.buffers = _Buffers()
 
     @classmethod
     def from_local_interactions(cls, local_uid, iid, n_local_users, num_items, user_deg, item_deg_global, rank, world,
@@ -140,18 +162,24 @@ def sharded_propagate_raw(g: ShardedBipartiteGraph, x_user, x_item_shard, n_laye
     # Horner form z <- x + A z (z_0 = x): after K steps z = sum_{k<=K} A^k x; both halves of a step
     # read the OLD z, every step writes one array per side (no separate layer output + running sum)
     z_u, z_i = x_user, x_item_shard
-    z_item_full = torch.empty(g.items_padded, d, dtype=torch.float32, device=dev) if world > 1 else None
+    pooled = world > 1 and spmm is _hip_spmm          # injected (test) SpMMs allocate their own outputs
+    z_item_full = g.buffers.get("z_item_full", g.items_padded, d, dev) if world > 1 else None
+    part_buf = g.buffers.get("part_i", g.items_padded, d, dev) if pooled else None
+    y_buf = g.buffers.get("y_i", g.items_per_rank, d, dev) if world > 1 else None
     for k in range(n_layers):
         s = scale if k == n_layers - 1 else 1.0
         if world > 1:
             h_ag = _all_gather(z_item_full, z_i.contiguous(), g.group, overlap)
         else:
             z_item_full, h_ag = z_i, None
-        part_i, _ = spmm(g.r_iu, z_u, **kw_iu)                            # item side: local users only
+        if pooled:
+            part_i, _ = spmm(g.r_iu, z_u, y_out=part_buf, **kw_iu)       # item side: local users only
+        else:
+            part_i, _ = spmm(g.r_iu, z_u, **kw_iu)
         if h_ag is not None:
             h_ag.wait()
         if world > 1:
-            y_i = torch.empty_like(z_i)
+            y_i = y_buf
             h_rs = _reduce_scatter(y_i, part_i, g.group, overlap)
         else:
             y_i, h_rs = part_i, None
@@ -217,6 +245,43 @@ def gather_items(item_shard, group=None):
     return _GatherItems.apply(item_shard, group)
 
 
+gather_rows = gather_items       # any row-sharded table: all-gather forward, reduce-scatter of the gradient backward
+
+
+class _AllReduceSum(torch.autograd.Function):
+    """Sum of per-rank partials into a REPLICATED tensor every rank goes on using for its share of the loss:
+    the gradient of the total loss w.r.t. the replicated value is the sum of the ranks' partial gradients."""
+
+    @staticmethod
+    def forward(ctx, part, group):
+        ctx.group = group
+        out = part.contiguous().clone()
+        dist.all_reduce(out, group=group)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous().clone()
+        dist.all_reduce(g, group=ctx.group)
+        return g, None
+
+
+def all_reduce_sum(part, group=None):
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return part
+    return _AllReduceSum.apply(part, group)
+
+
+def allreduce_replicated_grads(params, group=None):
+    """Replicated parameters (MHCN's gating / attention weights, a replicated item table) receive a partial
+    gradient on every rank (each rank back-propagates its own users' share of the loss): sum them."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    for p in params:
+        if p.grad is not None:
+            dist.all_reduce(p.grad, group=group)
+
+
 def sharded_info_nce_loss(z1_local, z2_local, temp=0.2, group=None, stats_fn=None):
     """gcl.py:28-35 over row-sharded views (BASELINE config 4): every rank holds the same row block of
     z1 and z2 ([M/world, d] each, equal sizes).  Both cross-entropies are row problems with LOCAL
@@ -235,3 +300,126 @@ def sharded_info_nce_loss(z1_local, z2_local, temp=0.2, group=None, stats_fn=Non
     lse21, pos21 = stats(z2_local, z1_full, pos, temp, True)[:2]
     m_total = m_local * world
     return ((lse12 - pos12).sum() + (lse21 - pos21).sum()) / (2 * m_total)
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE config 5: MHCN's three U x U hypergraph channels, row-sharded by user (SURVEY §8e last sentence)
+# ---------------------------------------------------------------------------------------------
+def _hip_dual(graph, x_full):
+    raw = torch.empty(graph.n_rows, x_full.shape[1], dtype=torch.float32, device=x_full.device)
+    nrm = torch.empty_like(raw)
+    inv = torch.empty(graph.n_rows, dtype=torch.float32, device=x_full.device)
+    Fn.spmm_dual_into(graph, x_full, raw, nrm, inv)
+    return raw, nrm, inv
+
+
+def _hip_spmm_t(graph, dz, out=None):
+    gt = graph.t
+    y = out if out is not None else torch.empty(gt.n_rows, dz.shape[1], dtype=torch.float32, device=dz.device)
+    Fn.spmm_into(gt, dz.contiguous(), y=y)
+    return y
+
+
+class ShardedChannels:
+    """Rank-local row blocks H_c[users_g, :] (CsrGraph [U_g, U_pad], columns = padded global user ids) of
+    MHCN's channel operators H_s, H_j, H_p (univariate/mhcn.py:340-368).  Users are padded to a multiple of
+    `world`; every rank owns `users_per_rank` rows."""
+
+    def __init__(self, blocks, users_per_rank, rank, world, group=None):
+        self.blocks = list(blocks)
+        self.users_per_rank, self.rank, self.world, self.group = users_per_rank, rank, world, group
+        self.users_padded = users_per_rank * world
+        for b in self.blocks:
+            if b.n_rows != users_per_rank or b.n_cols != self.users_padded:
+                raise ValueError("channel block must be [users_per_rank, users_per_rank * world]")
+        self.buffers = _Buffers()
+        dev = self.blocks[0].device
+        self.streams = [torch.cuda.Stream(device=dev) for _ in self.blocks] if dev.type == "cuda" else None
+
+
+class _ShardedChannelLayer(torch.autograd.Function):
+    """One MHCN layer over the three channels (mhcn.py:440-448) on row-sharded operators:
+        forward   all-gather X_c (its own [U, d] operand per channel) -> (raw_c, norm_c) = dual SpMM on H_c block
+        backward  dZ_c = g_raw + normalize-backward(g_norm) -> partial = H_c block^T dZ_c [U, d] -> reduce-scatter
+    The three all-gathers are issued back to back (async); channel c's SpMM starts as soon as ITS gather has
+    landed, on its own HIP stream, so gather c+1 (and c+2) run beside SpMM c; the backward mirrors it with the
+    reduce-scatter of channel c beside the transposed SpMM of channel c+1."""
+
+    @staticmethod
+    def forward(ctx, ch, dual_fn, spmm_t_fn, *xs):
+        ctx.ch, ctx.spmm_t_fn = ch, spmm_t_fn
+        world, dev, d = ch.world, xs[0].device, xs[0].shape[1]
+        n_c = len(ch.blocks)
+        fulls, handles = [], []
+        for c in range(n_c):
+            if world > 1:
+                full = ch.buffers.get(f"x_full{c}", ch.users_padded, d, dev)
+                handles.append(_all_gather(full, xs[c].contiguous(), ch.group, True))
+            else:
+                full = xs[c].contiguous()
+                handles.append(None)
+            fulls.append(full)
+        outs, saved = [], []
+        cur = torch.cuda.current_stream(dev) if ch.streams is not None else None
+        for c in range(n_c):
+            if ch.streams is not None:
+                s = ch.streams[c]
+                s.wait_stream(cur)
+                with torch.cuda.stream(s):
+                    if handles[c] is not None:
+                        handles[c].wait()                 # stream s waits for gather c only
+                    raw, nrm, inv = dual_fn(ch.blocks[c], fulls[c])
+                for t in (raw, nrm, inv):
+                    t.record_stream(cur)
+            else:
+                if handles[c] is not None:
+                    handles[c].wait()
+                raw, nrm, inv = dual_fn(ch.blocks[c], fulls[c])
+            outs += [raw, nrm]
+            saved += [nrm, inv]
+        if ch.streams is not None:
+            for s in ch.streams:
+                cur.wait_stream(s)                       # join: the pooled gather buffers are free again, outputs ready
+        ctx.save_for_backward(*saved)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        ch = ctx.ch
+        saved = ctx.saved_tensors
+        world = ch.world
+        n_c = len(ch.blocks)
+        dxs, handles, parts = [], [], []
+        for c in range(n_c):
+            g_raw, g_nrm = gs[2 * c], gs[2 * c + 1]
+            nrm, inv = saved[2 * c], saved[2 * c + 1]
+            dz = None
+            if g_nrm is not None:
+                dz = (g_nrm - nrm * (nrm * g_nrm).sum(1, keepdim=True)) * inv.unsqueeze(1)
+            if g_raw is not None:
+                dz = g_raw if dz is None else dz + g_raw
+            if dz is None:
+                dxs.append(None)
+                handles.append(None)
+                continue
+            d = dz.shape[1]
+            if world > 1:
+                buf = ch.buffers.get(f"g_part{c}", ch.users_padded, d, dz.device) if ctx.spmm_t_fn is _hip_spmm_t else None
+                part = ctx.spmm_t_fn(ch.blocks[c], dz, buf) if buf is not None else ctx.spmm_t_fn(ch.blocks[c], dz)
+                dx = torch.empty(ch.users_per_rank, d, dtype=torch.float32, device=dz.device)
+                handles.append(_reduce_scatter(dx, part, ch.group, True))    # runs beside the next channel's SpMM
+                parts.append(part)
+            else:
+                dx = ctx.spmm_t_fn(ch.blocks[c], dz)
+                handles.append(None)
+            dxs.append(dx)
+        for h in handles:
+            if h is not None:
+                h.wait()
+        return (None, None, None, *dxs)
+
+
+def sharded_channel_layer(ch: ShardedChannels, xs, dual_fn=_hip_dual, spmm_t_fn=_hip_spmm_t):
+    """[(raw_c, norm_c)] for the rank's user rows of every channel; xs: the rank's [U_g, d] operand rows."""
+    out = _ShardedChannelLayer.apply(ch, dual_fn, spmm_t_fn, *xs)
+    return [(out[2 * c], out[2 * c + 1]) for c in range(len(xs))]

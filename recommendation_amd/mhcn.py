@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import functional as Fn
+from .distributed import _hip_dual, _hip_spmm_t
 from .encoders import multi_stream_spmm
 from .graph import CsrGraph
 
@@ -107,3 +108,81 @@ class MHCNEncoder(nn.Module):
             p = None if perms is None else perms[3 * c:3 * c + 3]
             ss = ss + self.hierarchical_self_supervision(self.self_supervised_gating(final_user, c + 1), adj, p)
         return final_user[u_idx], final_item[v_idx], final_item[neg_idx], self.ss_rate * ss, final_user, final_item
+
+
+class HipOps:
+    """The SpMM primitives of the sharded encoder on the HIP path (the product default).  Tests that exercise
+    only the collectives' choreography on CPU tensors (gloo) inject stand-ins with the same four methods."""
+
+    @staticmethod
+    def spmm(graph, x):                       # autograd-aware A x
+        return Fn.spmm(graph, x)
+
+    @staticmethod
+    def dual(graph, x):                       # autograd-aware (A x, normalize(A x))
+        return Fn.spmm_l2norm_dual(graph, x)
+
+    channel_dual = staticmethod(_hip_dual)            # raw launches (no autograd) used inside the channel layer
+    channel_spmm_t = staticmethod(_hip_spmm_t)
+
+
+class ShardedMHCNEncoder(MHCNEncoder):
+    """MHCN's layer loop (mhcn.py:422-466) over `world` GPUs, users row-sharded (BASELINE config 5):
+      * every rank owns `users_per_rank` user rows: their embeddings, the row blocks H_c[users_g, :] of the three
+        channel operators (distributed.ShardedChannels) and R_g = R[users_g, :];
+      * channels: one all-gather of each channel's own [U, d] operand per layer, overlapped with the previous
+        channel's SpMM on its own stream (distributed.sharded_channel_layer);
+      * items: R_g^T mixed_g is a partial [I, d] sum -> all-reduce -> replicated item rows (normalised after the
+        reduction); the simple channel R_g items is local.
+    Replicated parameters (gating / attention weights, item embeddings) get partial gradients per rank:
+    call `allreduce_grads()` after backward."""
+
+    def __init__(self, channels, r_local: CsrGraph, emb_size=64, n_layers=2, ss_rate=0.01, ops=HipOps):
+        nn.Module.__init__(self)
+        self.channels, self.R, self.ops = channels, r_local, ops
+        self.H_s, self.H_j, self.H_p = channels.blocks
+        self.user_num, self.item_num = r_local.n_rows, r_local.n_cols      # LOCAL user rows
+        self.emb_size, self.n_layers, self.ss_rate, self.n_channel = emb_size, n_layers, ss_rate, 4
+        dev = r_local.device
+        xav = nn.init.xavier_uniform_
+        self.user_embeddings = nn.Parameter(xav(torch.empty(self.user_num, emb_size, device=dev)))
+        self.item_embeddings = nn.Parameter(xav(torch.empty(self.item_num, emb_size, device=dev)))
+        self.gating_weights, self.gating_bias = nn.ParameterDict(), nn.ParameterDict()
+        self.sgating_weights, self.sgating_bias = nn.ParameterDict(), nn.ParameterDict()
+        for c in range(1, self.n_channel + 1):
+            self.gating_weights[str(c)] = nn.Parameter(xav(torch.empty(emb_size, emb_size, device=dev)))
+            self.gating_bias[str(c)] = nn.Parameter(torch.zeros(1, emb_size, device=dev))
+            self.sgating_weights[str(c)] = nn.Parameter(xav(torch.empty(emb_size, emb_size, device=dev)))
+            self.sgating_bias[str(c)] = nn.Parameter(torch.zeros(1, emb_size, device=dev))
+        self.attention = nn.Parameter(xav(torch.empty(1, emb_size, device=dev)))
+        self.attention_mat = nn.Parameter(xav(torch.empty(emb_size, emb_size, device=dev)))
+        self._streams = None
+
+    def propagate(self):
+        from . import distributed as gd
+        ops, ch = self.ops, self.channels
+        c1, c2, c3 = (self.self_gating(self.user_embeddings, k) for k in (1, 2, 3))
+        simple = self.self_gating(self.user_embeddings, 4)
+        items = self.item_embeddings
+        sums = [c1, c2, c3, simple, items]
+        for _ in range(self.n_layers):
+            mixed, _ = self.channel_attention(c1, c2, c3)
+            mixed = mixed + simple / 2
+            (c1, n1), (c2, n2), (c3, n3) = gd.sharded_channel_layer(ch, [c1, c2, c3], ops.channel_dual, ops.channel_spmm_t)
+            new_items = gd.all_reduce_sum(ops.spmm(self.R.t, mixed), ch.group)      # R^T mixed: sum over the ranks' users
+            n_i = torch.nn.functional.normalize(new_items, p=2, dim=1)
+            simple, n_s = ops.dual(self.R, items)
+            sums = [sums[0] + n1, sums[1] + n2, sums[2] + n3, sums[3] + n_s, sums[4] + n_i]
+            items = new_items
+        final_user, _ = self.channel_attention(sums[0], sums[1], sums[2])
+        return final_user + sums[3] / 2, sums[4]
+
+    def replicated_parameters(self):
+        return [p for n, p in self.named_parameters() if n != "user_embeddings"]
+
+    def allreduce_grads(self):
+        from . import distributed as gd
+        gd.allreduce_replicated_grads(self.replicated_parameters(), self.channels.group)
+
+    def forward(self, *a, **kw):
+        raise NotImplementedError("the sharded encoder provides propagate(); the per-batch losses are the caller's")

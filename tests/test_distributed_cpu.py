@@ -156,3 +156,72 @@ def test_sharded_info_nce_loss_equals_single_process():
     for r in range(world):
         np.testing.assert_allclose(res[r]["ga"], g1[r * 32:(r + 1) * 32], rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(res[r]["gb"], g2[r * 32:(r + 1) * 32], rtol=1e-4, atol=1e-6)
+
+
+# --------------------------------------------------------------------------- BASELINE config 5 (MHCN channels)
+class _CpuGraph:
+    """Stand-in operator for the gloo choreography test: a dense float32 matrix with the CsrGraph attributes
+    the sharded encoder reads.  The SpMM arithmetic itself is covered by the GPU tests."""
+
+    def __init__(self, row, col, val, n_rows, n_cols):
+        m = torch.zeros(n_rows, n_cols)
+        m.index_put_((torch.from_numpy(row), torch.from_numpy(col)), torch.from_numpy(val), accumulate=True)
+        self.m, self.n_rows, self.n_cols, self.device = m, n_rows, n_cols, torch.device("cpu")
+
+    @property
+    def t(self):
+        g = _CpuGraph.__new__(_CpuGraph)
+        g.m, g.n_rows, g.n_cols, g.device = self.m.T.contiguous(), self.n_cols, self.n_rows, self.device
+        return g
+
+
+class _CpuOps:
+    @staticmethod
+    def spmm(graph, x):
+        return graph.m @ x
+
+    @staticmethod
+    def dual(graph, x):
+        z = graph.m @ x
+        return z, torch.nn.functional.normalize(z, p=2, dim=1)
+
+    @staticmethod
+    def channel_dual(graph, x_full):
+        z = graph.m @ x_full
+        nrm = z.norm(dim=1).clamp_min(1e-12)
+        return z, z / nrm.unsqueeze(1), 1.0 / nrm
+
+    @staticmethod
+    def channel_spmm_t(graph, dz):
+        return graph.m.T @ dz
+
+
+def _mhcn_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import mhcn_sharded_common as C
+        out[rank] = C.run_rank(rank, world, torch.device("cpu"), _CpuGraph, _CpuOps)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_mhcn_channels_equal_single_process():
+    """Config 5: users row-sharded over 2 ranks, one all-gather per channel operand, reduce-scatter of the
+    channel gradients, all-reduce of the item-side partial sums: values and gradients == single process."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import mhcn_sharded_common as C
+    ctx = mp.get_context("spawn")
+    world = 2
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        port = _free_port()
+        procs = [ctx.Process(target=_mhcn_worker, args=(r, world, port, out)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(180)
+            assert p.exitcode == 0
+        res = {r: out[r] for r in range(world)}
+    C.check(res, world, 2e-5)

@@ -161,3 +161,43 @@ def test_two_ranks_one_gpu_match_single_process():
         assert res[r]["nce"] == pytest.approx(nce, rel=1e-5)
         np.testing.assert_allclose(res[r]["ga"], g1[r * per:(r + 1) * per], rtol=1e-4, atol=1e-5 * np.abs(g1).max())
         np.testing.assert_allclose(res[r]["gb"], g2[r * per:(r + 1) * per], rtol=1e-4, atol=1e-5 * np.abs(g2).max())
+
+
+# --------------------------------------------------------------------------- BASELINE config 5 (MHCN channels)
+def _mhcn_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import mhcn_sharded_common as C
+        import recommendation_amd as ra
+        from recommendation_amd.mhcn import HipOps
+        dev = torch.device("cuda", 0)
+
+        def make_graph(row, col, val, n_rows, n_cols):
+            return ra.CsrGraph.from_coo(row, col, val, n_rows, n_cols, dev)
+
+        out[rank] = C.run_rank(rank, world, dev, make_graph, HipOps)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_mhcn_two_ranks_one_gpu():
+    """Config 5 with the real HIP kernels (dual-output SpMM on the row blocks of H_s / H_j / H_p, three streams,
+    per-channel all-gather / reduce-scatter over gloo): values and gradients == the single-process float64
+    restatement of univariate/mhcn.py:422-466."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import mhcn_sharded_common as C
+    world = 2
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        port = _free_port()
+        procs = [ctx.Process(target=_mhcn_worker, args=(r, world, port, out)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(300)
+            assert p.exitcode == 0
+        res = {r: out[r] for r in range(world)}
+    C.check(res, world, 2e-5)

@@ -358,4 +358,5 @@ def test_flash_forward_path_gives_the_same_gradients(Fn, engine, monkeypatch, m,
     for flag in (True, False):
         _gclose(grads[flag][0], g1, rel=2e-4)
         _gclose(grads[flag][1], g2, rel=2e-4)
-    assert float((grads[True][1] - grads[False][1]).abs().max()) == 0.0      # table side: the same launch
+    # table side: the same launch, fed an lse that differs in the last bits (online merge vs two-stage merge)
+    assert float((grads[True][1] - grads[False][1]).abs().max()) <= 1e-5 * float(grads[False][1].abs().max())

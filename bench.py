@@ -301,13 +301,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS) + ["cfg5"])
     ap.add_argument("--dim", type=int, default=64)
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = a cfg2-sized user block per rank; strong = the fixed workload graph over N ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--no-cfg4", action="store_true", help="skip the 10M x 1M / 100M-edge 1-GPU companion line")
+    ap.add_argument("--gcl-full", action="store_true",
+                    help="N > 1: run the GCL step leg on the benchmark graph itself (all-pairs user InfoNCE is O(U^2): minutes)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -327,6 +329,8 @@ def main():
 
     if world > 1 or os.environ.get("GCR_BENCH_FORCE_DIST") == "1":
         return main_sharded(args, rank, world, dev, ra)
+    if args.workload == "cfg5":
+        return main_cfg5(args, rank, world, dev, ra)
 
     name = args.workload or "cfg2"
     d = args.dim
@@ -394,72 +398,160 @@ def main():
     print(json.dumps(line))
 
 
-def main_sharded(args, rank, world, dev, ra):
-    """N > 1: one rank per GPU, users row-sharded, items all-gathered / reduce-scattered over
-    xGMI every layer (recommendation_amd/distributed.py).  WEAK scaling: every rank brings its
-    own cfg2-sized block (1M users / 10M interactions by default) and the item side grows with N
-    (100K x N items), so N = 8 is 8M users x 800K items / 80M interactions — the cfg4 regime."""
+def _init_dist(dev):
     import torch.distributed as dist
-    from recommendation_amd import distributed as gdist
-
     if not dist.is_initialized():
         if os.environ.get("GCR_BENCH_REHEARSE_ONE_GPU") == "1":
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=dev)
-    name = args.workload or "cfg2"
-    wl = WORKLOADS[name]
-    n_u, n_e, k_layers, d = wl["users"], wl["edges"], wl["layers"], args.dim
-    n_i = wl["items"] * world
-    per_i, i_pad = gdist.shard_bounds(n_i, world)
+    return dist
 
-    users, items = synth_interactions_device(n_u, n_i, n_e, SEED + 7919 * (rank + 1), dev, perm_seed=SEED)
-    deg_i = torch.bincount(items, minlength=i_pad)
-    dist.all_reduce(deg_i)                                       # global item degrees (integer)
-    deg_u = torch.bincount(users, minlength=n_u)
-    du, di = deg_u.float().pow(-0.5), deg_i.float().pow(-0.5)
-    du[torch.isinf(du)] = 0.0
-    di[torch.isinf(di)] = 0.0
 
-    def block(row, col, n_rows, n_cols, rscale, cscale):
-        order = torch.argsort(row * n_cols + col)
-        r, c = row[order], col[order]
-        rowptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=dev)
-        rowptr[1:] = torch.cumsum(torch.bincount(r, minlength=n_rows), 0)
-        return ra.CsrGraph(rowptr, c.to(torch.int32), rscale[r] * cscale[c], n_rows, n_cols, dev)
-
-    r_ui = block(users, items, n_u, i_pad, du, di)
-    r_iu = block(items, users, i_pad, n_u, di, du)
-    graph = gdist.ShardedBipartiteGraph(r_ui, r_iu, n_u, n_i, per_i, rank, world)
-    nnz_local = r_ui.nnz + r_iu.nnz
-    gen = torch.Generator(device=dev).manual_seed(rank)
-    bound = (6.0 / (n_u * world + n_i + d)) ** 0.5                # xavier_uniform of the global table
-    x_u = (torch.rand(n_u, d, device=dev, generator=gen) * 2 - 1) * bound
-    x_i = (torch.rand(per_i, d, device=dev, generator=gen) * 2 - 1) * bound
-    torch.cuda.synchronize()
-
-    def step():
-        with torch.no_grad():
-            return gdist.sharded_propagate_raw(graph, x_u, x_i, k_layers, 1.0)
-
-    for _ in range(args.warmup):
+def _timed_ranks(dist, dev, step, warmup, steps):
+    """W untimed + K timed steps between barrier + synchronize on both sides; MAX over ranks (seconds)."""
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
     elapsed = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
     dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    return float(elapsed.item())
+
+
+def build_sharded_bipartite(ra, gdist, dist, dev, rank, world, n_u_local, n_i, users, items):
+    """This rank's blocks of the symmetric-normalised bipartite operator from its own (local user id, item id)
+    interactions: global item degrees by all-reduce, blocks through the library ingest (gcr_coo_to_csr +
+    device transpose, which also gives ShardedEdgeDrop its nnz correspondence)."""
+    per_i, i_pad = gdist.shard_bounds(n_i, world)
+    deg_i = torch.bincount(items, minlength=n_i)
+    dist.all_reduce(deg_i)                                       # global item degrees (integer)
+    deg_u = torch.bincount(users, minlength=n_u_local)
+    du, di = deg_u.float().pow(-0.5), deg_i.float().pow(-0.5)
+    du[torch.isinf(du)] = 0.0
+    di[torch.isinf(di)] = 0.0
+    r_ui = ra.CsrGraph.from_coo(users, items, du[users] * di[items], n_u_local, i_pad, dev, coalesce=True)
+    r_iu = r_ui.t
+    return gdist.ShardedBipartiteGraph(r_ui, r_iu, n_u_local, n_i, per_i, rank, world)
+
+
+def local_interactions(name, scaling, rank, world, dev, gdist):
+    """(local user ids, item ids, users on this rank, global users, items, global interactions).
+    weak: every rank draws its own `users` x (items * world) block (the item popularity law is shared);
+    strong: the ONE global graph of the workload, generated identically on every rank (same seed) and
+    filtered to the rank's contiguous user block."""
+    wl = WORKLOADS[name]
+    if scaling == "weak":
+        n_u, n_i = wl["users"], wl["items"] * world
+        users, items = synth_interactions_device(n_u, n_i, wl["edges"], SEED + 7919 * (rank + 1), dev, perm_seed=SEED)
+        return users, items, n_u, n_u * world, n_i, wl["edges"] * world
+    n_ug, n_i = wl["users"], wl["items"]
+    per_u, _ = gdist.shard_bounds(n_ug, world)
+    users, items = synth_interactions_device(n_ug, n_i, wl["edges"], SEED, dev)
+    lo = rank * per_u
+    sel = (users >= lo) & (users < lo + per_u)
+    return (users[sel] - lo).contiguous(), items[sel].contiguous(), per_u, n_ug, n_i, wl["edges"]
+
+
+GCL_LEG = dict(users=1 << 18, items=1 << 15, edges=(1 << 18) * 10, layers=3)   # per rank (weak): the step is O(U^2)
+
+
+def gcl_step_leg(ra, gdist, dist, dev, rank, world, d, full_graph=None):
+    """One sharded SSL4Rec / GCL training step (gcl.py:205-227 with the propagation BASELINE config 4 names):
+    two edge-dropped views (ShardedEdgeDrop, independent draws per stored non-zero), K-layer sharded
+    propagation of each, all-pairs symmetric InfoNCE over users and over items between the views
+    (row-sharded anchors, all-gathered tables), BPR on a batch, backward incl. the reduce-scatter of the item
+    gradients, on its own named workload (the all-pairs user InfoNCE is O(U^2))."""
+    from recommendation_amd import functional as Fn
+    wl = GCL_LEG
+    if full_graph is None:
+        n_u, n_i, k_layers = wl["users"], wl["items"] * world, wl["layers"]
+        users, items = synth_interactions_device(n_u, n_i, wl["edges"], SEED + 104729 * (rank + 1), dev, perm_seed=SEED)
+        g = build_sharded_bipartite(ra, gdist, dist, dev, rank, world, n_u, n_i, users, items)
+    else:
+        g, users, items, k_layers = full_graph
+        n_u, n_i = g.n_local_users, g.num_items
+    gen = torch.Generator(device=dev).manual_seed(100 + rank)
+    bound = (6.0 / (n_u * world + n_i + d)) ** 0.5
+    x_u = ((torch.rand(n_u, d, device=dev, generator=gen) * 2 - 1) * bound).requires_grad_(True)
+    x_i = ((torch.rand(g.items_per_rank, d, device=dev, generator=gen) * 2 - 1) * bound).requires_grad_(True)
+    bsz = 2048
+    sel = torch.randint(0, users.numel(), (bsz,), device=dev, generator=gen)
+    bu, bi = users[sel], items[sel]
+    bj = torch.randint(0, n_i, (bsz,), device=dev, generator=gen)
+    pe, temp = 0.2, 0.2
+    state = {"n": 0}
+
+    def step():
+        state["n"] += 1
+        x_u.grad = x_i.grad = None
+        v1 = gdist.ShardedEdgeDrop(g, pe, seed=2 * state["n"] + 1)
+        v2 = gdist.ShardedEdgeDrop(g, pe, seed=2 * state["n"] + 2)
+        u1, i1 = gdist.sharded_lightgcn_propagate(g, x_u, x_i, k_layers, "mean", view=v1)
+        u2, i2 = gdist.sharded_lightgcn_propagate(g, x_u, x_i, k_layers, "mean", view=v2)
+        ssl = gdist.sharded_info_nce_loss(u1, u2, temp) + gdist.sharded_info_nce_loss(i1, i2, temp)
+        items_full = gdist.gather_items(i1)[: n_i]
+        sums = Fn.bpr_sums(u1, items_full, bu, bi, bj, Fn.BPR_LOGSIGMOID)
+        loss = ssl + sums[0] / bsz + 1e-4 * (sums[1] + sums[2] + sums[3]) / bsz
+        loss.backward()
+
+    t = _timed_ranks(dist, dev, step, 1, 2)
+    n_edges = torch.tensor([g.r_ui.nnz + g.r_iu.nnz], device=dev, dtype=torch.int64)
+    dist.all_reduce(n_edges)
+    u_tot, i_tot = n_u * world, g.items_padded
+    pairs = u_tot * u_tot + i_tot * i_tot                     # logits of the two all-pairs similarity matrices
+    return {"workload": f"gcl step: {u_tot} users ({n_u}/GPU) x {n_i} items, nnz={int(n_edges)}, {k_layers}-layer d={d}, "
+                        f"two edge-dropped views (pe={pe}) + all-pairs InfoNCE(users) + InfoNCE(items) + BPR(B={bsz}) + backward",
+            "ms_per_step": 1e3 * t / 2, "infonce_pairs_per_s": pairs * 2 / t,
+            "edges_per_s_fwd_bwd": int(n_edges) * k_layers * 2 * 2 * 2 / t,
+            "pairs_per_step": pairs, "note": "pairs = U^2 + I^2 logits per step (each feeds a row and a column softmax)"}
+
+
+def main_sharded(args, rank, world, dev, ra):
+    """N > 1: one rank per GPU, users row-sharded, items all-gathered / reduce-scattered over xGMI every layer
+    (recommendation_amd/distributed.py).  --scaling weak (default): every rank brings its own cfg2-sized block
+    (1M users / 10M interactions) and the item side grows with N (100K x N items), so N = 8 is 8M users x 800K
+    items / 80M interactions — the cfg4 regime; --scaling strong: the fixed graph of --workload (cfg4: 10M x 1M /
+    100M interactions) split over the N ranks."""
+    from recommendation_amd import distributed as gdist
+    dist = _init_dist(dev)
+    name = args.workload or ("cfg4" if args.scaling == "strong" else "cfg2")
+    if name == "cfg5":
+        return main_cfg5(args, rank, world, dev, ra)
+    k_layers, d = WORKLOADS[name]["layers"], args.dim
+    users, items, n_u, n_u_total, n_i, n_e_total = local_interactions(name, args.scaling, rank, world, dev, gdist)
+    graph = build_sharded_bipartite(ra, gdist, dist, dev, rank, world, n_u, n_i, users, items)
+    nnz_local = graph.r_ui.nnz + graph.r_iu.nnz
+    gen = torch.Generator(device=dev).manual_seed(rank)
+    bound = (6.0 / (n_u_total + n_i + d)) ** 0.5                  # xavier_uniform of the global table
+    x_u = (torch.rand(n_u, d, device=dev, generator=gen) * 2 - 1) * bound
+    x_i = (torch.rand(graph.items_per_rank, d, device=dev, generator=gen) * 2 - 1) * bound
+    torch.cuda.synchronize()
+
+    def step():
+        with torch.no_grad():
+            return gdist.sharded_propagate_raw(graph, x_u, x_i, k_layers, 1.0)
+
+    elapsed = _timed_ranks(dist, dev, step, args.warmup, args.steps)
     nnz_all = torch.tensor([nnz_local], device=dev, dtype=torch.int64)
     dist.all_reduce(nnz_all)
-    elapsed, nnz_all = float(elapsed.item()), int(nnz_all.item())
+    nnz_all = int(nnz_all.item())
+    gcl = None
+    if not args.no_extra:
+        try:
+            full = (graph, users, items, k_layers) if args.gcl_full else None
+            gcl = gcl_step_leg(ra, gdist, dist, dev, rank, world, d, full)
+        except Exception as e:      # noqa: BLE001  (secondary: never costs the headline line)
+            gcl = {"error": repr(e)[:300]}
     if rank == 0:
-        n_nodes = n_u * world + n_i
+        n_nodes = n_u_total + n_i
         bytes_alg = nnz_all * (8 + 4 * d) + n_nodes * (4 * d + 4)
         per_layer_s = elapsed / (args.steps * k_layers)
         achieved = bytes_alg / per_layer_s / 1e9
@@ -467,19 +559,113 @@ def main_sharded(args, rank, world, dev, ra):
             "metric": "edges propagated/sec (LightGCN d=%d, %d-layer fwd message pass)" % (d, k_layers),
             "value": nnz_all * k_layers * args.steps / elapsed, "unit": "edges/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{name} x{world} (weak): LightGCN {k_layers}-layer d={d}, {n_u * world} users "
-                                   f"(row-sharded, {n_u}/GPU) x {n_i} items / {n_e * world} interactions "
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{name} x{world} ({args.scaling}): LightGCN {k_layers}-layer d={d}, {n_u_total} users "
+                                   f"(row-sharded, {n_u}/GPU) x {n_i} items / {n_e_total} interactions "
                                    f"(nnz={nnz_all}); all-gather + reduce-scatter of the item table per layer",
-                       "users": n_u * world, "items": n_i, "interactions": n_e * world, "layers": k_layers, "dim": d,
+                       "users": n_u_total, "items": n_i, "interactions": n_e_total, "layers": k_layers, "dim": d,
                        "parallelism": f"user-row shards x{world}, items replicated for compute"},
+            "infonce_pairs_per_s": None if not gcl or "error" in gcl else gcl["infonce_pairs_per_s"],
             "roofline": {"bound": "hbm", "kernel": "spmm_parts (per-layer wall time incl. collectives)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
-                         "frac": round(achieved / (HBM_PEAK_GBS * world), 4), "traffic": None},
-            "cpu_baseline": None,
+                         "frac": round(achieved / (HBM_PEAK_GBS * world), 4), "traffic": None,
+                         "frac_alg": round(achieved / (HBM_PEAK_GBS * world), 4),
+                         "collective_bytes_per_rank_per_layer": 2 * graph.items_padded * d * 4 * (world - 1) // world},
+            "cpu_baseline": None, "dist_backend": dist.get_backend(), "dist_world": dist.get_world_size(),
+            "gcl_step": gcl,
         }
         print(json.dumps(line))
     dist.destroy_process_group()
+
+
+CFG5 = dict(users=250_000, items=50_000, deg=(24, 16, 8), deg_r=10, layers=2)       # per rank (weak)
+
+
+def main_cfg5(args, rank, world, dev, ra):
+    """BASELINE config 5: MHCN's layer loop (univariate/mhcn.py:422-466) with the three U x U channel operators
+    row-sharded by user: per layer three all-gathers of [U, d] channel operands, each overlapped with the
+    previous channel's dual-output SpMM on its own stream, plus the R^T / R item side (all-reduce of the partial
+    item sums).  Synthetic operators: `deg` random columns per row and channel, row-normalised (the motif
+    adjacency of a real social graph comes from graph_ops.build_hyper_graphs)."""
+    import torch.distributed as dist
+    from recommendation_amd import distributed as gdist
+    from recommendation_amd.mhcn import ShardedMHCNEncoder
+    if world > 1:
+        dist = _init_dist(dev)
+    per_u, n_i, d, k_layers = CFG5["users"], CFG5["items"], args.dim, CFG5["layers"]
+    u_pad = per_u * world
+    gen = torch.Generator(device=dev).manual_seed(SEED + rank)
+    rows = torch.arange(per_u, device=dev)
+
+    def rand_block(n_cols, deg):
+        r = rows.repeat_interleave(deg)
+        c = torch.randint(0, n_cols, (per_u * deg,), device=dev, generator=gen)
+        return ra.CsrGraph.row_normalised(r, c, None, per_u, n_cols, dev)
+
+    blocks = [rand_block(u_pad, k) for k in CFG5["deg"]]
+    r_local = rand_block(n_i, CFG5["deg_r"])
+    ch = gdist.ShardedChannels(blocks, per_u, rank, world)
+    enc = ShardedMHCNEncoder(ch, r_local, d, k_layers)
+    nnz_local = sum(b.nnz for b in blocks) + 2 * r_local.nnz
+    torch.cuda.synchronize()
+
+    def step():
+        with torch.no_grad():
+            return enc.propagate()
+
+    def step_fb():
+        enc.zero_grad(set_to_none=True)
+        fu, fi = enc.propagate()
+        (fu.sum() + fi.sum() / world).backward()
+        enc.allreduce_grads()
+
+    if world > 1:
+        elapsed = _timed_ranks(dist, dev, step, args.warmup, args.steps)
+        t_fb = _timed_ranks(dist, dev, step_fb, 1, 3) / 3
+        nnz_all = torch.tensor([nnz_local], device=dev, dtype=torch.int64)
+        dist.all_reduce(nnz_all)
+        nnz_all = int(nnz_all.item())
+    else:
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        step_fb()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            step_fb()
+        torch.cuda.synchronize()
+        t_fb = (time.perf_counter() - t0) / 3
+        nnz_all = nnz_local
+    if rank == 0:
+        n_rows = u_pad * 4 + n_i                                       # output rows of the five operators
+        bytes_alg = nnz_all * (8 + 4 * d) + n_rows * (2 * 4 * d + 4)   # dual epilogue: two output rows
+        achieved = bytes_alg * k_layers * args.steps / elapsed / 1e9
+        line = {
+            "metric": "edges propagated/sec (MHCN d=%d, %d-layer multi-channel message pass)" % (d, k_layers),
+            "value": nnz_all * k_layers * args.steps / elapsed, "unit": "edges/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"cfg5 x{world}: MHCN {k_layers}-layer d={d}, {u_pad} users ({per_u}/GPU) x {n_i} items; "
+                                   f"H_s/H_j/H_p with {CFG5['deg']} nnz per row, R with {CFG5['deg_r']} (nnz={nnz_all}); "
+                                   "three channel all-gathers per layer overlapped with the previous channel's SpMM",
+                       "users": u_pad, "items": n_i, "layers": k_layers, "dim": d,
+                       "parallelism": f"user-row shards x{world}, items replicated"},
+            "roofline": {"bound": "hbm", "kernel": "spmm_parts dual epilogue (per-step wall time incl. gating / attention "
+                                                   "GEMMs and collectives)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                         "frac": round(achieved / (HBM_PEAK_GBS * world), 4), "traffic": None},
+            "cpu_baseline": None, "dist_backend": dist.get_backend() if world > 1 else None, "dist_world": world,
+            "extra": {"fwd_bwd_ms": 1e3 * t_fb},
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def bench_extra(ra, Fn, graph, x0, k_layers, nnz, dev, n_u, n_i):

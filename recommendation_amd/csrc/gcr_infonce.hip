@@ -881,7 +881,9 @@ __device__ __forceinline__ void stage_store_b3t_one(unsigned char* __restrict__ 
   }
 }
 
-template <int D, bool ILV, bool EXD = false>
+// SIDES: which softmax terms of P are live — 0 both, 1 only the stationary rows' (w_x, lse_x), 2 only the
+// streamed rows' (w_y, lse_y): a dead term costs an exp2 and an FMA per score in the exposed part of the loop.
+template <int D, bool ILV, bool EXD = false, int SIDES = 0>
 __global__ __launch_bounds__(256, 2) void infonce_bwd_b3_kernel(
     const float* __restrict__ x, const float* __restrict__ x_scale, int64_t mx, const float* __restrict__ y,
     const float* __restrict__ y_scale, int64_t ny, float scale2, float out_scale, const float* __restrict__ lse_x,
@@ -1031,7 +1033,9 @@ __global__ __launch_bounds__(256, 2) void infonce_bwd_b3_kernel(
           const int r = 4 * g + e;
           const bool dead = (ragged && (j0 + acc_row(r, h) >= ny)) || (EXD && xr == e + 8 * g);
           const float sc = dead ? -INFINITY : acc[r];
-          acc[r] = wl * __builtin_amdgcn_exp2f(sc - lse2l) + wre[e] * __builtin_amdgcn_exp2f(sc - lre[e]);
+          if (SIDES == 1) acc[r] = wl * __builtin_amdgcn_exp2f(sc - lse2l);
+          else if (SIDES == 2) acc[r] = wre[e] * __builtin_amdgcn_exp2f(sc - lre[e]);
+          else acc[r] = wl * __builtin_amdgcn_exp2f(sc - lse2l) + wre[e] * __builtin_amdgcn_exp2f(sc - lre[e]);
         }
       }
       unsigned pq[2][3][4];
@@ -1121,7 +1125,9 @@ __global__ __launch_bounds__(256, 2) void infonce_bwd_b3_kernel(
           const int r = 4 * g + e;
           const bool dead = (ragged && (j0 + acc_row(r, h) >= ny)) || (EXD && xr == e + 8 * g);
           const float sc = dead ? -INFINITY : acc[0][r];
-          acc[0][r] = wl * __builtin_amdgcn_exp2f(sc - lse2l) + wre[e] * __builtin_amdgcn_exp2f(sc - lre[e]);
+          if (SIDES == 1) acc[0][r] = wl * __builtin_amdgcn_exp2f(sc - lse2l);
+          else if (SIDES == 2) acc[0][r] = wre[e] * __builtin_amdgcn_exp2f(sc - lre[e]);
+          else acc[0][r] = wl * __builtin_amdgcn_exp2f(sc - lse2l) + wre[e] * __builtin_amdgcn_exp2f(sc - lre[e]);
         }
       }
       // G^T[c][i] += yhat[j][c] * P[j][i], 16 streamed rows per k-chunk, six bf16 terms
@@ -1548,12 +1554,20 @@ int32_t launch_bwd(const float* x, const float* x_scale, int64_t mx, const float
       const FwdPlan p = plan_bwd_rows(mx, ny, D, BwdB3<D>::ROWS_PER_BLOCK);
       float* gpart = p.nsplit == 1 ? g : reinterpret_cast<float*>(workspace);
       const dim3 grid((unsigned)(p.m_blocks * p.nsplit));
-      if (exd)
-        hipLaunchKernelGGL((infonce_bwd_b3_kernel<D, ILV, true>), grid, dim3(256), 0, s, x, x_scale, mx, y, y_scale, ny,
-                           inv_tau * kLog2e, inv_tau, lse_x, w_x, lse_y, w_y, p.nsplit, p.tiles_per_split, gpart);
-      else
-        hipLaunchKernelGGL((infonce_bwd_b3_kernel<D, ILV, false>), grid, dim3(256), 0, s, x, x_scale, mx, y, y_scale, ny,
-                           inv_tau * kLog2e, inv_tau, lse_x, w_x, lse_y, w_y, p.nsplit, p.tiles_per_split, gpart);
+      const bool has_x = w_x != nullptr && lse_x != nullptr, has_y = w_y != nullptr && lse_y != nullptr;
+#define GCR_BWD3(EX, SD)                                                                                              \
+  hipLaunchKernelGGL((infonce_bwd_b3_kernel<D, ILV, EX, SD>), grid, dim3(256), 0, s, x, x_scale, mx, y, y_scale, ny, \
+                     inv_tau * kLog2e, inv_tau, lse_x, w_x, lse_y, w_y, p.nsplit, p.tiles_per_split, gpart)
+      if (exd) {
+        GCR_BWD3(true, 0);
+      } else if (has_x && !has_y) {
+        GCR_BWD3(false, 1);
+      } else if (has_y && !has_x) {
+        GCR_BWD3(false, 2);
+      } else {
+        GCR_BWD3(false, 0);
+      }
+#undef GCR_BWD3
       int32_t st = GCR_LAUNCH_STATUS();
       if (st != GCR_OK) return st;
       return reduce_splits(p, gpart, mx, D, g, s);

@@ -401,6 +401,9 @@ def main():
 def _init_dist(dev):
     import torch.distributed as dist
     if not dist.is_initialized():
+        if "RANK" not in os.environ:             # single process through the sharded path (GCR_BENCH_FORCE_DIST=1)
+            os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+                              MASTER_PORT=os.environ.get("MASTER_PORT", "29533"))
         if os.environ.get("GCR_BENCH_REHEARSE_ONE_GPU") == "1":
             dist.init_process_group(backend="gloo")
         else:

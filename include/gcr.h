@@ -327,6 +327,35 @@ int32_t gcr_topk_masked_f32(float* scores, int64_t n_query, int64_t n_items, con
                             int64_t n_users, const int64_t* user_rowptr, const int32_t* user_items_sorted,
                             int32_t k, int64_t* top_items, float* top_scores, void* stream);
 
+/*
+ * Fused full ranking: the same top-k as gcr_score_rows_f32 + gcr_topk_masked_f32 without ever writing the
+ * [n_query, n_items] score matrix.  Pass 0 scores the first 4096 items densely and takes, per user, the k-th
+ * largest eligible score as a threshold; pass 1 recomputes the score tiles over all items (split-operand
+ * bf16 MFMA, f32-accurate) and keeps only (score >= threshold, item not a training positive) candidates —
+ * about k * n_items / 4096 per user; a per-user bitonic sort finishes.  status[q] = 1 marks a user whose
+ * candidate list overflowed or came up short (re-rank those through the two-call path); 0 = row q is final.
+ * Supported (gcr_rank_fused_supported): d in {32, 64, 128}, n_items >= 16384, k <= 256.
+ * replaces lightgcn.py:48-57, gcl.py:87-96, ncl.py:253-264,390-394 (as gcr_topk_masked_f32).
+ */
+int32_t gcr_rank_fused_supported(int64_t n_items, int32_t d, int32_t k);
+int64_t gcr_rank_fused_workspace_bytes(int64_t n_query);
+int32_t gcr_rank_fused_f32(const float* user_emb, const int64_t* user_ids, int64_t n_query, int64_t n_users,
+                           const float* item_emb, int64_t n_items, int32_t d, const int64_t* user_rowptr,
+                           const int32_t* user_items_sorted, int32_t k, int64_t* top_items, float* top_scores,
+                           int32_t* status, void* workspace, void* stream);
+
+/*
+ * Per-user terms of the ranking metrics (ncl.py:133-177 `Metric.hits` / `Metric.NDCG`, the same quantities in
+ * lightgcn.py:59-74, gcl.py:98-108) from the ranked lists: for query row q and every cut-off n = cutoffs[c]
+ * (ascending), hits[q, c] = #{p < n : top_items[q, p] in the user's test items}, dcg[q, c] = sum over those p of
+ * 1 / log2(p + 2), idcg[q, c] = sum_{p < min(|test_q|, n)} 1 / log2(p + 2).  test_rowptr [n_query + 1] /
+ * test_items_sorted: CSR of the test items per QUERY row, ascending inside a row; top_items: int64 [n_query, k]
+ * (-1 = padding).  The means over users (hit ratio, precision, recall, NDCG) are the caller's.
+ */
+int32_t gcr_rank_metrics(const int64_t* top_items, int64_t n_query, int32_t k, const int64_t* test_rowptr,
+                         const int32_t* test_items_sorted, const int32_t* cutoffs, int32_t n_cut,
+                         int32_t* hits, double* dcg, double* idcg, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Graph ingest on the device (integer work, bit-exact with the reference's host construction).
  * --------------------------------------------------------------------------------------------- */

@@ -675,3 +675,36 @@ def neighbor_discrimination(positive, emb, aug_emb, temperature=0.1):
 def sparse_dropout_values(val, keep, rate):
     """univariate/buir.py:300-309: kept non-zeros (dropout_mask = floor(1 - rate + rand)) times 1 / (1 - rate)."""
     return np.asarray(val, dtype=F64) * np.asarray(keep, dtype=F64) * (1.0 / (1.0 - rate))
+
+
+# --------------------------------------------------------------------------
+# ranking metrics (ncl.py:133-177), pinned by tests/golden/eval.json (the reference's own report lines)
+# --------------------------------------------------------------------------
+
+
+def ranking_report(origin, res, cutoffs):
+    """ncl.py:133-177 `ranking_evaluation` + `Metric`: origin {user: {item: 1}}, res {user: [(item, score), ...]}.
+    Per cut-off n over the users of `origin` that have a list: hit ratio = all hits / all test items, precision =
+    hits / (users * n), recall = mean of hits_u / |test_u|, NDCG = mean of DCG_u / IDCG_u with gains
+    1 / log2(rank + 2); every value rounded to 5 decimals, formatted as the reference prints them."""
+    import math
+    users = [u for u in origin if u in res]
+    lines = []
+    for n in cutoffs:
+        hits, rec_sum, ndcg_sum = {}, 0.0, 0.0
+        for u in users:
+            top = [it for it, _ in res[u][:n]]
+            hits[u] = len(set(origin[u]) & set(top))
+        total_test = sum(len(origin[u]) for u in origin)
+        for u in hits:
+            rec_sum += hits[u] / len(origin[u])
+        for u in res:
+            dcg = sum(1.0 / math.log2(p + 2) for p, (it, _) in enumerate(res[u][:n]) if it in origin[u])
+            idcg = sum(1.0 / math.log2(p + 2) for p in range(min(len(origin[u]), n)))
+            ndcg_sum += dcg / idcg if idcg else 0
+        lines.append(f"Top {n}\n")
+        lines.append(f"Hit Ratio:{round(sum(hits.values()) / total_test, 5)}\n")
+        lines.append(f"Precision:{round(sum(hits.values()) / (len(hits) * n), 5)}\n")
+        lines.append(f"Recall:{round(float(np.mean([hits[u] / len(origin[u]) for u in hits])), 5)}\n")
+        lines.append(f"NDCG:{round(ndcg_sum / len(res), 5)}\n")
+    return lines

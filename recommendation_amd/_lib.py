@@ -57,6 +57,10 @@ SIGNATURES = {
     "gcr_kmeans_update_sorted_f32": (c_int32, [_P, c_int64, c_int32, _P, _P, c_int64, _P, _P, _P, _P, _P]),
     "gcr_score_rows_f32": (c_int32, [_P, _P, c_int64, c_int64, _P, c_int64, c_int32, _P, _P]),
     "gcr_topk_masked_f32": (c_int32, [_P, c_int64, c_int64, _P, c_int64, _P, _P, c_int32, _P, _P, _P]),
+    "gcr_rank_fused_supported": (c_int32, [c_int64, c_int32, c_int32]),
+    "gcr_rank_fused_workspace_bytes": (c_int64, [c_int64]),
+    "gcr_rank_fused_f32": (c_int32, [_P, _P, c_int64, c_int64, _P, c_int64, c_int32, _P, _P, c_int32, _P, _P, _P, _P, _P]),
+    "gcr_rank_metrics": (c_int32, [_P, c_int64, c_int32, _P, _P, _P, c_int32, _P, _P, _P, _P]),
     "gcr_coo_to_csr_workspace_bytes": (c_int64, [c_int64]),
     "gcr_coo_to_csr": (c_int32, [_P, _P, _P, c_int64, c_int64, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gcr_csr_sym_norm_f32": (c_int32, [_P, _P, _P, c_int64, c_int64, _P, _P, _P, _P, _P, _P]),

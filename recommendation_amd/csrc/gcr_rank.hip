@@ -31,6 +31,9 @@ struct RShape {
 
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+constexpr int kTileJ = 32;
+#include "gcr_b3.h"   // split-operand bf16 MFMA helpers (inside this anonymous namespace)
+
 template <int D>
 __global__ __launch_bounds__(256, 2) void score_rows_kernel(const float* __restrict__ user_emb,
                                                             const int64_t* __restrict__ user_ids, int64_t n_query,
@@ -132,6 +135,149 @@ __global__ __launch_bounds__(256, 2) void score_rows_kernel(const float* __restr
 __device__ __forceinline__ uint32_t order_key(float f) {
   const uint32_t b = __float_as_uint(f);
   return (b & 0x80000000u) ? ~b : (b | 0x80000000u);   // larger float -> larger key; -inf smallest
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused ranking: the U x I score matrix never reaches HBM.
+//   pass 0 (MODE 0)  scores of every query user against the first kSample items, written dense to a small
+//                    [Q, kSample] buffer; rank_threshold_kernel masks the training positives in it and takes the
+//                    k-th largest: a lower bound thr[q] of the row's k-th largest eligible score;
+//   pass 1 (MODE 1)  the same score tiles over ALL items; a score >= thr[q] whose item is not a training
+//                    positive of the user (binary search in the sorted row) is appended to the user's candidate
+//                    list — about k * I / kSample entries per user instead of I scores;
+//   rank_finish      gathers a user's candidates, bitonic-sorts them in LDS, writes the exact top-k
+//                    (ties -> smaller item id).  A list that overflowed (or came up short) sets status[q] = 1 and
+//                    the host re-ranks that user through gcr_score_rows_f32 + gcr_topk_masked_f32.
+// Score tile: the split-operand bf16 MFMA (gcr_b3.h, f32-accurate), users stationary on the lanes (64 per wave),
+// items streamed through LDS.  A lane owns its user for the block's whole item range, so the candidate counter is
+// a lane-private register and every (user, item split, lane half) triple appends to its own region: no atomics.  Both passes
+// build the same tiles with the same MFMA sequence, so a score is bitwise the same in both.
+// ------------------------------------------------------------------------------------------------
+constexpr int kFuseSample = 4096;
+constexpr int kFuseCap = 4096;          // candidate entries per user over all item splits
+
+__device__ __forceinline__ bool is_train_item(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ items,
+                                              int64_t uid, int32_t j) {
+  int64_t lo = rowptr[uid], hi = rowptr[uid + 1];
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    const int32_t v = items[mid];
+    if (v == j) return true;
+    if (v < j) lo = mid + 1; else hi = mid;
+  }
+  return false;
+}
+
+template <int D, int MODE>
+__global__ __launch_bounds__(256, 2) void rank_fused_b3_kernel(
+    const float* __restrict__ user_emb, const int64_t* __restrict__ user_ids, int64_t n_query, int64_t n_users,
+    const float* __restrict__ item_emb, int64_t n_items, int64_t j_end, int nsplit, int64_t tiles_per_split,
+    float* __restrict__ sample, int sample_stride, const float* __restrict__ thr,
+    const int64_t* __restrict__ user_rowptr, const int32_t* __restrict__ user_items,
+    unsigned long long* __restrict__ cand, int32_t* __restrict__ counts, int cap_split) {
+  using S = ShapeB3<D>;
+  __shared__ __align__(16) unsigned char lds[2][3 * S::PLANE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i32 = lane & 31, h = lane >> 5;
+  const int64_t ublk = blockIdx.x / nsplit;
+  const int split = blockIdx.x % nsplit;
+  const int64_t q0 = (ublk * 4 + wave) * (32 * S::NT);
+
+  // stationary users (gathered by id): three bf16 planes of features [h * KH, (h + 1) * KH)
+  u32x4 bq[S::NT][3][S::KC];
+  int64_t uid[S::NT];
+  float thr_l[S::NT];
+  int cnt[S::NT];
+#pragma unroll
+  for (int t = 0; t < S::NT; ++t) {
+    const int64_t q = q0 + 32 * t + i32;
+    int64_t u = q < n_query ? (user_ids != nullptr ? user_ids[q] : q) : -1;
+    const bool ok = u >= 0 && u < n_users;
+    uid[t] = ok ? u : -1;
+    load_stationary_b3<D>(user_emb, nullptr, ok ? u + 1 : 0, ok ? u : 0, h, 1.0f, bq[t]);
+    thr_l[t] = (MODE == 1 && ok) ? thr[q] : INFINITY;       // an invalid query never produces a candidate
+    cnt[t] = 0;
+  }
+
+  const int64_t total_tiles = (j_end + kTileJ - 1) / kTileJ;
+  const int64_t tile0 = (int64_t)split * tiles_per_split;
+  const int64_t tile1 = min(total_tiles, tile0 + tiles_per_split);
+  float4 regs[S::NLD];
+  auto stage_load_items = [&](int64_t j0) {
+#pragma unroll
+    for (int u = 0; u < S::NLD; ++u) {
+      const int idx = tid + 256 * u;
+      const int row = idx / (D / 4), c4 = idx % (D / 4);
+      const int64_t j = j0 + row;
+      const int64_t jj = j < n_items ? j : n_items - 1;
+      float4 v = *reinterpret_cast<const float4*>(item_emb + jj * D + 4 * c4);
+      if (j >= n_items) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      regs[u] = v;
+    }
+  };
+  if (tile0 < tile1) {
+    stage_load_items(tile0 * kTileJ);
+    stage_store_b3<D>(lds[0], tid, regs);
+  }
+  __syncthreads();
+  for (int64_t tt = tile0; tt < tile1; ++tt) {
+    const int cur = (int)((tt - tile0) & 1);
+    const int64_t nxt = tt + 1 < tile1 ? tt + 1 : tt;
+    stage_load_items(nxt * kTileJ);
+    f32x16 acc[S::NT];
+    score_tile_b3<D, S::NT>(lds[cur], i32, h, bq, acc);
+    const int64_t j0 = tt * kTileJ;
+    if (MODE == 0) {
+      // dense sample: registers 4g .. 4g+3 are items j0 + 8g + 4h .. +3 of the lane's user: one 16-B store
+#pragma unroll
+      for (int t = 0; t < S::NT; ++t) {
+        const int64_t q = q0 + 32 * t + i32;
+        if (q < n_query) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int64_t j = j0 + 8 * g + 4 * h;
+            if (j + 3 < (int64_t)sample_stride)
+              *reinterpret_cast<float4*>(sample + q * sample_stride + j) =
+                  make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < S::NT; ++t) {
+        float mx = fmaxf(fmaxf(acc[t][0], acc[t][1]), fmaxf(acc[t][2], acc[t][3]));
+#pragma unroll
+        for (int g = 1; g < 4; ++g)
+          mx = fmaxf(mx, fmaxf(fmaxf(acc[t][4 * g], acc[t][4 * g + 1]), fmaxf(acc[t][4 * g + 2], acc[t][4 * g + 3])));
+        if (__any(mx >= thr_l[t])) {                   // rare: ~k / kSample of the scores pass
+          if (mx >= thr_l[t]) {
+            const int64_t q = q0 + 32 * t + i32;
+            unsigned long long* region = cand + (((int64_t)q * nsplit + split) * 2 + h) * cap_split;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int64_t j = j0 + acc_row(r, h);
+              if (acc[t][r] >= thr_l[t] && j < n_items) {
+                if (user_rowptr == nullptr || !is_train_item(user_rowptr, user_items, uid[t], (int32_t)j)) {
+                  if (cnt[t] < cap_split)
+                    region[cnt[t]] = ((unsigned long long)order_key(acc[t][r]) << 32) | (0xFFFFFFFFu - (uint32_t)j);
+                  ++cnt[t];                            // keeps counting past the capacity: overflow is detected
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+    stage_store_b3<D>(lds[cur ^ 1], tid, regs);
+    __syncthreads();
+  }
+  if (MODE == 1) {
+#pragma unroll
+    for (int t = 0; t < S::NT; ++t) {
+      const int64_t q = q0 + 32 * t + i32;
+      if (q < n_query) counts[(q * nsplit + split) * 2 + h] = cnt[t];     // one sub-region per lane half
+    }
+  }
 }
 
 constexpr int kTopThreads = 256;
@@ -275,6 +421,120 @@ __device__ void topk_row_full(const float* __restrict__ row, int64_t n_items, in
       top_items[q * k + i] = -1;
       top_scores[q * k + i] = -INFINITY;
     }
+  }
+}
+
+
+__device__ __forceinline__ float key_to_float(uint32_t key) {
+  return __uint_as_float((key & 0x80000000u) ? (key & 0x7FFFFFFFu) : ~key);
+}
+
+// thr[q] = k-th largest score of the user's first kFuseSample items after masking the training positives among
+// them (a lower bound of the row's k-th largest eligible score); -inf when the sample has fewer than k eligible
+// items (everything passes, the list overflows and the user takes the exact fallback).
+__global__ __launch_bounds__(kTopThreads) void rank_threshold_kernel(const float* __restrict__ sample, int64_t n_query,
+                                                                     const int64_t* __restrict__ user_ids, int64_t n_users,
+                                                                     const int64_t* __restrict__ user_rowptr,
+                                                                     const int32_t* __restrict__ user_items, int k,
+                                                                     float* __restrict__ thr) {
+  __shared__ uint32_t hist[2048];
+  __shared__ uint32_t sh[kTopThreads + 2];
+  __shared__ uint32_t skey[kFuseSample];
+  const int tid = threadIdx.x;
+  for (int64_t q = blockIdx.x; q < n_query; q += gridDim.x) {
+    const float* row = sample + q * kFuseSample;
+    for (int j = tid; j < kFuseSample; j += kTopThreads) skey[j] = order_key(row[j]);
+    __syncthreads();
+    const int64_t uid = user_ids != nullptr ? user_ids[q] : q;
+    if (user_rowptr != nullptr && uid >= 0 && uid < n_users) {
+      for (int64_t e = user_rowptr[uid] + tid; e < user_rowptr[uid + 1]; e += kTopThreads) {
+        const int32_t it = user_items[e];
+        if (it >= 0 && it < kFuseSample) skey[it] = 0u;          // below every real score, -inf included
+      }
+    }
+    __syncthreads();
+    uint32_t prefix = 0, want = (uint32_t)k, above = 0;
+    const int shifts[3] = {21, 10, 0}, widths[3] = {11, 11, 10};
+    for (int pass = 0; pass < 3; ++pass) {
+      const int nb = 1 << widths[pass];
+      for (int b2 = tid; b2 < nb; b2 += kTopThreads) hist[b2] = 0;
+      __syncthreads();
+      for (int j = tid; j < kFuseSample; j += kTopThreads) {
+        const uint32_t key = skey[j];
+        const bool in_prefix = pass == 0 || (key >> (shifts[pass] + widths[pass])) == prefix;
+        if (in_prefix) atomicAdd(&hist[(key >> shifts[pass]) & (uint32_t)(nb - 1)], 1u);
+      }
+      __syncthreads();
+      const uint32_t bin = (uint32_t)pick_bin(hist, nb, want, &above, sh);
+      want -= above;
+      prefix = (prefix << widths[pass]) | bin;
+    }
+    if (tid == 0) thr[q] = prefix > order_key(-INFINITY) ? key_to_float(prefix) : -INFINITY;
+    __syncthreads();
+  }
+}
+
+// exact top-k of one user from its candidate regions (bitonic sort in LDS); status[q] = 1 asks for the fallback
+__global__ __launch_bounds__(kTopThreads) void rank_finish_kernel(const unsigned long long* __restrict__ cand_g,
+                                                                  const int32_t* __restrict__ counts, int n_regions,
+                                                                  int cap_split, int64_t n_query, int k,
+                                                                  int64_t* __restrict__ top_items,
+                                                                  float* __restrict__ top_scores, int32_t* __restrict__ status) {
+  __shared__ unsigned long long cand[kFuseCap];
+  __shared__ int s_total, s_bad;
+  const int tid = threadIdx.x;
+  for (int64_t q = blockIdx.x; q < n_query; q += gridDim.x) {
+    if (tid == 0) {
+      int total = 0, bad = 0;
+      for (int r = 0; r < n_regions; ++r) {
+        const int c = counts[q * n_regions + r];
+        bad |= c > cap_split;
+        total += c < cap_split ? c : cap_split;
+      }
+      s_total = total;
+      s_bad = bad || total > kFuseCap || total < k;
+    }
+    __syncthreads();
+    const int total = s_total;
+    if (s_bad) {
+      if (tid == 0) status[q] = 1;
+      __syncthreads();
+      continue;
+    }
+    if (tid == 0) status[q] = 0;
+    // gather: region r's entries land at the prefix sum of the counts before it
+    int base = 0;
+    for (int r = 0; r < n_regions; ++r) {
+      const int c = counts[q * n_regions + r];
+      const unsigned long long* src = cand_g + ((int64_t)q * n_regions + r) * cap_split;
+      for (int i = tid; i < c; i += kTopThreads) cand[base + i] = src[i];
+      base += c;
+    }
+    int n2 = 1;
+    while (n2 < total) n2 <<= 1;
+    for (int i = total + tid; i < n2; i += kTopThreads) cand[i] = 0ull;
+    __syncthreads();
+    for (int size = 2; size <= n2; size <<= 1) {
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        for (int i = tid; i < n2; i += kTopThreads) {
+          const int partner = i ^ stride;
+          if (partner > i) {
+            const bool desc = (i & size) == 0;
+            const unsigned long long x = cand[i], y = cand[partner];
+            if ((x < y) == desc) {
+              cand[i] = y;
+              cand[partner] = x;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+    for (int i = tid; i < k; i += kTopThreads) {
+      top_items[q * k + i] = (int64_t)(0xFFFFFFFFu - (uint32_t)(cand[i] & 0xFFFFFFFFull));
+      top_scores[q * k + i] = key_to_float((uint32_t)(cand[i] >> 32));
+    }
+    __syncthreads();
   }
 }
 
@@ -425,7 +685,156 @@ int32_t launch_score(const float* user_emb, const int64_t* user_ids, int64_t n_q
   return GCR_LAUNCH_STATUS();
 }
 
+
+struct FusePlan {
+  int nsplit;
+  int64_t tiles_per_split;
+  int64_t ublocks;
+  int cap_split;
+};
+
+FusePlan plan_fuse(int64_t n_query, int64_t n_items, int users_per_block) {
+  FusePlan p;
+  p.ublocks = (n_query + users_per_block - 1) / users_per_block;
+  const int64_t total_tiles = (n_items + kTileJ - 1) / kTileJ;
+  // >= 3 rounds of 512 resident blocks, but never fewer than 64 tiles per block and at most 8 splits
+  // (the candidate regions are sized per split)
+  int64_t nsplit = (3 * 512 + p.ublocks - 1) / p.ublocks;
+  if (nsplit > 8) nsplit = 8;
+  if (nsplit > total_tiles / 64) nsplit = total_tiles / 64 > 0 ? total_tiles / 64 : 1;
+  p.tiles_per_split = (total_tiles + nsplit - 1) / nsplit;
+  p.nsplit = (int)((total_tiles + p.tiles_per_split - 1) / p.tiles_per_split);
+  p.cap_split = kFuseCap / (2 * p.nsplit);
+  return p;
+}
+
+template <int D>
+int32_t launch_fused(const float* user_emb, const int64_t* user_ids, int64_t n_query, int64_t n_users,
+                     const float* item_emb, int64_t n_items, const int64_t* user_rowptr, const int32_t* user_items,
+                     int k, int64_t* top_items, float* top_scores, int32_t* status, void* workspace, hipStream_t s) {
+  constexpr int UPB = ShapeB3<D>::ANCHORS_PER_BLOCK;
+  const FusePlan p = plan_fuse(n_query, n_items, UPB);
+  unsigned char* w = reinterpret_cast<unsigned char*>(workspace);
+  float* sample = reinterpret_cast<float*>(w);
+  w += (size_t)n_query * kFuseSample * sizeof(float);
+  unsigned long long* cand = reinterpret_cast<unsigned long long*>(w);
+  w += (size_t)n_query * kFuseCap * sizeof(unsigned long long);
+  float* thr = reinterpret_cast<float*>(w);
+  w += (size_t)n_query * sizeof(float);
+  int32_t* counts = reinterpret_cast<int32_t*>(w);
+  // pass 0: dense sample scores (one split: 128 tiles per block)
+  hipLaunchKernelGGL((rank_fused_b3_kernel<D, 0>), dim3((unsigned)p.ublocks), dim3(256), 0, s, user_emb, user_ids, n_query,
+                     n_users, item_emb, n_items, (int64_t)kFuseSample, 1, (int64_t)(kFuseSample / kTileJ), sample,
+                     kFuseSample, (const float*)nullptr, user_rowptr, user_items, cand, counts, 0);
+  int32_t st = GCR_LAUNCH_STATUS();
+  if (st != GCR_OK) return st;
+  const int64_t tb = n_query < 65536 ? n_query : 65536;
+  hipLaunchKernelGGL(rank_threshold_kernel, dim3((unsigned)tb), dim3(kTopThreads), 0, s, sample, n_query, user_ids,
+                     n_users, user_rowptr, user_items, k, thr);
+  st = GCR_LAUNCH_STATUS();
+  if (st != GCR_OK) return st;
+  // pass 1: all items, candidates only
+  hipLaunchKernelGGL((rank_fused_b3_kernel<D, 1>), dim3((unsigned)(p.ublocks * p.nsplit)), dim3(256), 0, s, user_emb,
+                     user_ids, n_query, n_users, item_emb, n_items, n_items, p.nsplit, p.tiles_per_split, sample,
+                     kFuseSample, thr, user_rowptr, user_items, cand, counts, p.cap_split);
+  st = GCR_LAUNCH_STATUS();
+  if (st != GCR_OK) return st;
+  hipLaunchKernelGGL(rank_finish_kernel, dim3((unsigned)tb), dim3(kTopThreads), 0, s, cand, counts, 2 * p.nsplit,
+                     p.cap_split, n_query, k, top_items, top_scores, status);
+  return GCR_LAUNCH_STATUS();
+}
+
+
+// Per query user and cut-off n: #hits in the first n ranked items, DCG = sum over hit positions p of 1 / log2(p + 2),
+// IDCG = sum_{p < min(|test|, n)} 1 / log2(p + 2) — the per-user terms of ncl.py:133-163 (Metric.hits / NDCG); the
+// means over users are the caller's.  One thread per user; test items sorted per user (binary search).
+__global__ __launch_bounds__(256) void rank_metrics_kernel(const int64_t* __restrict__ top_items, int64_t n_query, int k,
+                                                           const int64_t* __restrict__ test_rowptr,
+                                                           const int32_t* __restrict__ test_items,
+                                                           const int32_t* __restrict__ cutoffs, int n_cut,
+                                                           int32_t* __restrict__ hits, double* __restrict__ dcg,
+                                                           double* __restrict__ idcg) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n_query) return;
+  const int64_t lo0 = test_rowptr[q], hi0 = test_rowptr[q + 1];
+  const int64_t n_test = hi0 - lo0;
+  int h = 0;
+  double d = 0.0, ideal = 0.0;
+  int c = 0;
+  for (int p = 0; p <= k && c < n_cut; ++p) {
+    while (c < n_cut && cutoffs[c] == p) {            // cut-offs ascending: emit the running sums at n = p
+      hits[q * n_cut + c] = h;
+      dcg[q * n_cut + c] = d;
+      idcg[q * n_cut + c] = ideal;
+      ++c;
+    }
+    if (p == k) break;
+    const double gain = 1.0 / log2((double)(p + 2));
+    if (p < n_test) ideal += gain;
+    const int64_t it = top_items[q * k + p];
+    if (it >= 0) {
+      int64_t lo = lo0, hi = hi0;
+      while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (test_items[mid] < it) lo = mid + 1; else hi = mid;
+      }
+      if (lo < hi0 && test_items[lo] == it) {
+        ++h;
+        d += gain;
+      }
+    }
+  }
+  for (; c < n_cut; ++c) {                            // cut-offs beyond k see the whole list
+    hits[q * n_cut + c] = h;
+    dcg[q * n_cut + c] = d;
+    double x = ideal;
+    for (int p = k; p < cutoffs[c] && p < n_test; ++p) x += 1.0 / log2((double)(p + 2));
+    idcg[q * n_cut + c] = x;
+  }
+}
+
 }  // namespace
+
+extern "C" int32_t gcr_rank_metrics(const int64_t* top_items, int64_t n_query, int32_t k, const int64_t* test_rowptr,
+                                    const int32_t* test_items_sorted, const int32_t* cutoffs, int32_t n_cut,
+                                    int32_t* hits, double* dcg, double* idcg, void* stream) {
+  GCR_CHECK_ARG(n_query >= 0 && k >= 1 && n_cut >= 1 && n_cut <= 64);
+  if (n_query == 0) return GCR_OK;
+  GCR_CHECK_ARG(top_items && test_rowptr && cutoffs && hits && dcg && idcg);
+  hipLaunchKernelGGL(rank_metrics_kernel, dim3((unsigned)((n_query + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     top_items, n_query, k, test_rowptr, test_items_sorted, cutoffs, n_cut, hits, dcg, idcg);
+  return GCR_LAUNCH_STATUS();
+}
+
+extern "C" int32_t gcr_rank_fused_supported(int64_t n_items, int32_t d, int32_t k) {
+  return (d == 32 || d == 64 || d == 128) && n_items >= 4 * kFuseSample && k >= 1 && k <= kMaxK ? 1 : 0;
+}
+
+extern "C" int64_t gcr_rank_fused_workspace_bytes(int64_t n_query) {
+  if (n_query <= 0) return 0;
+  return n_query * ((int64_t)kFuseSample * 4 + (int64_t)kFuseCap * 8 + 4 + 16 * 4);
+}
+
+extern "C" int32_t gcr_rank_fused_f32(const float* user_emb, const int64_t* user_ids, int64_t n_query, int64_t n_users,
+                                      const float* item_emb, int64_t n_items, int32_t d, const int64_t* user_rowptr,
+                                      const int32_t* user_items_sorted, int32_t k, int64_t* top_items, float* top_scores,
+                                      int32_t* status, void* workspace, void* stream) {
+  GCR_CHECK_ARG(n_query >= 0 && n_users >= 1 && n_items >= 1 && n_items < (1ll << 31));
+  if (!gcr_rank_fused_supported(n_items, d, k)) return GCR_EUNSUPPORTED;
+  if (n_query == 0) return GCR_OK;
+  GCR_CHECK_ARG(user_emb && item_emb && top_items && top_scores && status && workspace);
+  GCR_CHECK_ARG((user_rowptr == nullptr) == (user_items_sorted == nullptr));
+  GCR_CHECK_ARG(n_query < (1ll << 24));
+  hipStream_t s = (hipStream_t)stream;
+  switch (d) {
+    case 32: return launch_fused<32>(user_emb, user_ids, n_query, n_users, item_emb, n_items, user_rowptr, user_items_sorted,
+                                     k, top_items, top_scores, status, workspace, s);
+    case 64: return launch_fused<64>(user_emb, user_ids, n_query, n_users, item_emb, n_items, user_rowptr, user_items_sorted,
+                                     k, top_items, top_scores, status, workspace, s);
+    default: return launch_fused<128>(user_emb, user_ids, n_query, n_users, item_emb, n_items, user_rowptr,
+                                      user_items_sorted, k, top_items, top_scores, status, workspace, s);
+  }
+}
 
 extern "C" int32_t gcr_score_rows_f32(const float* user_emb, const int64_t* user_ids, int64_t n_query, int64_t n_users,
                                       const float* item_emb, int64_t n_items, int32_t d, float* scores, void* stream) {

@@ -13,12 +13,21 @@ from oracle import oracle_np as O
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "eval.json")
 
 
+def test_oracle_ranking_report_matches_reference():
+    """ncl.py:133-177: Hit Ratio / Precision / Recall / NDCG lines for N in [10, 20, 30, 50] (CPU oracle)."""
+    g = json.load(open(GOLDEN))
+    res = {u: [tuple(p) for p in lst] for u, lst in g["res"].items()}
+    assert O.ranking_report(g["origin"], res, g["N"]) == g["lines"]
+
+
+@pytest.mark.gpu
 def test_ranking_evaluation_strings_match_reference():
-    """ncl.py:133-177: Hit Ratio / Precision / Recall / NDCG lines for N in [10, 20, 30, 50]."""
+    """The same lines from the device-side per-user hits / DCG sums (gcr_rank_metrics)."""
     from recommendation_amd.evaluate import ranking_evaluation
     g = json.load(open(GOLDEN))
     res = {u: [tuple(p) for p in lst] for u, lst in g["res"].items()}
     assert ranking_evaluation(g["origin"], res, g["N"]) == g["lines"]
+    assert ranking_evaluation(g["origin"], res, [10, 70]) == O.ranking_report(g["origin"], res, [10, 70])   # cut-off > list
 
 
 def _ref_topk(ue, ie, uids, pos, k):
@@ -30,8 +39,11 @@ def _ref_topk(ue, ie, uids, pos, k):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_u,n_i,d,k", [(300, 1682, 64, 50), (200, 257, 32, 10), (100, 5000, 128, 20), (64, 40, 64, 50)])
+@pytest.mark.parametrize("n_u,n_i,d,k", [(300, 1682, 64, 50), (200, 257, 32, 10), (100, 5000, 128, 20), (64, 40, 64, 50),
+                                         (700, 20000, 64, 50), (300, 70001, 128, 20), (150, 16384, 32, 100)])
 def test_rank_topk_matches_numpy(n_u, n_i, d, k):
+    """The last three shapes are catalogue-sized (>= 16384 items): the fused score + candidate-filter path
+    (gcr_rank_fused_f32), the others the two-call path."""
     from recommendation_amd.evaluate import rank_topk
     rng = np.random.default_rng(n_u + n_i)
     ue = rng.standard_normal((n_u, d)).astype(np.float32)
@@ -70,7 +82,7 @@ def test_rank_topk_matches_numpy(n_u, n_i, d, k):
 def test_topk_ties_and_reference_protocol(golden):
     """Exact ties resolve to the smaller item id; `test()` returns the ncl.py:253-264 structure."""
     from recommendation_amd.encoders import Interaction
-    from recommendation_amd.evaluate import Metric, rank_topk, ranking_evaluation, test as run_test
+    from recommendation_amd.evaluate import rank_topk, ranking_evaluation, test as run_test
     ue = torch.zeros(4, 64, device="cuda")
     ue[:, 0] = 1.0
     ie = torch.zeros(300, 64, device="cuda")
@@ -93,8 +105,7 @@ def test_topk_ties_and_reference_protocol(golden):
         assert [s for _, s in lst] == sorted((s for _, s in lst), reverse=True)
     lines = ranking_evaluation(data.test_set, rec, [10, 20])
     assert lines[0] == "Top 10\n" and lines[5] == "Top 20\n" and len(lines) == 10
-    hits = Metric.hits(data.test_set, rec)
-    assert 0 <= Metric.hit_ratio(data.test_set, hits) <= 1
+    assert lines == O.ranking_report(data.test_set, rec, [10, 20])
 
 
 @pytest.mark.gpu
@@ -132,3 +143,48 @@ def test_topk_long_rows_candidate_filter_and_fallback(layout):
         ref = np.argsort(-row, kind="stable")[:k]           # stable: equal scores keep increasing item id
         assert np.array_equal(top_i[q].cpu().numpy(), ref), (layout, q)
         assert np.array_equal(top_s[q].cpu().numpy(), row[ref])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["ascending", "descending", "ties", "hot_tail", "few_eligible"])
+def test_fused_rank_adversarial_rows(layout):
+    """gcr_rank_fused_f32 on rows built to stress the threshold: scores = item_emb[:, 0] (users = e_0), so ascending
+    in item id makes the 4096-item sample the row's minimum (candidate overflow -> status 1 -> exact fallback),
+    descending puts every winner in the sample, `ties` has huge groups of equal scores at the threshold, `hot_tail`
+    the winners at the end, `few_eligible` a user whose training set covers most of the sample's top."""
+    from recommendation_amd.evaluate import rank_topk
+    rng = np.random.default_rng(3)
+    n_q, n_i, k, d = 5, 30_000, 50, 64
+    base = rng.standard_normal(n_i).astype(np.float32)
+    if layout == "ascending":
+        base = np.sort(base)
+    elif layout == "descending":
+        base = -np.sort(-base)
+    elif layout == "ties":
+        base = (np.round(base * 2) / 2).astype(np.float32)
+    elif layout == "hot_tail":
+        base[-200:] += 10.0
+    ie = np.zeros((n_i, d), dtype=np.float32)
+    ie[:, 0] = base
+    ie[:, 1] = rng.standard_normal(n_i).astype(np.float32)          # a second direction so that users differ
+    ue = np.zeros((n_q, d), dtype=np.float32)
+    ue[:, 0] = 1.0
+    ue[:, 1] = np.linspace(0, 0.5, n_q)
+    scores = ue.astype(np.float64) @ ie.astype(np.float64).T
+    train = [np.sort(rng.choice(n_i, 30, replace=False)) for _ in range(n_q)]
+    if layout == "few_eligible":
+        train[0] = np.sort(np.argsort(-scores[0, :4096])[:4000])      # almost the whole sample is masked
+    rowptr = np.concatenate([[0], np.cumsum([len(t) for t in train])]).astype(np.int64)
+    items = np.concatenate(train).astype(np.int32)
+    got_i, got_s = rank_topk(torch.from_numpy(ue).cuda(), torch.from_numpy(ie).cuda(), np.arange(n_q),
+                             torch.from_numpy(rowptr).cuda(), torch.from_numpy(items).cuda(), k)
+    got_i, got_s = got_i.cpu().numpy(), got_s.cpu().numpy()
+    for q in range(n_q):
+        row = scores[q].copy()
+        row[train[q]] = -np.inf
+        ref = np.argsort(-row, kind="stable")[:k]
+        np.testing.assert_allclose(got_s[q], row[ref], rtol=1e-5, atol=1e-5)
+        diff = got_i[q] != ref
+        # different ids only where the float64 scores are within f32 rounding of each other
+        assert np.all(np.abs(row[got_i[q][diff]] - row[ref[diff]]) < 1e-5), (layout, q)
+        assert len(set(got_i[q].tolist())) == k and not (set(got_i[q].tolist()) & set(train[q].tolist()))

@@ -403,6 +403,42 @@ int32_t gcr_edge_mask_exact_bits(int64_t nnz, int64_t n_keep, uint64_t seed, uin
                                  void* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The stages either side of the hot path.
+ * --------------------------------------------------------------------------------------------- */
+/*
+ * One fused dense Adam step on an embedding table (torch.optim.Adam as ncl.py:305, lightgcn.py:84, gcl.py:201 use
+ * it: no amsgrad, L2 weight_decay added to the gradient): g = grad_scale * (grad + grad2 + grad3) + weight_decay * p;
+ * m += (1 - beta1) (g - m); v = beta2 v + (1 - beta2) g^2; p -= lr / (1 - beta1^step) * m / (sqrt(v / (1 - beta2^step)) + eps).
+ * grad2 / grad3 are optional further gradient pieces of the same parameter (summed on the way in instead of by
+ * separate element-wise adds).  n a multiple of 4, pointers 16-B aligned; step counts from 1.
+ */
+int32_t gcr_adam_step_f32(float* param, const float* grad, const float* grad2, const float* grad3, float* exp_avg,
+                          float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
+                          float weight_decay, int64_t step, float grad_scale, void* stream);
+
+/* out[r, c] = keep bit c ? x[r, c] : 0 — PyGCL's FeatureMasking / drop_feature (univariate/grace.py:261-278): whole
+ * feature columns zeroed.  keep_bits: bit c of a little-endian uint32 bitmap (gcr_edge_mask_bits(d, pf, seed) draws
+ * it: keep = u_c >= pf, as `uniform_(0, 1) < drop_prob` drops).  The backward is the same call on the gradient. */
+int32_t gcr_mask_columns_f32(const float* x, int64_t n, int32_t d, const uint32_t* keep_bits, float* out, void* stream);
+
+/*
+ * Sparse x sparse product, expand step (MHCN's motif adjacency, univariate/mhcn.py:340-368: U.dot(U), Y.dot(Y.T), ...):
+ * for every non-zero e = (i, k, a) of A and every non-zero (k, j, b) of B's row k one COO entry (i, j, a * b) at
+ * out[offset[e] + position in row k]; offset = exclusive prefix sum of B's row lengths over A's non-zeros (caller),
+ * a_row_of[e] = row of e.  The sort + duplicate sum that completes the product is gcr_coo_to_csr(coalesce = 1).
+ * a_val / b_val NULL = ones.
+ */
+int32_t gcr_spgemm_expand_f32(const int64_t* a_rowptr, const int32_t* a_col, const float* a_val, int64_t a_rows,
+                              int64_t a_nnz, const int32_t* a_row_of, const int64_t* b_rowptr, const int32_t* b_col,
+                              const float* b_val, const int64_t* offset, int64_t* out_row, int64_t* out_col,
+                              float* out_val, void* stream);
+
+/* out[e] = value of (row_of[e], col[e]) in the CSR m (columns ascending inside a row; m_val NULL = ones), 0 when it
+ * is not stored: the sparse element-wise products `.multiply(U.T)` / `.multiply(B)` of mhcn.py:340-368. */
+int32_t gcr_csr_lookup_f32(const int32_t* row_of, const int32_t* col, int64_t nnz, const int64_t* m_rowptr,
+                           const int32_t* m_col, const float* m_val, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Memory-system probes (measurement aids for the roofline block of bench.py; SURVEY.md §8d asks for
  * a device-copy bandwidth measured on the box next to the vendor peak).  16 B per lane.
  * --------------------------------------------------------------------------------------------- */

@@ -587,8 +587,26 @@ def gen_buir():
     print("wrote buir.npz: nnz", nnz, "kept", int(np.floor(1 - rate + draws[0]).sum()))
 
 
+def gen_featmask():
+    """tests/golden/featmask.npz: univariate/grace.py's drop_feature (:261-267, what FeatureMasking.augment calls),
+    lifted from the AST (the module imports torch_geometric) and run unchanged under a fixed torch seed."""
+    ns = load_defs(os.path.join(REF, "univariate", "grace.py"), {"drop_feature"})
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(37, 64, generator=g)
+    out = {}
+    for k, pf in enumerate((0.0, 0.3, 0.7)):
+        torch.manual_seed(100 + k)
+        y = ns["drop_feature"](x, pf)
+        out[f"pf{k}"], out[f"y{k}"] = np.float32(pf), y.numpy()
+    assert torch.equal(x, torch.randn(37, 64, generator=torch.Generator().manual_seed(4)))      # input untouched
+    np.savez_compressed(os.path.join(OUT, "featmask.npz"), x=x.numpy(), **out)
+    print("wrote featmask.npz: dropped columns", [int((out[f"y{k}"] == 0).all(0).sum()) for k in range(3)])
+
+
 if __name__ == "__main__":
-    if "--mhcn" in sys.argv:
+    if "--featmask" in sys.argv:
+        gen_featmask()
+    elif "--mhcn" in sys.argv:
         gen_mhcn()
     elif "--sept-social" in sys.argv:
         gen_sept_social()

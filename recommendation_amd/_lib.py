@@ -67,6 +67,11 @@ SIGNATURES = {
     "gcr_csr_row_norm_f32": (c_int32, [_P, _P, _P, c_int64, _P, _P, _P]),
     "gcr_edge_mask_exact_workspace_bytes": (c_int64, [c_int64]),
     "gcr_edge_mask_exact_bits": (c_int32, [c_int64, c_int64, c_uint64, _P, _P, _P]),
+    "gcr_adam_step_f32": (c_int32, [_P, _P, _P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int64,
+                                    c_float, _P]),
+    "gcr_mask_columns_f32": (c_int32, [_P, c_int64, c_int32, _P, _P, _P]),
+    "gcr_spgemm_expand_f32": (c_int32, [_P, _P, _P, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gcr_csr_lookup_f32": (c_int32, [_P, _P, c_int64, _P, _P, _P, _P, _P]),
     "gcr_probe_copy_f32": (c_int32, [_P, _P, c_int64, _P]),
     "gcr_probe_read_f32": (c_int32, [_P, c_int64, _P, _P]),
     "gcr_probe_gather_rows_f32": (c_int32, [_P, c_int64, _P, c_int64, _P, _P]),

@@ -779,7 +779,11 @@ __global__ __launch_bounds__(256) void rank_metrics_kernel(const int64_t* __rest
         if (test_items[mid] < it) lo = mid + 1; else hi = mid;
       }
       if (lo < hi0 && test_items[lo] == it) {
-        ++h;
+        // the reference counts hits on SETS (a repeated item counts once, ncl.py:136) but adds a DCG gain at every
+        // position holding a test item (ncl.py:157); hits are rare, so the look-back scan is cheap
+        bool seen = false;
+        for (int pp = 0; pp < p && !seen; ++pp) seen = top_items[q * k + pp] == it;
+        h += seen ? 0 : 1;
         d += gain;
       }
     }

@@ -670,3 +670,39 @@ def edge_mask_exact_bits(nnz, n_keep, seed, device):
     _lib.check(L.gcr_edge_mask_exact_bits(int(nnz), int(n_keep), int(seed) & (2 ** 64 - 1), _lib.dptr(bits),
                                           _lib.dptr(ws), _lib.cur_stream(device)), "gcr_edge_mask_exact_bits")
     return bits
+
+
+# ---------------------------------------------------------------------------------------------
+# PyGCL feature masking (univariate/grace.py:261-278)
+# ---------------------------------------------------------------------------------------------
+class _MaskColumns(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, keep_bits):
+        ctx.save_for_backward(keep_bits)
+        return mask_columns_raw(x, keep_bits)
+
+    @staticmethod
+    def backward(ctx, g):
+        (keep_bits,) = ctx.saved_tensors
+        return mask_columns_raw(g, keep_bits), None
+
+
+def mask_columns_raw(x, keep_bits):
+    _lib.require_cuda(x, keep_bits)
+    x = x.contiguous()
+    if x.dim() != 2 or x.dtype != torch.float32 or keep_bits.dtype != torch.int32 or keep_bits.numel() * 32 < x.shape[1]:
+        raise ValueError("x float32 [n, d]; keep_bits int32 bitmap with >= d bits")
+    out = torch.empty_like(x)
+    _lib.check(_lib.lib().gcr_mask_columns_f32(_lib.dptr(x), x.shape[0], x.shape[1], _lib.dptr(keep_bits), _lib.dptr(out),
+                                               _lib.cur_stream(x.device)), "gcr_mask_columns_f32")
+    return out
+
+
+def feature_masking(x, pf, seed, keep_bits=None):
+    """`drop_feature(x, pf)` / FeatureMasking(pf) (univariate/grace.py:261-278): every feature COLUMN is zeroed with
+    probability pf (one draw per column: `uniform_(0, 1) < drop_prob` drops), x itself untouched; differentiable.
+    The d draws come from the counter RNG (gcr_edge_mask_bits over the d column ids: keep = u_c >= pf); pass
+    `keep_bits` to replay a recorded mask.  Returns (masked x, keep_bits)."""
+    if keep_bits is None:
+        keep_bits = edge_mask_bits(x.shape[1], pf, seed, x.device)
+    return _MaskColumns.apply(x, keep_bits), keep_bits

@@ -750,8 +750,9 @@ def bench_extra(ra, Fn, graph, x0, k_layers, nnz, dev, n_u, n_i):
 
     # one whole NCL training step (ncl.py:311-329 without the per-batch e_step): propagate, BPR,
     # structure + prototype contrast, backward, Adam
+    from recommendation_amd.optim import FusedAdam
     xp = torch.nn.Parameter(x0.clone())
-    opt = torch.optim.Adam([xp], lr=1e-3, fused=True)
+    opt = FusedAdam([xp], lr=1e-3)                      # gcr_adam_step_f32 (ncl.py:305 / lightgcn.py:84 torch.optim.Adam)
     jn = Fn.neg_sample(rowptr_u, items_u, uidx, 1, n_i, 3, 0, 101)
 
     def ncl_step():

@@ -410,7 +410,7 @@ int32_t gcr_edge_mask_exact_bits(int64_t nnz, int64_t n_keep, uint64_t seed, uin
  * it: no amsgrad, L2 weight_decay added to the gradient): g = grad_scale * (grad + grad2 + grad3) + weight_decay * p;
  * m += (1 - beta1) (g - m); v = beta2 v + (1 - beta2) g^2; p -= lr / (1 - beta1^step) * m / (sqrt(v / (1 - beta2^step)) + eps).
  * grad2 / grad3 are optional further gradient pieces of the same parameter (summed on the way in instead of by
- * separate element-wise adds).  n a multiple of 4, pointers 16-B aligned; step counts from 1.
+ * separate element-wise adds).  Pointers 16-B aligned; step counts from 1.
  */
 int32_t gcr_adam_step_f32(float* param, const float* grad, const float* grad2, const float* grad3, float* exp_avg,
                           float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,

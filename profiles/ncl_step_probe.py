@@ -18,7 +18,8 @@ n_u, n_i = wl["users"], wl["items"]
 graph = ra.CsrGraph.bipartite_sym_norm(users, items, n_u, n_i, dev)
 xp = torch.nn.Parameter(torch.empty(n_u + n_i, 64, device=dev))
 torch.nn.init.xavier_uniform_(xp)
-opt = torch.optim.Adam([xp], lr=1e-3, fused=True)
+from recommendation_amd.optim import FusedAdam  # noqa: E402
+opt = FusedAdam([xp], lr=1e-3)
 gen = torch.Generator(device=dev).manual_seed(1)
 bsz = 2048
 uidx = torch.randint(0, n_u, (bsz,), device=dev, generator=gen)

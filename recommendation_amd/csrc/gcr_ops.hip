@@ -13,7 +13,7 @@ namespace {
 __global__ __launch_bounds__(256) void adam_step_kernel(float4* __restrict__ p, const float4* __restrict__ g1,
                                                         const float4* __restrict__ g2, const float4* __restrict__ g3,
                                                         float4* __restrict__ m, float4* __restrict__ v, int64_t n4,
-                                                        float lr_over_bc1, float beta1, float beta2, float eps,
+                                                        int tail, float lr_over_bc1, float beta1, float beta2, float eps,
                                                         float inv_sqrt_bc2, float weight_decay, float grad_scale) {
   const float omb1 = 1.0f - beta1, omb2 = 1.0f - beta2;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
@@ -39,6 +39,21 @@ __global__ __launch_bounds__(256) void adam_step_kernel(float4* __restrict__ p, 
     p[i] = make_float4(pe[0], pe[1], pe[2], pe[3]);
     m[i] = make_float4(me[0], me[1], me[2], me[3]);
     v[i] = make_float4(ve[0], ve[1], ve[2], ve[3]);
+  }
+  if (blockIdx.x == 0 && (int)threadIdx.x < tail) {        // the last n % 4 elements, one per thread
+    const int64_t i = 4 * n4 + threadIdx.x;
+    float* ps = reinterpret_cast<float*>(p);
+    float* ms = reinterpret_cast<float*>(m);
+    float* vs = reinterpret_cast<float*>(v);
+    float g = reinterpret_cast<const float*>(g1)[i];
+    if (g2 != nullptr) g += reinterpret_cast<const float*>(g2)[i];
+    if (g3 != nullptr) g += reinterpret_cast<const float*>(g3)[i];
+    g = fmaf(weight_decay, ps[i], g * grad_scale);
+    const float mm = fmaf(omb1, g - ms[i], ms[i]);
+    const float vv = fmaf(beta2, vs[i], omb2 * g * g);
+    ps[i] -= lr_over_bc1 * (mm / (sqrtf(vv) * inv_sqrt_bc2 + eps));
+    ms[i] = mm;
+    vs[i] = vv;
   }
 }
 
@@ -99,16 +114,16 @@ int ops_grid(int64_t n, int per_block) {
 extern "C" int32_t gcr_adam_step_f32(float* param, const float* grad, const float* grad2, const float* grad3,
                                      float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
                                      float eps, float weight_decay, int64_t step, float grad_scale, void* stream) {
-  GCR_CHECK_ARG(n >= 0 && (n & 3) == 0 && step >= 1);
+  GCR_CHECK_ARG(n >= 0 && step >= 1);
   GCR_CHECK_ARG(lr >= 0.f && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f);
   if (n == 0) return GCR_OK;
   GCR_CHECK_ARG(param && grad && exp_avg && exp_avg_sq);
   GCR_CHECK_ARG((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)grad2 | (uintptr_t)grad3 | (uintptr_t)exp_avg |
                   (uintptr_t)exp_avg_sq) & 15) == 0);
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-  hipLaunchKernelGGL(adam_step_kernel, dim3(ops_grid(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, (float4*)param,
+  hipLaunchKernelGGL(adam_step_kernel, dim3(ops_grid(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, (float4*)param,
                      (const float4*)grad, (const float4*)grad2, (const float4*)grad3, (float4*)exp_avg, (float4*)exp_avg_sq,
-                     n / 4, (float)((double)lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), weight_decay, grad_scale);
+                     n / 4, (int)(n & 3), (float)((double)lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), weight_decay, grad_scale);
   return GCR_LAUNCH_STATUS();
 }
 

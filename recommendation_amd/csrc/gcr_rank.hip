@@ -142,10 +142,10 @@ __device__ __forceinline__ uint32_t order_key(float f) {
 //   pass 0 (MODE 0)  scores of every query user against the first kSample items, written dense to a small
 //                    [Q, kSample] buffer; rank_threshold_kernel masks the training positives in it and takes the
 //                    k-th largest: a lower bound thr[q] of the row's k-th largest eligible score;
-//   pass 1 (MODE 1)  the same score tiles over ALL items; a score >= thr[q] whose item is not a training
-//                    positive of the user (binary search in the sorted row) is appended to the user's candidate
+//   pass 1 (MODE 1)  the same score tiles over ALL items; a score >= thr[q] is appended to the user's candidate
 //                    list — about k * I / kSample entries per user instead of I scores;
-//   rank_finish      gathers a user's candidates, bitonic-sorts them in LDS, writes the exact top-k
+//   rank_finish      gathers a user's candidates, drops the training positives among them (binary search in the
+//                    user's sorted row), bitonic-sorts the rest in LDS, writes the exact top-k
 //                    (ties -> smaller item id).  A list that overflowed (or came up short) sets status[q] = 1 and
 //                    the host re-ranks that user through gcr_score_rows_f32 + gcr_topk_masked_f32.
 // Score tile: the split-operand bf16 MFMA (gcr_b3.h, f32-accurate), users stationary on the lanes (64 per wave),
@@ -257,11 +257,11 @@ __global__ __launch_bounds__(256, 2) void rank_fused_b3_kernel(
             for (int r = 0; r < 16; ++r) {
               const int64_t j = j0 + acc_row(r, h);
               if (acc[t][r] >= thr_l[t] && j < n_items) {
-                if (user_rowptr == nullptr || !is_train_item(user_rowptr, user_items, uid[t], (int32_t)j)) {
-                  if (cnt[t] < cap_split)
-                    region[cnt[t]] = ((unsigned long long)order_key(acc[t][r]) << 32) | (0xFFFFFFFFu - (uint32_t)j);
-                  ++cnt[t];                            // keeps counting past the capacity: overflow is detected
-                }
+                // training positives are weeded out by rank_finish_kernel (a binary search in global memory here
+                // would stall the wave that feeds the matrix pipe)
+                if (cnt[t] < cap_split)
+                  region[cnt[t]] = ((unsigned long long)order_key(acc[t][r]) << 32) | (0xFFFFFFFFu - (uint32_t)j);
+                ++cnt[t];                              // keeps counting past the capacity: overflow is detected
               }
             }
           }
@@ -478,10 +478,13 @@ __global__ __launch_bounds__(kTopThreads) void rank_threshold_kernel(const float
 __global__ __launch_bounds__(kTopThreads) void rank_finish_kernel(const unsigned long long* __restrict__ cand_g,
                                                                   const int32_t* __restrict__ counts, int n_regions,
                                                                   int cap_split, int64_t n_query, int k,
+                                                                  const int64_t* __restrict__ user_ids, int64_t n_users,
+                                                                  const int64_t* __restrict__ user_rowptr,
+                                                                  const int32_t* __restrict__ user_items,
                                                                   int64_t* __restrict__ top_items,
                                                                   float* __restrict__ top_scores, int32_t* __restrict__ status) {
   __shared__ unsigned long long cand[kFuseCap];
-  __shared__ int s_total, s_bad;
+  __shared__ int s_total, s_bad, s_masked;
   const int tid = threadIdx.x;
   for (int64_t q = blockIdx.x; q < n_query; q += gridDim.x) {
     if (tid == 0) {
@@ -493,6 +496,7 @@ __global__ __launch_bounds__(kTopThreads) void rank_finish_kernel(const unsigned
       }
       s_total = total;
       s_bad = bad || total > kFuseCap || total < k;
+      s_masked = 0;
     }
     __syncthreads();
     const int total = s_total;
@@ -510,10 +514,27 @@ __global__ __launch_bounds__(kTopThreads) void rank_finish_kernel(const unsigned
       for (int i = tid; i < c; i += kTopThreads) cand[base + i] = src[i];
       base += c;
     }
+    __syncthreads();
+    // training positives among the candidates sink to the end (key 0 is below every real score)
+    const int64_t uid = user_ids != nullptr ? user_ids[q] : q;
+    if (user_rowptr != nullptr && uid >= 0 && uid < n_users) {
+      for (int i = tid; i < total; i += kTopThreads) {
+        const int32_t j = (int32_t)(0xFFFFFFFFu - (uint32_t)(cand[i] & 0xFFFFFFFFull));
+        if (is_train_item(user_rowptr, user_items, uid, j)) {
+          cand[i] = 0ull;
+          atomicAdd(&s_masked, 1);
+        }
+      }
+    }
     int n2 = 1;
     while (n2 < total) n2 <<= 1;
     for (int i = total + tid; i < n2; i += kTopThreads) cand[i] = 0ull;
     __syncthreads();
+    if (total - s_masked < k) {                      // cannot happen when the threshold came from >= k eligible items
+      if (tid == 0) status[q] = 1;
+      __syncthreads();
+      continue;
+    }
     for (int size = 2; size <= n2; size <<= 1) {
       for (int stride = size >> 1; stride > 0; stride >>= 1) {
         for (int i = tid; i < n2; i += kTopThreads) {
@@ -740,7 +761,7 @@ int32_t launch_fused(const float* user_emb, const int64_t* user_ids, int64_t n_q
   st = GCR_LAUNCH_STATUS();
   if (st != GCR_OK) return st;
   hipLaunchKernelGGL(rank_finish_kernel, dim3((unsigned)tb), dim3(kTopThreads), 0, s, cand, counts, 2 * p.nsplit,
-                     p.cap_split, n_query, k, top_items, top_scores, status);
+                     p.cap_split, n_query, k, user_ids, n_users, user_rowptr, user_items, top_items, top_scores, status);
   return GCR_LAUNCH_STATUS();
 }
 

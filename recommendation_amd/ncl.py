@@ -19,6 +19,7 @@ from . import losses as Ls
 from .encoders import Interaction, LGCNEncoder
 from .evaluate import ranking_evaluation, test as rank_test
 from .kmeans import run_kmeans
+from .optim import FusedAdam
 from .sampler import next_batch_pairwise
 
 
@@ -96,7 +97,7 @@ class NCLModel:
         return rec_loss, ssl_loss, proto_loss, total
 
     def train(self):
-        optimizer = torch.optim.Adam(self.model.parameters(), lr=self.lRate, fused=True)   # one pass over p, g, m, v (ncl.py:305 semantics)
+        optimizer = FusedAdam(self.model.parameters(), lr=self.lRate)      # ncl.py:305 torch.optim.Adam: gcr_adam_step_f32
         self.model.train()
         for epoch in range(self.max_epoch):
             self.e_step()

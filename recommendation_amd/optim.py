@@ -30,8 +30,8 @@ class FusedAdam(torch.optim.Optimizer):
                 if p.grad is None:
                     continue
                 _lib.require_cuda(p, p.grad)
-                if p.dtype != torch.float32 or not p.is_contiguous() or p.numel() % 4:
-                    raise ValueError("FusedAdam needs contiguous float32 parameters with a multiple of 4 elements")
+                if p.dtype != torch.float32 or not p.is_contiguous():
+                    raise ValueError("FusedAdam needs contiguous float32 parameters")
                 st = self.state[p]
                 if not st:
                     st["step"] = 0

@@ -25,6 +25,8 @@ if [ "$WHAT" = "nce" ] || [ "$WHAT" = "all" ]; then
   echo "infonce passes done"
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_ncl" -- python3 "$R/profiles/ncl_step_probe.py" > "$OUT/kt_ncl.log" 2>&1
   echo "ncl step pass done"
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_rank" -- python3 "$R/profiles/rank_probe.py" > "$OUT/kt_rank.log" 2>&1
+  echo "rank pass done"
 fi
 # keep the merge-back small: only the CSV summaries are read afterwards
 find "$OUT" -name "*.db" -delete 2>/dev/null || true

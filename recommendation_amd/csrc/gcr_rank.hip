@@ -474,7 +474,8 @@ __global__ __launch_bounds__(kTopThreads) void rank_threshold_kernel(const float
   }
 }
 
-// exact top-k of one user from its candidate regions (bitonic sort in LDS); status[q] = 1 asks for the fallback
+// exact top-k of one user from its candidate regions (radix select of the k-th key in LDS, then a bitonic sort of
+// the k winners only); status[q] = 1 asks for the fallback
 __global__ __launch_bounds__(kTopThreads) void rank_finish_kernel(const unsigned long long* __restrict__ cand_g,
                                                                   const int32_t* __restrict__ counts, int n_regions,
                                                                   int cap_split, int64_t n_query, int k,
@@ -484,6 +485,11 @@ __global__ __launch_bounds__(kTopThreads) void rank_finish_kernel(const unsigned
                                                                   int64_t* __restrict__ top_items,
                                                                   float* __restrict__ top_scores, int32_t* __restrict__ status) {
   __shared__ unsigned long long cand[kFuseCap];
+  __shared__ unsigned long long win[kMaxK];
+  __shared__ unsigned long long eq[kEqCap];
+  __shared__ uint32_t hist[2048];
+  __shared__ uint32_t sh[kTopThreads + 2];
+  __shared__ uint32_t n_gt, n_eq;
   __shared__ int s_total, s_bad, s_masked;
   const int tid = threadIdx.x;
   for (int64_t q = blockIdx.x; q < n_query; q += gridDim.x) {
@@ -526,25 +532,74 @@ __global__ __launch_bounds__(kTopThreads) void rank_finish_kernel(const unsigned
         }
       }
     }
-    int n2 = 1;
-    while (n2 < total) n2 <<= 1;
-    for (int i = total + tid; i < n2; i += kTopThreads) cand[i] = 0ull;
     __syncthreads();
     if (total - s_masked < k) {                      // cannot happen when the threshold came from >= k eligible items
       if (tid == 0) status[q] = 1;
       __syncthreads();
       continue;
     }
+    // k largest of the `total` distinct 64-bit entries: 3-pass radix select on the 32-bit score key (the masked
+    // entries carry key 0), the winners gathered, then a bitonic sort of k entries only
+    uint32_t prefix = 0, want = (uint32_t)k, above = 0;
+    const int shifts[3] = {21, 10, 0}, widths[3] = {11, 11, 10};
+    for (int pass = 0; pass < 3; ++pass) {
+      const int nb = 1 << widths[pass];
+      for (int b2 = tid; b2 < nb; b2 += kTopThreads) hist[b2] = 0;
+      __syncthreads();
+      for (int i = tid; i < total; i += kTopThreads) {
+        const uint32_t key = (uint32_t)(cand[i] >> 32);
+        const bool in_prefix = pass == 0 || (key >> (shifts[pass] + widths[pass])) == prefix;
+        if (in_prefix) atomicAdd(&hist[(key >> shifts[pass]) & (uint32_t)(nb - 1)], 1u);
+      }
+      __syncthreads();
+      const uint32_t bin = (uint32_t)pick_bin(hist, nb, want, &above, sh);
+      want -= above;
+      prefix = (prefix << widths[pass]) | bin;
+    }
+    const uint32_t thr_key = prefix, need_eq = want;     // take every key > thr_key and `need_eq` of the keys == thr_key
+    if (tid == 0) {
+      n_gt = 0;
+      n_eq = 0;
+    }
+    __syncthreads();
+    for (int i = tid; i < total; i += kTopThreads) {
+      const unsigned long long e = cand[i];
+      const uint32_t key = (uint32_t)(e >> 32);
+      if (key > thr_key) {
+        win[atomicAdd(&n_gt, 1u)] = e;                   // < k of them by construction
+      } else if (key == thr_key) {
+        const uint32_t p = atomicAdd(&n_eq, 1u);
+        if (p < (uint32_t)kEqCap) eq[p] = e;
+      }
+    }
+    __syncthreads();
+    const uint32_t gt = n_gt, ne = n_eq;
+    if (ne > (uint32_t)kEqCap) {                       // a huge tie group at the threshold: exact fallback
+      if (tid == 0) status[q] = 1;
+      __syncthreads();
+      continue;
+    }
+    for (uint32_t a2 = tid; a2 < ne; a2 += kTopThreads) {     // ties: larger low word = smaller item id first
+      const unsigned long long me = eq[a2];
+      uint32_t rank = 0;
+      for (uint32_t b2 = 0; b2 < ne; ++b2) rank += eq[b2] > me;
+      if (rank < need_eq) win[gt + rank] = me;
+    }
+    int n2 = 1;
+    while (n2 < k) n2 <<= 1;
+    __syncthreads();
+    for (int i = k + tid; i < n2; i += kTopThreads) win[i] = 0ull;
+    __syncthreads();
     for (int size = 2; size <= n2; size <<= 1) {
       for (int stride = size >> 1; stride > 0; stride >>= 1) {
         for (int i = tid; i < n2; i += kTopThreads) {
           const int partner = i ^ stride;
           if (partner > i) {
             const bool desc = (i & size) == 0;
-            const unsigned long long x = cand[i], y = cand[partner];
+            const unsigned long long x = win[i], y = win[partner];
             if ((x < y) == desc) {
-              cand[i] = y;
-              cand[partner] = x;
+              win[i] = y;
+              win[partner] = x;
             }
           }
         }
@@ -552,8 +607,8 @@ __global__ __launch_bounds__(kTopThreads) void rank_finish_kernel(const unsigned
       }
     }
     for (int i = tid; i < k; i += kTopThreads) {
-      top_items[q * k + i] = (int64_t)(0xFFFFFFFFu - (uint32_t)(cand[i] & 0xFFFFFFFFull));
-      top_scores[q * k + i] = key_to_float((uint32_t)(cand[i] >> 32));
+      top_items[q * k + i] = (int64_t)(0xFFFFFFFFu - (uint32_t)(win[i] & 0xFFFFFFFFull));
+      top_scores[q * k + i] = key_to_float((uint32_t)(win[i] >> 32));
     }
     __syncthreads();
   }

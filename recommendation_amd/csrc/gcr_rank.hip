@@ -524,11 +524,33 @@ __global__ __launch_bounds__(kTopThreads) void rank_finish_kernel(const unsigned
     // training positives among the candidates sink to the end (key 0 is below every real score)
     const int64_t uid = user_ids != nullptr ? user_ids[q] : q;
     if (user_rowptr != nullptr && uid >= 0 && uid < n_users) {
-      for (int i = tid; i < total; i += kTopThreads) {
-        const int32_t j = (int32_t)(0xFFFFFFFFu - (uint32_t)(cand[i] & 0xFFFFFFFFull));
-        if (is_train_item(user_rowptr, user_items, uid, j)) {
-          cand[i] = 0ull;
-          atomicAdd(&s_masked, 1);
+      const int64_t t0 = user_rowptr[uid], t1 = user_rowptr[uid + 1];
+      const int n_train = (int)(t1 - t0);
+      if (n_train <= kEqCap * 2) {
+        // the user's sorted training row staged in LDS (the tie buffer is free until the select): the binary
+        // searches of all candidates then never leave the CU
+        int32_t* trow = reinterpret_cast<int32_t*>(eq);
+        for (int i = tid; i < n_train; i += kTopThreads) trow[i] = user_items[t0 + i];
+        __syncthreads();
+        for (int i = tid; i < total; i += kTopThreads) {
+          const int32_t j = (int32_t)(0xFFFFFFFFu - (uint32_t)(cand[i] & 0xFFFFFFFFull));
+          int lo = 0, hi = n_train;
+          while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (trow[mid] < j) lo = mid + 1; else hi = mid;
+          }
+          if (lo < n_train && trow[lo] == j) {
+            cand[i] = 0ull;
+            atomicAdd(&s_masked, 1);
+          }
+        }
+      } else {
+        for (int i = tid; i < total; i += kTopThreads) {
+          const int32_t j = (int32_t)(0xFFFFFFFFu - (uint32_t)(cand[i] & 0xFFFFFFFFull));
+          if (is_train_item(user_rowptr, user_items, uid, j)) {
+            cand[i] = 0ull;
+            atomicAdd(&s_masked, 1);
+          }
         }
       }
     }

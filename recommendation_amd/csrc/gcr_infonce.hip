@@ -1323,6 +1323,290 @@ __global__ __launch_bounds__(256, 2) void infonce_fwdo_b3_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Two-product tile loop, software-pipelined ACROSS tiles (d <= 64): the exposed part of the loops above is
+// the VALU work between the two MFMA phases (P from the scores + its bf16 split: ~150 instructions per
+// tile against ~1500 cycles of MFMA, ~50 % MFMA-busy measured).  Here step t runs
+//     phase A   score MFMAs of tile t+1          ||  operand split + LDS stores of tile t+2 (staging)
+//     phase B   second-product MFMAs of tile t   ||  P(t+1) from the finished scores + its bf16 split
+// so every VALU instruction sits in an MFMA shadow; one barrier per step.  LDS: the row-major planes
+// (score operand) are double-buffered, the transposed planes (second-product operand) live three tiles
+// (t read in B, t+1 waiting, t+2 being written in A): 2 x 13.5 + 3 x 13.5 KB = 67.5 KB, two blocks per CU.
+//   MODE 0  backward: P = w_x e^{s - lse_x} + w_y e^{s - lse_y}   (infonce_bwd_b3_kernel's arithmetic)
+//   MODE 1  forward with the weighted row sum (infonce_fwdo_b3_kernel's arithmetic): online reference point,
+//           the rare rescale of the accumulators happens between two B phases.
+// ------------------------------------------------------------------------------------------
+template <int D, int MODE, bool EXD, int SIDES>
+__global__ __launch_bounds__(256, 2) void infonce_pipe_b3_kernel(
+    const float* __restrict__ x, const float* __restrict__ x_scale, int64_t mx, const float* __restrict__ y,
+    const float* __restrict__ y_scale, int64_t ny, float scale2, float out_scale, const float* __restrict__ lse_x,
+    const float* __restrict__ w_x, const float* __restrict__ lse_y, const float* __restrict__ w_y, int nsplit,
+    int64_t tiles_per_split, float* __restrict__ gpart, float2* __restrict__ part) {
+  using S = ShapeB3<D>;
+  using B = BwdB3<D>;
+  static_assert(D <= 64, "the pipelined loop keeps five plane sets in LDS");
+  constexpr int RM = 3 * S::PLANE, TR = 3 * B::TPLANE;
+  __shared__ __align__(16) unsigned char lds_rm[2][RM];
+  __shared__ __align__(16) unsigned char lds_tr[3][TR];
+  __shared__ __align__(16) float st_lse[2][kTileJ];
+  __shared__ __align__(16) float st_w[2][kTileJ];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i32 = lane & 31, h = lane >> 5;
+  const int64_t mblk = blockIdx.x / nsplit;
+  const int split = blockIdx.x % nsplit;
+  const int64_t row_i = (mblk * 4 + wave) * 32 + i32;
+
+  u32x4 bq[1][3][S::KC];
+  load_stationary_b3<D>(x, x_scale, mx, row_i, h, scale2, bq[0]);
+  const bool on_x = MODE == 0 && row_i < mx && w_x != nullptr;
+  const float wl = on_x ? w_x[row_i] : 0.f;
+  const float lse2l = on_x ? lse_x[row_i] * kLog2e : 1.0e30f;
+  float m_run = kNegBig, l_run = 0.f;                   // MODE 1
+  f32x16 gacc[B::CT];
+#pragma unroll
+  for (int c = 0; c < B::CT; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gacc[c][r] = 0.f;
+
+  const int64_t total_tiles = (ny + kTileJ - 1) / kTileJ;
+  const int64_t tile0 = (int64_t)split * tiles_per_split;
+  const int64_t tile1 = min(total_tiles, tile0 + tiles_per_split);
+  if (tile0 < tile1) {
+    constexpr int NP = 4 * S::NLD, NS1 = 6 * S::KC, NG = B::CT * 12;
+    constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+    const int64_t last = tile1 - 1;
+    float4 ra[S::NLD], rb[S::NLD];
+    float sla = 0.f, swa = 0.f, slb = 0.f, swb = 0.f;
+    auto load_tile = [&](int64_t t, float4 (&r)[S::NLD], float& sl, float& sw) {
+      const int64_t j0 = min(t, last) * kTileJ;
+      stage_load<D>(y, y_scale, ny, j0, tid, r);
+      if (MODE == 0 && tid < kTileJ) {
+        const int64_t j = j0 + tid;
+        const bool on = j < ny && w_y != nullptr;
+        sw = on ? w_y[j] : 0.f;
+        sl = on ? lse_y[j] * kLog2e : 1.0e30f;
+      }
+    };
+    // one quarter of the staging of one float4: split (x, y), split (z, w), row-major stores, transposed stores
+    auto stage_part = [&](int pi, const float4 (&st)[S::NLD], unsigned (&sa)[S::NLD][3], unsigned (&sb)[S::NLD][3],
+                          unsigned char* rm, unsigned char* tr, int sbuf, float sl, float sw) {
+      const int u = pi / 4, k = pi % 4;
+      const int idx = tid + 256 * u;
+      const int row = idx / (D / 4), c4 = idx % (D / 4);
+      if (k == 0) {
+        split3(st[u].x, st[u].y, sa[u][0], sa[u][1], sa[u][2]);
+      } else if (k == 1) {
+        split3(st[u].z, st[u].w, sb[u][0], sb[u][1], sb[u][2]);
+      } else if (k == 2) {
+        unsigned char* p = rm + row * S::ROWB + c4 * 8;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint2*>(p + pl * S::PLANE) = make_uint2(sa[u][pl], sb[u][pl]);
+        if (MODE == 0 && u == 0 && tid < kTileJ) {
+          st_lse[sbuf][tid] = sl;
+          st_w[sbuf][tid] = sw;
+        }
+      } else {
+        unsigned short* q = reinterpret_cast<unsigned short*>(tr + (4 * c4) * B::RT + row * 2);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          unsigned short* qq = q + pl * (B::TPLANE / 2);
+          qq[0] = (unsigned short)(sa[u][pl] & 0xffffu);
+          qq[B::RT / 2] = (unsigned short)(sa[u][pl] >> 16);
+          qq[2 * (B::RT / 2)] = (unsigned short)(sb[u][pl] & 0xffffu);
+          qq[3 * (B::RT / 2)] = (unsigned short)(sb[u][pl] >> 16);
+        }
+      }
+    };
+    auto stage_all = [&](const float4 (&st)[S::NLD], unsigned char* rm, unsigned char* tr, int sbuf, float sl, float sw) {
+      unsigned sa[S::NLD][3], sb[S::NLD][3];
+#pragma unroll
+      for (int pi = 0; pi < NP; ++pi) stage_part(pi, st, sa, sb, rm, tr, sbuf, sl, sw);
+    };
+    // micro-unit m of P(t) from the finished scores of tile t: MODE 0: 0..15 one register each, 16..23 one split3
+    // each; MODE 1: the same after `prepare` fixed the reference point.
+    float m_use = kNegBig, alpha = 1.0f, psum = 0.f;
+    bool rescale = false;
+    auto prepare = [&](f32x16& acc, int64_t t) {        // masks (ragged tile / excluded diagonal); MODE 1: reference point
+      const int64_t j0 = t * kTileJ;
+      if (EXD || j0 + kTileJ > ny) {
+        const int xr = EXD ? diag_offset(row_i, j0, h) : -1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * g + e;
+            const bool dead = (j0 + acc_row(r, h) >= ny) || (EXD && xr == e + 8 * g);
+            acc[r] = dead ? -INFINITY : acc[r];
+          }
+      }
+      if (MODE == 1) {
+        float tmax = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
+#pragma unroll
+        for (int g = 1; g < 4; ++g)
+          tmax = fmaxf(tmax, fmaxf(fmaxf(acc[4 * g], acc[4 * g + 1]), fmaxf(acc[4 * g + 2], acc[4 * g + 3])));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        rescale = __any(tmax > m_run + kDefer);
+        m_use = rescale ? fmaxf(m_run, tmax) : m_run;
+        alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+        psum = 0.f;
+      }
+    };
+    auto p_unit = [&](int m, f32x16& acc, int sbuf, unsigned (&pq)[2][3][4]) {
+      if (m < 16) {
+        const int r = m;
+        if (MODE == 1) {
+          acc[r] = __builtin_amdgcn_exp2f(acc[r] - m_use);
+          psum += acc[r];
+        } else {
+          const float lre = st_lse[sbuf][acc_row(r, h)], wre = st_w[sbuf][acc_row(r, h)];
+          const float sc = acc[r];
+          if (SIDES == 1) acc[r] = wl * __builtin_amdgcn_exp2f(sc - lse2l);
+          else if (SIDES == 2) acc[r] = wre * __builtin_amdgcn_exp2f(sc - lre);
+          else acc[r] = wl * __builtin_amdgcn_exp2f(sc - lse2l) + wre * __builtin_amdgcn_exp2f(sc - lre);
+        }
+      } else {
+        const int e = m - 16;                            // pair (2e, 2e + 1): k-chunk e / 4, dword e % 4
+        split3(acc[2 * e], acc[2 * e + 1], pq[e >> 2][0][e & 3], pq[e >> 2][1][e & 3], pq[e >> 2][2][e & 3]);
+      }
+    };
+    auto finish_p = [&]() {                               // MODE 1: between two B phases
+      if (MODE == 1) {
+        if (rescale) {
+          l_run *= alpha;
+#pragma unroll
+          for (int c = 0; c < B::CT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gacc[c][r] *= alpha;
+          m_run = m_use;
+        }
+        l_run += psum;
+      }
+    };
+    auto score_plain = [&](const unsigned char* rm, f32x16& acc) {
+      f32x16 a1[1];
+      score_tile_b3<D, 1>(rm, i32, h, bq, a1);
+      acc = a1[0];
+    };
+
+    // ---- prologue: tiles 0 and 1 staged, P(tile0) ready, tile 2 in registers, tile 3 loading
+    unsigned pqa[2][3][4], pqb[2][3][4];
+    f32x16 acc;
+    load_tile(tile0, ra, sla, swa);
+    stage_all(ra, lds_rm[0], lds_tr[0], 0, sla, swa);
+    load_tile(tile0 + 1, ra, sla, swa);
+    stage_all(ra, lds_rm[1], lds_tr[1], 1, sla, swa);
+    load_tile(tile0 + 2, ra, sla, swa);
+    __syncthreads();
+    score_plain(lds_rm[0], acc);
+    prepare(acc, tile0);
+#pragma unroll
+    for (int m = 0; m < 24; ++m) p_unit(m, acc, 0, pqa);
+    finish_p();
+    __syncthreads();                                     // every wave is done with rm[0] before step 0 restages it
+
+    // step t: tile t's P planes in `pc`, tile t+2 in `st` registers; produces P(t+1) in `pn`, loads tile t+3 to `ld`
+    auto step = [&](int64_t t, int k3, unsigned (&pc)[2][3][4], unsigned (&pn)[2][3][4], const float4 (&st)[S::NLD],
+                    float st_l, float st_w_v, float4 (&ld)[S::NLD], float& ld_l, float& ld_w) {
+      const int par = (int)((t - tile0) & 1);            // tile t lives in rm[par] (already consumed), t+1 in rm[par ^ 1]
+      load_tile(t + 3, ld, ld_l, ld_w);
+      unsigned char* rm_out = lds_rm[par];
+      unsigned char* tr_out = lds_tr[(k3 + 2) % 3];
+      unsigned sa[S::NLD][3], sb[S::NLD][3];
+      // phase A: S^T of tile t+1 || staging of tile t+2
+      {
+        const unsigned char* base = lds_rm[par ^ 1] + i32 * S::ROWB + h * (S::KH * 2);
+        u32x4 ap[2][3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) ap[0][pl] = *reinterpret_cast<const u32x4*>(base + pl * S::PLANE);
+#pragma unroll
+        for (int c = 0; c < S::KC; ++c) {
+          if (c + 1 < S::KC) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+              ap[(c + 1) & 1][pl] = *reinterpret_cast<const u32x4*>(base + pl * S::PLANE + 16 * (c + 1));
+          }
+#pragma unroll
+          for (int term = 0; term < 6; ++term) {
+            const int slot = c * 6 + term;
+            f32x16 cin = acc;
+            if (slot == 0) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) cin[r] = 0.f;
+            }
+            acc = mfma_bf16(ap[c & 1][TA[term]], bq[0][TB[term]][c], cin);
+#pragma unroll
+            for (int pi = slot * NP / NS1; pi < (slot + 1) * NP / NS1; ++pi)
+              stage_part(pi, st, sa, sb, rm_out, tr_out, par, st_l, st_w_v);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+      const bool real_next = t + 1 < tile1;                // the tile after the split's last one is a clamped repeat
+      if (MODE == 0 || real_next) prepare(acc, t + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      // phase B: second product of tile t || P(t+1)
+      const unsigned char* tbase = lds_tr[k3] + i32 * B::RT + 8 * h;
+      auto load_ya = [&](int grp, u32x4 (&ya)[3]) {     // grp = kc * CT + c
+        const int kc = grp / B::CT, c = grp % B::CT;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          const unsigned char* p = tbase + pl * B::TPLANE + (32 * c) * B::RT + 32 * kc;
+          const uint2 lo = *reinterpret_cast<const uint2*>(p);
+          const uint2 hi = *reinterpret_cast<const uint2*>(p + 16);
+          ya[pl] = (u32x4){lo.x, lo.y, hi.x, hi.y};
+        }
+      };
+      u32x4 ya[2][3];
+      load_ya(0, ya[0]);
+#pragma unroll
+      for (int grp = 0; grp < 2 * B::CT; ++grp) {
+        const int kc = grp / B::CT, c = grp % B::CT;
+        if (grp + 1 < 2 * B::CT) load_ya(grp + 1, ya[(grp + 1) & 1]);
+        u32x4 pp[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) pp[pl] = (u32x4){pc[kc][pl][0], pc[kc][pl][1], pc[kc][pl][2], pc[kc][pl][3]};
+#pragma unroll
+        for (int term = 0; term < 6; ++term) {
+          gacc[c] = mfma_bf16(ya[grp & 1][TA[term]], pp[TB[term]], gacc[c]);
+          const int slot = grp * 6 + term;
+          if (MODE == 0 || real_next) {
+#pragma unroll
+            for (int m = slot * 24 / NG; m < (slot + 1) * 24 / NG; ++m) p_unit(m, acc, par ^ 1, pn);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (MODE == 0 || real_next) finish_p();
+      __syncthreads();
+    };
+    int k3 = 0;
+    int64_t tt = tile0;
+    for (; tt + 1 < tile1; tt += 2) {
+      step(tt, k3, pqa, pqb, ra, sla, swa, rb, slb, swb);
+      k3 = (k3 + 1) % 3;
+      step(tt + 1, k3, pqb, pqa, rb, slb, swb, ra, sla, swa);
+      k3 = (k3 + 1) % 3;
+    }
+    if (tt < tile1) step(tt, k3, pqa, pqb, ra, sla, swa, rb, slb, swb);
+  }
+
+  float* gout = gpart + (int64_t)split * mx * D;
+  if (MODE == 1) {
+    const float l_o = __shfl_xor(l_run, 32, 64);
+    if (h == 0 && row_i < mx) part[(int64_t)split * mx + row_i] = make_float2(m_run, l_run + l_o);
+  }
+  if (row_i < mx) {
+#pragma unroll
+    for (int c = 0; c < B::CT; ++c)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 v = make_float4(gacc[c][4 * g + 0] * out_scale, gacc[c][4 * g + 1] * out_scale,
+                               gacc[c][4 * g + 2] * out_scale, gacc[c][4 * g + 3] * out_scale);
+        *reinterpret_cast<float4*>(gout + row_i * D + 32 * c + 8 * g + 4 * h) = v;
+      }
+  }
+}
+
 // lse and o from the per-split partials: o = sum_s O_s 2^(m_s - m) / sum_s l_s 2^(m_s - m)
 __global__ __launch_bounds__(256) void infonce_merge_o_kernel(const float2* __restrict__ part, const float* __restrict__ opart,
                                                               int nsplit, int64_t m_rows, int d, float* __restrict__ lse,
@@ -1426,16 +1710,20 @@ int32_t launch_bwd(const float* x, const float* x_scale, int64_t mx, const float
                    void* workspace, bool exd, bool force_f32, hipStream_t s) {
   if constexpr (D <= 128) {
     if (use_b3(D, force_f32)) {
-      // d <= 64: double-buffered, hand-interleaved; d = 128: single-buffered (one tile with its transposed
-      // copy is 54 KB of LDS)
-      constexpr bool ILV = D <= 64;
+      // d <= 64: the cross-tile pipelined loop (infonce_pipe_b3_kernel); d = 128: single-buffered (one tile with its
+      // transposed copy is 54 KB of LDS)
       const FwdPlan p = plan_bwd_rows(mx, ny, D, BwdB3<D>::ROWS_PER_BLOCK);
       float* gpart = p.nsplit == 1 ? g : reinterpret_cast<float*>(workspace);
       const dim3 grid((unsigned)(p.m_blocks * p.nsplit));
       const bool has_x = w_x != nullptr && lse_x != nullptr, has_y = w_y != nullptr && lse_y != nullptr;
-#define GCR_BWD3(EX, SD)                                                                                              \
-  hipLaunchKernelGGL((infonce_bwd_b3_kernel<D, ILV, EX, SD>), grid, dim3(256), 0, s, x, x_scale, mx, y, y_scale, ny, \
-                     inv_tau * kLog2e, inv_tau, lse_x, w_x, lse_y, w_y, p.nsplit, p.tiles_per_split, gpart)
+#define GCR_BWD3(EX, SD)                                                                                                \
+  if constexpr (D <= 64)                                                                                                \
+    hipLaunchKernelGGL((infonce_pipe_b3_kernel<D, 0, EX, SD>), grid, dim3(256), 0, s, x, x_scale, mx, y, y_scale, ny,   \
+                       inv_tau * kLog2e, inv_tau, lse_x, w_x, lse_y, w_y, p.nsplit, p.tiles_per_split, gpart,           \
+                       (float2*)nullptr);                                                                               \
+  else                                                                                                                  \
+    hipLaunchKernelGGL((infonce_bwd_b3_kernel<D, false, EX, SD>), grid, dim3(256), 0, s, x, x_scale, mx, y, y_scale,    \
+                       ny, inv_tau * kLog2e, inv_tau, lse_x, w_x, lse_y, w_y, p.nsplit, p.tiles_per_split, gpart)
       if (exd) {
         GCR_BWD3(true, 0);
       } else if (has_x && !has_y) {
@@ -1521,17 +1809,26 @@ int32_t launch_fwd(const float* a, const float* a_scale, int64_t m, const float*
 template <int D>
 int32_t launch_fwd_o(const float* a, const float* a_scale, int64_t m, const float* b, const float* b_scale, int64_t n,
                      float inv_tau, float* lse, float* o, void* workspace, bool exd, hipStream_t s) {
-  constexpr bool ILV = D <= 64;
   const FwdPlan p = plan_bwd_rows(m, n, D, BwdB3<D>::ROWS_PER_BLOCK);
   float2* part = reinterpret_cast<float2*>(workspace);
   float* opart = reinterpret_cast<float*>(part + (int64_t)p.nsplit * m);
   const dim3 grid((unsigned)(p.m_blocks * p.nsplit));
-  if (exd)
-    hipLaunchKernelGGL((infonce_fwdo_b3_kernel<D, ILV, true>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale, n,
-                       inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part, opart);
-  else
-    hipLaunchKernelGGL((infonce_fwdo_b3_kernel<D, ILV, false>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale, n,
-                       inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part, opart);
+  if constexpr (D <= 64) {
+    const float* none = nullptr;
+    if (exd)
+      hipLaunchKernelGGL((infonce_pipe_b3_kernel<D, 1, true, 0>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale, n,
+                         inv_tau * kLog2e, 1.0f, none, none, none, none, p.nsplit, p.tiles_per_split, opart, part);
+    else
+      hipLaunchKernelGGL((infonce_pipe_b3_kernel<D, 1, false, 0>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale, n,
+                         inv_tau * kLog2e, 1.0f, none, none, none, none, p.nsplit, p.tiles_per_split, opart, part);
+  } else {
+    if (exd)
+      hipLaunchKernelGGL((infonce_fwdo_b3_kernel<D, false, true>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale, n,
+                         inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part, opart);
+    else
+      hipLaunchKernelGGL((infonce_fwdo_b3_kernel<D, false, false>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale, n,
+                         inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part, opart);
+  }
   int32_t st = GCR_LAUNCH_STATUS();
   if (st != GCR_OK) return st;
   const int64_t threads = m * (D / 4);

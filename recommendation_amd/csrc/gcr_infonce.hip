@@ -1329,13 +1329,20 @@ __global__ __launch_bounds__(256, 2) void infonce_fwdo_b3_kernel(
 // tile against ~1500 cycles of MFMA, ~50 % MFMA-busy measured).  Here step t runs
 //     phase A   score MFMAs of tile t+1          ||  operand split + LDS stores of tile t+2 (staging)
 //     phase B   second-product MFMAs of tile t   ||  P(t+1) from the finished scores + its bf16 split
-// so every VALU instruction sits in an MFMA shadow; one barrier per step.  LDS: the row-major planes
-// (score operand) are double-buffered, the transposed planes (second-product operand) live three tiles
-// (t read in B, t+1 waiting, t+2 being written in A): 2 x 13.5 + 3 x 13.5 KB = 67.5 KB, two blocks per CU.
+// so every VALU instruction sits in an MFMA shadow; one barrier per step.  LDS: ONE row-major image of the
+// three bf16 planes per tile serves both products — `ds_read_b128` rows for the score operand, the
+// transposing `ds_read_b64_tr_b16` for the second product's operand (the 2-byte stores of a transposed copy
+// were 8-way bank-conflicted and made the loop LDS-bound) — in a ring of three tiles (t read in B, t+1 read in
+// A, t+2 being written in A): 3 x 13.5 KB = 40.5 KB.
 //   MODE 0  backward: P = w_x e^{s - lse_x} + w_y e^{s - lse_y}   (infonce_bwd_b3_kernel's arithmetic)
 //   MODE 1  forward with the weighted row sum (infonce_fwdo_b3_kernel's arithmetic): online reference point,
 //           the rare rescale of the accumulators happens between two B phases.
 // ------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 lds_read_tr16(const unsigned char* p) {      // ds_read_b64_tr_b16; EXEC must be all ones
+  return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p));
+}
+
 template <int D, int MODE, bool EXD, int SIDES>
 __global__ __launch_bounds__(256, 2) void infonce_pipe_b3_kernel(
     const float* __restrict__ x, const float* __restrict__ x_scale, int64_t mx, const float* __restrict__ y,
@@ -1345,9 +1352,8 @@ __global__ __launch_bounds__(256, 2) void infonce_pipe_b3_kernel(
   using S = ShapeB3<D>;
   using B = BwdB3<D>;
   static_assert(D <= 64, "the pipelined loop keeps five plane sets in LDS");
-  constexpr int RM = 3 * S::PLANE, TR = 3 * B::TPLANE;
-  __shared__ __align__(16) unsigned char lds_rm[2][RM];
-  __shared__ __align__(16) unsigned char lds_tr[3][TR];
+  constexpr int RM = 3 * S::PLANE;
+  __shared__ __align__(16) unsigned char lds_rm[3][RM];      // ring: tile t (B, transposed reads), t+1 (A), t+2 (staging)
   __shared__ __align__(16) float st_lse[2][kTileJ];
   __shared__ __align__(16) float st_w[2][kTileJ];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1372,7 +1378,7 @@ __global__ __launch_bounds__(256, 2) void infonce_pipe_b3_kernel(
   const int64_t tile0 = (int64_t)split * tiles_per_split;
   const int64_t tile1 = min(total_tiles, tile0 + tiles_per_split);
   if (tile0 < tile1) {
-    constexpr int NP = 4 * S::NLD, NS1 = 6 * S::KC, NG = B::CT * 12;
+    constexpr int NP = 3 * S::NLD, NS1 = 6 * S::KC, NG = B::CT * 12;
     constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
     const int64_t last = tile1 - 1;
     float4 ra[S::NLD], rb[S::NLD];
@@ -1387,17 +1393,17 @@ __global__ __launch_bounds__(256, 2) void infonce_pipe_b3_kernel(
         sl = on ? lse_y[j] * kLog2e : 1.0e30f;
       }
     };
-    // one quarter of the staging of one float4: split (x, y), split (z, w), row-major stores, transposed stores
+    // one third of the staging of one float4: split (x, y), split (z, w), row-major plane stores
     auto stage_part = [&](int pi, const float4 (&st)[S::NLD], unsigned (&sa)[S::NLD][3], unsigned (&sb)[S::NLD][3],
-                          unsigned char* rm, unsigned char* tr, int sbuf, float sl, float sw) {
-      const int u = pi / 4, k = pi % 4;
+                          unsigned char* rm, int sbuf, float sl, float sw) {
+      const int u = pi / 3, k = pi % 3;
       const int idx = tid + 256 * u;
       const int row = idx / (D / 4), c4 = idx % (D / 4);
       if (k == 0) {
         split3(st[u].x, st[u].y, sa[u][0], sa[u][1], sa[u][2]);
       } else if (k == 1) {
         split3(st[u].z, st[u].w, sb[u][0], sb[u][1], sb[u][2]);
-      } else if (k == 2) {
+      } else {
         unsigned char* p = rm + row * S::ROWB + c4 * 8;
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint2*>(p + pl * S::PLANE) = make_uint2(sa[u][pl], sb[u][pl]);
@@ -1405,22 +1411,12 @@ __global__ __launch_bounds__(256, 2) void infonce_pipe_b3_kernel(
           st_lse[sbuf][tid] = sl;
           st_w[sbuf][tid] = sw;
         }
-      } else {
-        unsigned short* q = reinterpret_cast<unsigned short*>(tr + (4 * c4) * B::RT + row * 2);
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-          unsigned short* qq = q + pl * (B::TPLANE / 2);
-          qq[0] = (unsigned short)(sa[u][pl] & 0xffffu);
-          qq[B::RT / 2] = (unsigned short)(sa[u][pl] >> 16);
-          qq[2 * (B::RT / 2)] = (unsigned short)(sb[u][pl] & 0xffffu);
-          qq[3 * (B::RT / 2)] = (unsigned short)(sb[u][pl] >> 16);
-        }
       }
     };
-    auto stage_all = [&](const float4 (&st)[S::NLD], unsigned char* rm, unsigned char* tr, int sbuf, float sl, float sw) {
+    auto stage_all = [&](const float4 (&st)[S::NLD], unsigned char* rm, int sbuf, float sl, float sw) {
       unsigned sa[S::NLD][3], sb[S::NLD][3];
 #pragma unroll
-      for (int pi = 0; pi < NP; ++pi) stage_part(pi, st, sa, sb, rm, tr, sbuf, sl, sw);
+      for (int pi = 0; pi < NP; ++pi) stage_part(pi, st, sa, sb, rm, sbuf, sl, sw);
     };
     // micro-unit m of P(t) from the finished scores of tile t: MODE 0: 0..15 one register each, 16..23 one split3
     // each; MODE 1: the same after `prepare` fixed the reference point.
@@ -1492,9 +1488,9 @@ __global__ __launch_bounds__(256, 2) void infonce_pipe_b3_kernel(
     unsigned pqa[2][3][4], pqb[2][3][4];
     f32x16 acc;
     load_tile(tile0, ra, sla, swa);
-    stage_all(ra, lds_rm[0], lds_tr[0], 0, sla, swa);
+    stage_all(ra, lds_rm[0], 0, sla, swa);
     load_tile(tile0 + 1, ra, sla, swa);
-    stage_all(ra, lds_rm[1], lds_tr[1], 1, sla, swa);
+    stage_all(ra, lds_rm[1], 1, sla, swa);
     load_tile(tile0 + 2, ra, sla, swa);
     __syncthreads();
     score_plain(lds_rm[0], acc);
@@ -1502,19 +1498,18 @@ __global__ __launch_bounds__(256, 2) void infonce_pipe_b3_kernel(
 #pragma unroll
     for (int m = 0; m < 24; ++m) p_unit(m, acc, 0, pqa);
     finish_p();
-    __syncthreads();                                     // every wave is done with rm[0] before step 0 restages it
+    __syncthreads();
 
     // step t: tile t's P planes in `pc`, tile t+2 in `st` registers; produces P(t+1) in `pn`, loads tile t+3 to `ld`
     auto step = [&](int64_t t, int k3, unsigned (&pc)[2][3][4], unsigned (&pn)[2][3][4], const float4 (&st)[S::NLD],
                     float st_l, float st_w_v, float4 (&ld)[S::NLD], float& ld_l, float& ld_w) {
-      const int par = (int)((t - tile0) & 1);            // tile t lives in rm[par] (already consumed), t+1 in rm[par ^ 1]
+      const int par = (int)((t - tile0) & 1);            // parity of tile t (the per-tile statistics are double-buffered)
       load_tile(t + 3, ld, ld_l, ld_w);
-      unsigned char* rm_out = lds_rm[par];
-      unsigned char* tr_out = lds_tr[(k3 + 2) % 3];
+      unsigned char* rm_out = lds_rm[(k3 + 2) % 3];      // tile t in rm[k3], t+1 in rm[k3 + 1], t+2 goes to rm[k3 + 2]
       unsigned sa[S::NLD][3], sb[S::NLD][3];
       // phase A: S^T of tile t+1 || staging of tile t+2
       {
-        const unsigned char* base = lds_rm[par ^ 1] + i32 * S::ROWB + h * (S::KH * 2);
+        const unsigned char* base = lds_rm[(k3 + 1) % 3] + i32 * S::ROWB + h * (S::KH * 2);
         u32x4 ap[2][3];
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) ap[0][pl] = *reinterpret_cast<const u32x4*>(base + pl * S::PLANE);
@@ -1536,7 +1531,7 @@ __global__ __launch_bounds__(256, 2) void infonce_pipe_b3_kernel(
             acc = mfma_bf16(ap[c & 1][TA[term]], bq[0][TB[term]][c], cin);
 #pragma unroll
             for (int pi = slot * NP / NS1; pi < (slot + 1) * NP / NS1; ++pi)
-              stage_part(pi, st, sa, sb, rm_out, tr_out, par, st_l, st_w_v);
+              stage_part(pi, st, sa, sb, rm_out, par, st_l, st_w_v);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -1545,14 +1540,19 @@ __global__ __launch_bounds__(256, 2) void infonce_pipe_b3_kernel(
       if (MODE == 0 || real_next) prepare(acc, t + 1);
       __builtin_amdgcn_sched_barrier(0);
       // phase B: second product of tile t || P(t+1)
-      const unsigned char* tbase = lds_tr[k3] + i32 * B::RT + 8 * h;
+      // A operand yhat^T[feature][tile row] straight from the ROW-MAJOR planes with the transposing LDS read
+      // (ds_read_b64_tr_b16: per 16-lane group a 4-row x 16-column block, lane 4q + p supplies the address of
+      // (row q, columns 4p..4p+3) and receives column `lane & 15`, rows 0..3): no transposed copy of the tile, no
+      // 2-byte stores.  Fragment element j of lane half h is tile row 16 kc + 8 (j >> 2) + 4 h + (j & 3), the
+      // k order of the accumulator-as-operand P planes.
+      const unsigned char* tbase = lds_rm[k3] + (4 * h + ((lane & 15) >> 2)) * S::ROWB + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
       auto load_ya = [&](int grp, u32x4 (&ya)[3]) {     // grp = kc * CT + c
         const int kc = grp / B::CT, c = grp % B::CT;
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
-          const unsigned char* p = tbase + pl * B::TPLANE + (32 * c) * B::RT + 32 * kc;
-          const uint2 lo = *reinterpret_cast<const uint2*>(p);
-          const uint2 hi = *reinterpret_cast<const uint2*>(p + 16);
+          const unsigned char* p = tbase + pl * S::PLANE + (16 * kc) * S::ROWB + 64 * c;
+          const uint2 lo = lds_read_tr16(p);
+          const uint2 hi = lds_read_tr16(p + 8 * S::ROWB);
           ya[pl] = (u32x4){lo.x, lo.y, hi.x, hi.y};
         }
       };

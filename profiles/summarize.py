@@ -118,7 +118,7 @@ if pmc:
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(pmc)):
         k = r["Kernel_Name"]
-        if "infonce_fwd" in k or "infonce_bwd" in k:
+        if "infonce_fwd" in k or "infonce_bwd" in k or "infonce_pipe" in k:
             name = k.split("::")[-1].split("(")[0]          # infonce_fwd_b3_kernel<64, false, true> ...
             agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
     util = {}
@@ -138,9 +138,11 @@ if pmc:
     info_path = os.path.join(root, "gpurun_out", "pmc_probe_infonce.json")
     if util and os.path.exists(info_path):
         info = json.load(open(info_path))
+        # infonce_pipe_b3_kernel<D, MODE, EXD, SIDES>: MODE 0 = backward, MODE 1 = forward with the weighted row sum
+        is_pipe = lambda k, mode: "infonce_pipe_b3_kernel<" in k and k.split("<")[1].split(",")[1].strip() == str(mode)   # noqa: E731
         fwd = [v for k, v in util.items() if "infonce_fwd_" in k]
-        fwdo = [v for k, v in util.items() if "infonce_fwdo_" in k]
-        bwd = [v for k, v in util.items() if "infonce_bwd" in k]
+        fwdo = [v for k, v in util.items() if "infonce_fwdo_" in k or is_pipe(k, 1)]
+        bwd = [v for k, v in util.items() if "infonce_bwd" in k or is_pipe(k, 0)]
         traffic["infonce"] = {
             "fwd_mfma_busy_pct": round(max(fwd), 1) if fwd else None, "bwd_mfma_busy_pct": round(max(bwd), 1) if bwd else None,
             "fwdo_mfma_busy_pct": round(max(fwdo), 1) if fwdo else None,

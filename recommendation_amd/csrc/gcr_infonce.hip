@@ -761,7 +761,7 @@ __device__ __forceinline__ void stage_store_b3t_one(unsigned char* __restrict__ 
 
 // SIDES: which softmax terms of P are live — 0 both, 1 only the stationary rows' (w_x, lse_x), 2 only the
 // streamed rows' (w_y, lse_y): a dead term costs an exp2 and an FMA per score in the exposed part of the loop.
-template <int D, bool ILV, bool EXD = false, int SIDES = 0>
+template <int D, bool EXD = false, int SIDES = 0>
 __global__ __launch_bounds__(256, 2) void infonce_bwd_b3_kernel(
     const float* __restrict__ x, const float* __restrict__ x_scale, int64_t mx, const float* __restrict__ y,
     const float* __restrict__ y_scale, int64_t ny, float scale2, float out_scale, const float* __restrict__ lse_x,
@@ -772,7 +772,6 @@ __global__ __launch_bounds__(256, 2) void infonce_bwd_b3_kernel(
   // d = 128: one tile is 54 KB (row-major + transposed planes): a single LDS buffer (two barriers per tile,
   // two blocks per CU cover each other) instead of the double buffer of d <= 64
   constexpr int NBUF = D <= 64 ? 2 : 1;
-  static_assert(NBUF == 2 || !ILV, "the interleaved loop is double-buffered");
   __shared__ __align__(16) unsigned char lds[NBUF][B::TILE_BYTES];
   __shared__ __align__(16) float st_lse[2][kTileJ];
   __shared__ __align__(16) float st_w[2][kTileJ];
@@ -814,165 +813,7 @@ __global__ __launch_bounds__(256, 2) void infonce_bwd_b3_kernel(
       st_w[buf][tid] = s_w;
     }
   };
-  if constexpr (ILV) {
-    // Interleaved by hand (a wave issues in order, see the forward): phase 1 alternates the 6*KC score
-    // MFMAs with the operand split + LDS stores of the NEXT tile (loaded one iteration earlier: two
-    // staging register sets); phase 2 (exposed) forms P and splits its first 16 rows; phase 3
-    // alternates the G MFMAs of rows 0-15 with the split of rows 16-31, then issues those of rows 16-31.
-    constexpr int NP = 4 * S::NLD, NS1 = 6 * S::KC, NG = B::CT * 6;
-    constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
-    float4 ra[S::NLD], rb[S::NLD];
-    float lse_a = 0.f, w_a = 0.f, lse_b = 0.f, w_b = 0.f;
-    const int64_t last = tile1 - 1;
-    auto load_tile = [&](int64_t t, float4 (&r)[S::NLD], float& sl, float& sw) {
-      const int64_t j0 = min(t, last) * kTileJ;
-      stage_load<D>(y, y_scale, ny, j0, tid, r);
-      if (tid < kTileJ) {
-        const int64_t j = j0 + tid;
-        const bool on = j < ny && w_y != nullptr;
-        sw = on ? w_y[j] : 0.f;
-        sl = on ? lse_y[j] * kLog2e : 1.0e30f;
-      }
-    };
-    auto step = [&](int64_t tt, int cur, const float4 (&st)[S::NLD], float st_l, float st_w_v, float4 (&ld)[S::NLD],
-                    float& ld_l, float& ld_w) {
-      load_tile(tt + 2, ld, ld_l, ld_w);
-      unsigned char* out = lds[cur ^ 1];
-      unsigned sa[S::NLD][3], sb[S::NLD][3];
-      auto part = [&](int pi) {
-        const int u = pi / 4, k = pi % 4;
-        const int idx = tid + 256 * u;
-        const int row = idx / (D / 4), c4 = idx % (D / 4);
-        if (k == 0) {
-          split3(st[u].x, st[u].y, sa[u][0], sa[u][1], sa[u][2]);
-        } else if (k == 1) {
-          split3(st[u].z, st[u].w, sb[u][0], sb[u][1], sb[u][2]);
-        } else if (k == 2) {
-          unsigned char* p = out + row * S::ROWB + c4 * 8;
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint2*>(p + pl * S::PLANE) = make_uint2(sa[u][pl], sb[u][pl]);
-          if (u == 0 && tid < kTileJ) {
-            st_lse[cur ^ 1][tid] = st_l;
-            st_w[cur ^ 1][tid] = st_w_v;
-          }
-        } else {
-          unsigned short* q = reinterpret_cast<unsigned short*>(out + 3 * S::PLANE + (4 * c4) * B::RT + row * 2);
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl) {
-            unsigned short* qq = q + pl * (B::TPLANE / 2);
-            qq[0] = (unsigned short)(sa[u][pl] & 0xffffu);
-            qq[B::RT / 2] = (unsigned short)(sa[u][pl] >> 16);
-            qq[2 * (B::RT / 2)] = (unsigned short)(sb[u][pl] & 0xffffu);
-            qq[3 * (B::RT / 2)] = (unsigned short)(sb[u][pl] >> 16);
-          }
-        }
-      };
-      // phase 1: S^T tile (the forward's MFMA order) + staging of the next tile
-      f32x16 acc;
-      {
-        const unsigned char* base = lds[cur] + i32 * S::ROWB + h * (S::KH * 2);
-        u32x4 ap[2][3];
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) ap[0][pl] = *reinterpret_cast<const u32x4*>(base + pl * S::PLANE);
-#pragma unroll
-        for (int c = 0; c < S::KC; ++c) {
-          if (c + 1 < S::KC) {
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-              ap[(c + 1) & 1][pl] = *reinterpret_cast<const u32x4*>(base + pl * S::PLANE + 16 * (c + 1));
-          }
-#pragma unroll
-          for (int term = 0; term < 6; ++term) {
-            const int slot = c * 6 + term;
-            f32x16 cin = acc;
-            if (slot == 0) {
-#pragma unroll
-              for (int r = 0; r < 16; ++r) cin[r] = 0.f;
-            }
-            acc = mfma_bf16(ap[c & 1][TA[term]], bq[0][TB[term]][c], cin);
-#pragma unroll
-            for (int pi = slot * NP / NS1; pi < (slot + 1) * NP / NS1; ++pi) part(pi);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-      }
-      // phase 2: P in place of the scores, first half split
-      const int64_t j0 = tt * kTileJ;
-      const bool ragged = j0 + kTileJ > ny;
-      const int xr = EXD ? diag_offset(row_i, j0, h) : -1;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 lr = *reinterpret_cast<const float4*>(&st_lse[cur][8 * g + 4 * h]);
-        const float4 wr = *reinterpret_cast<const float4*>(&st_w[cur][8 * g + 4 * h]);
-        const float lre[4] = {lr.x, lr.y, lr.z, lr.w};
-        const float wre[4] = {wr.x, wr.y, wr.z, wr.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = 4 * g + e;
-          const bool dead = (ragged && (j0 + acc_row(r, h) >= ny)) || (EXD && xr == e + 8 * g);
-          const float sc = dead ? -INFINITY : acc[r];
-          if (SIDES == 1) acc[r] = wl * __builtin_amdgcn_exp2f(sc - lse2l);
-          else if (SIDES == 2) acc[r] = wre[e] * __builtin_amdgcn_exp2f(sc - lre[e]);
-          else acc[r] = wl * __builtin_amdgcn_exp2f(sc - lse2l) + wre[e] * __builtin_amdgcn_exp2f(sc - lre[e]);
-        }
-      }
-      unsigned pq[2][3][4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) split3(acc[2 * e], acc[2 * e + 1], pq[0][0][e], pq[0][1][e], pq[0][2][e]);
-      __builtin_amdgcn_sched_barrier(0);
-      // phase 3: G^T[c][i] += yhat[j][c] * P[j][i]
-      const unsigned char* tbase = lds[cur] + 3 * S::PLANE + i32 * B::RT + 8 * h;
-      auto load_ya = [&](int grp, u32x4 (&ya)[3]) {     // grp = kc * CT + c
-        const int kc = grp / B::CT, c = grp % B::CT;
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-          const unsigned char* p = tbase + pl * B::TPLANE + (32 * c) * B::RT + 32 * kc;
-          const uint2 lo = *reinterpret_cast<const uint2*>(p);
-          const uint2 hi = *reinterpret_cast<const uint2*>(p + 16);
-          ya[pl] = (u32x4){lo.x, lo.y, hi.x, hi.y};
-        }
-      };
-      u32x4 ya[2][3];
-      load_ya(0, ya[0]);
-#pragma unroll
-      for (int grp = 0; grp < 2 * B::CT; ++grp) {
-        const int kc = grp / B::CT, c = grp % B::CT;
-        if (grp + 1 < 2 * B::CT) load_ya(grp + 1, ya[(grp + 1) & 1]);
-        u32x4 pp[3];
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) pp[pl] = (u32x4){pq[kc][pl][0], pq[kc][pl][1], pq[kc][pl][2], pq[kc][pl][3]};
-#pragma unroll
-        for (int term = 0; term < 6; ++term) {
-          gacc[c] = mfma_bf16(ya[grp & 1][TA[term]], pp[TB[term]], gacc[c]);
-          if (kc == 0) {                                   // split of rows 16-31 under the MFMAs of rows 0-15
-            const int slot = c * 6 + term;
-#pragma unroll
-            for (int e = slot * 4 / NG; e < (slot + 1) * 4 / NG; ++e)
-              split3(acc[8 + 2 * e], acc[8 + 2 * e + 1], pq[1][0][e], pq[1][1][e], pq[1][2][e]);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      __syncthreads();
-    };
-    if (tile0 < tile1) {
-      load_tile(tile0, ra, lse_a, w_a);
-#pragma unroll
-      for (int u = 0; u < S::NLD; ++u) {
-        stage_store_b3t_one<D>(lds[0], tid, ra[u], u);
-      }
-      if (tid < kTileJ) {
-        st_lse[0][tid] = lse_a;
-        st_w[0][tid] = w_a;
-      }
-      load_tile(tile0 + 1, ra, lse_a, w_a);
-    }
-    __syncthreads();
-    for (int64_t tt = tile0; tt < tile1; tt += 2) {
-      step(tt, 0, ra, lse_a, w_a, rb, lse_b, w_b);
-      if (tt + 1 < tile1) step(tt + 1, 1, rb, lse_b, w_b, ra, lse_a, w_a);
-    }
-  } else {
+  {
     if (tile0 < tile1) {
       stage_load<D>(y, y_scale, ny, tile0 * kTileJ, tid, regs);
       load_stats(tile0 * kTileJ);
@@ -1073,7 +914,7 @@ __global__ __launch_bounds__(256, 2) void infonce_bwd_b3_kernel(
 // ------------------------------------------------------------------------------------------
 constexpr float kDefer = 8.0f;
 
-template <int D, bool ILV, bool EXD = false>
+template <int D, bool EXD = false>
 __global__ __launch_bounds__(256, 2) void infonce_fwdo_b3_kernel(
     const float* __restrict__ x, const float* __restrict__ x_scale, int64_t mx, const float* __restrict__ y,
     const float* __restrict__ y_scale, int64_t ny, float scale2, int nsplit, int64_t tiles_per_split,
@@ -1081,7 +922,6 @@ __global__ __launch_bounds__(256, 2) void infonce_fwdo_b3_kernel(
   using S = ShapeB3<D>;
   using B = BwdB3<D>;
   constexpr int NBUF = D <= 64 ? 2 : 1;
-  static_assert(NBUF == 2 || !ILV, "the interleaved loop is double-buffered");
   __shared__ __align__(16) unsigned char lds[NBUF][B::TILE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i32 = lane & 31, h = lane >> 5;
@@ -1140,122 +980,7 @@ __global__ __launch_bounds__(256, 2) void infonce_fwdo_b3_kernel(
     l_run += sum;
   };
 
-  if constexpr (ILV) {
-    constexpr int NP = 4 * S::NLD, NS1 = 6 * S::KC, NG = B::CT * 6;
-    constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
-    float4 ra[S::NLD], rb[S::NLD];
-    const int64_t last = tile1 - 1;
-    auto load_tile = [&](int64_t t, float4 (&r)[S::NLD]) { stage_load<D>(y, y_scale, ny, min(t, last) * kTileJ, tid, r); };
-    auto step = [&](int64_t tt, int cur, const float4 (&st)[S::NLD], float4 (&ld)[S::NLD]) {
-      load_tile(tt + 2, ld);
-      unsigned char* out = lds[cur ^ 1];
-      unsigned sa[S::NLD][3], sb[S::NLD][3];
-      auto stage_part = [&](int pi) {
-        const int u = pi / 4, k = pi % 4;
-        const int idx = tid + 256 * u;
-        const int row = idx / (D / 4), c4 = idx % (D / 4);
-        if (k == 0) {
-          split3(st[u].x, st[u].y, sa[u][0], sa[u][1], sa[u][2]);
-        } else if (k == 1) {
-          split3(st[u].z, st[u].w, sb[u][0], sb[u][1], sb[u][2]);
-        } else if (k == 2) {
-          unsigned char* p = out + row * S::ROWB + c4 * 8;
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint2*>(p + pl * S::PLANE) = make_uint2(sa[u][pl], sb[u][pl]);
-        } else {
-          unsigned short* q = reinterpret_cast<unsigned short*>(out + 3 * S::PLANE + (4 * c4) * B::RT + row * 2);
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl) {
-            unsigned short* qq = q + pl * (B::TPLANE / 2);
-            qq[0] = (unsigned short)(sa[u][pl] & 0xffffu);
-            qq[B::RT / 2] = (unsigned short)(sa[u][pl] >> 16);
-            qq[2 * (B::RT / 2)] = (unsigned short)(sb[u][pl] & 0xffffu);
-            qq[3 * (B::RT / 2)] = (unsigned short)(sb[u][pl] >> 16);
-          }
-        }
-      };
-      // phase 1: S^T tile (the forward's MFMA order) + staging of the next tile
-      f32x16 acc;
-      {
-        const unsigned char* base = lds[cur] + i32 * S::ROWB + h * (S::KH * 2);
-        u32x4 ap[2][3];
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) ap[0][pl] = *reinterpret_cast<const u32x4*>(base + pl * S::PLANE);
-#pragma unroll
-        for (int c = 0; c < S::KC; ++c) {
-          if (c + 1 < S::KC) {
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-              ap[(c + 1) & 1][pl] = *reinterpret_cast<const u32x4*>(base + pl * S::PLANE + 16 * (c + 1));
-          }
-#pragma unroll
-          for (int term = 0; term < 6; ++term) {
-            const int slot = c * 6 + term;
-            f32x16 cin = acc;
-            if (slot == 0) {
-#pragma unroll
-              for (int r = 0; r < 16; ++r) cin[r] = 0.f;
-            }
-            acc = mfma_bf16(ap[c & 1][TA[term]], bq[0][TB[term]][c], cin);
-#pragma unroll
-            for (int pi = slot * NP / NS1; pi < (slot + 1) * NP / NS1; ++pi) stage_part(pi);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-      }
-      // phase 2: online softmax, first half of P split
-      softmax_p(acc, tt);
-      unsigned pq[2][3][4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) split3(acc[2 * e], acc[2 * e + 1], pq[0][0][e], pq[0][1][e], pq[0][2][e]);
-      __builtin_amdgcn_sched_barrier(0);
-      // phase 3: O^T[c][i] += yhat[j][c] * P[j][i]
-      const unsigned char* tbase = lds[cur] + 3 * S::PLANE + i32 * B::RT + 8 * h;
-      auto load_ya = [&](int grp, u32x4 (&ya)[3]) {     // grp = kc * CT + c
-        const int kc = grp / B::CT, c = grp % B::CT;
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-          const unsigned char* p = tbase + pl * B::TPLANE + (32 * c) * B::RT + 32 * kc;
-          const uint2 lo = *reinterpret_cast<const uint2*>(p);
-          const uint2 hi = *reinterpret_cast<const uint2*>(p + 16);
-          ya[pl] = (u32x4){lo.x, lo.y, hi.x, hi.y};
-        }
-      };
-      u32x4 ya[2][3];
-      load_ya(0, ya[0]);
-#pragma unroll
-      for (int grp = 0; grp < 2 * B::CT; ++grp) {
-        const int kc = grp / B::CT, c = grp % B::CT;
-        if (grp + 1 < 2 * B::CT) load_ya(grp + 1, ya[(grp + 1) & 1]);
-        u32x4 pp[3];
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) pp[pl] = (u32x4){pq[kc][pl][0], pq[kc][pl][1], pq[kc][pl][2], pq[kc][pl][3]};
-#pragma unroll
-        for (int term = 0; term < 6; ++term) {
-          gacc[c] = mfma_bf16(ya[grp & 1][TA[term]], pp[TB[term]], gacc[c]);
-          if (kc == 0) {                                   // split of rows 16-31 under the MFMAs of rows 0-15
-            const int slot = c * 6 + term;
-#pragma unroll
-            for (int e = slot * 4 / NG; e < (slot + 1) * 4 / NG; ++e)
-              split3(acc[8 + 2 * e], acc[8 + 2 * e + 1], pq[1][0][e], pq[1][1][e], pq[1][2][e]);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      __syncthreads();
-    };
-    if (tile0 < tile1) {
-      load_tile(tile0, ra);
-#pragma unroll
-      for (int u = 0; u < S::NLD; ++u) stage_store_b3t_one<D>(lds[0], tid, ra[u], u);
-      load_tile(tile0 + 1, ra);
-    }
-    __syncthreads();
-    for (int64_t tt = tile0; tt < tile1; tt += 2) {
-      step(tt, 0, ra, rb);
-      if (tt + 1 < tile1) step(tt + 1, 1, rb, ra);
-    }
-  } else {
+  {
     float4 regs[S::NLD];
     if (tile0 < tile1) {
       stage_load<D>(y, y_scale, ny, tile0 * kTileJ, tid, regs);
@@ -1722,7 +1447,7 @@ int32_t launch_bwd(const float* x, const float* x_scale, int64_t mx, const float
                        inv_tau * kLog2e, inv_tau, lse_x, w_x, lse_y, w_y, p.nsplit, p.tiles_per_split, gpart,           \
                        (float2*)nullptr);                                                                               \
   else                                                                                                                  \
-    hipLaunchKernelGGL((infonce_bwd_b3_kernel<D, false, EX, SD>), grid, dim3(256), 0, s, x, x_scale, mx, y, y_scale,    \
+    hipLaunchKernelGGL((infonce_bwd_b3_kernel<D, EX, SD>), grid, dim3(256), 0, s, x, x_scale, mx, y, y_scale,    \
                        ny, inv_tau * kLog2e, inv_tau, lse_x, w_x, lse_y, w_y, p.nsplit, p.tiles_per_split, gpart)
       if (exd) {
         GCR_BWD3(true, 0);
@@ -1823,10 +1548,10 @@ int32_t launch_fwd_o(const float* a, const float* a_scale, int64_t m, const floa
                          inv_tau * kLog2e, 1.0f, none, none, none, none, p.nsplit, p.tiles_per_split, opart, part);
   } else {
     if (exd)
-      hipLaunchKernelGGL((infonce_fwdo_b3_kernel<D, false, true>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale, n,
+      hipLaunchKernelGGL((infonce_fwdo_b3_kernel<D, true>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale, n,
                          inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part, opart);
     else
-      hipLaunchKernelGGL((infonce_fwdo_b3_kernel<D, false, false>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale, n,
+      hipLaunchKernelGGL((infonce_fwdo_b3_kernel<D, false>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale, n,
                          inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part, opart);
   }
   int32_t st = GCR_LAUNCH_STATUS();

@@ -9,33 +9,38 @@
 
 namespace {
 
+// every block owns one contiguous slice; a thread keeps eight 16-B loads in flight, 4 KB apart
 __global__ __launch_bounds__(256) void probe_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst,
                                                          int64_t n4) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  for (; i + 3 * stride < n4; i += 4 * stride) {       // four 16-B loads in flight per lane before the stores
-    const float4 v0 = src[i], v1 = src[i + stride], v2 = src[i + 2 * stride], v3 = src[i + 3 * stride];
-    dst[i] = v0;
-    dst[i + stride] = v1;
-    dst[i + 2 * stride] = v2;
-    dst[i + 3 * stride] = v3;
+  const int64_t per = (n4 + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = (int64_t)blockIdx.x * per, hi = min(n4, lo + per);
+  int64_t i = lo + threadIdx.x;
+  for (; i + 7 * 256 < hi; i += 8 * 256) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[i + 256 * u];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) dst[i + 256 * u] = v[u];
   }
-  for (; i < n4; i += stride) dst[i] = src[i];
+  for (; i < hi; i += 256) dst[i] = src[i];
 }
 
 __global__ __launch_bounds__(256) void probe_read_kernel(const float4* __restrict__ src, int64_t n4,
                                                          float* __restrict__ sink) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t per = (n4 + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = (int64_t)blockIdx.x * per, hi = min(n4, lo + per);
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  for (; i + 3 * stride < n4; i += 4 * stride) {
-    const float4 v0 = src[i], v1 = src[i + stride], v2 = src[i + 2 * stride], v3 = src[i + 3 * stride];
-    a.x += v0.x + v1.x + v2.x + v3.x;
-    a.y += v0.y + v1.y + v2.y + v3.y;
-    a.z += v0.z + v1.z + v2.z + v3.z;
-    a.w += v0.w + v1.w + v2.w + v3.w;
+  int64_t i = lo + threadIdx.x;
+  for (; i + 7 * 256 < hi; i += 8 * 256) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[i + 256 * u];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w;
+    }
   }
-  for (; i < n4; i += stride) {
+  for (; i < hi; i += 256) {
     const float4 v = src[i];
     a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
   }
@@ -69,7 +74,7 @@ extern "C" int32_t gcr_probe_copy_f32(const float* src, float* dst, int64_t n_fl
   GCR_CHECK_ARG(src != nullptr && dst != nullptr && n_floats >= 0 && (n_floats & 3) == 0);
   GCR_CHECK_ARG((((uintptr_t)src | (uintptr_t)dst) & 15) == 0);
   if (n_floats == 0) return GCR_OK;
-  hipLaunchKernelGGL(probe_copy_kernel, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, (const float4*)src,
+  hipLaunchKernelGGL(probe_copy_kernel, dim3(256 * 32), dim3(256), 0, (hipStream_t)stream, (const float4*)src,
                      (float4*)dst, n_floats / 4);
   return GCR_LAUNCH_STATUS();
 }
@@ -78,7 +83,7 @@ extern "C" int32_t gcr_probe_read_f32(const float* src, int64_t n_floats, float*
   GCR_CHECK_ARG(src != nullptr && sink != nullptr && n_floats >= 0 && (n_floats & 3) == 0);
   GCR_CHECK_ARG(((uintptr_t)src & 15) == 0);
   if (n_floats == 0) return GCR_OK;
-  hipLaunchKernelGGL(probe_read_kernel, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, (const float4*)src,
+  hipLaunchKernelGGL(probe_read_kernel, dim3(256 * 32), dim3(256), 0, (hipStream_t)stream, (const float4*)src,
                      n_floats / 4, sink);
   return GCR_LAUNCH_STATUS();
 }

@@ -573,7 +573,7 @@ class _InfoNCEStats(torch.autograd.Function):
     flash-style HIP backward.  Every loss of the InfoNCE family is a few [M]-vector ops on top."""
 
     @staticmethod
-    def forward(ctx, a, b, pos, inv_tau, normalize, want_col, exd=False):
+    def forward(ctx, a, b, pos, inv_tau, normalize, want_col, exd=False, grad_a=False):
         a_p, b_p = _pad_dim(a).contiguous(), _pad_dim(b).contiguous()
         sa = row_inv_norm(a_p) if normalize else None
         sb = row_inv_norm(b_p) if normalize else None
@@ -587,7 +587,7 @@ class _InfoNCEStats(torch.autograd.Function):
         on_f32 = eng == INFONCE_ENGINE_F32 or _lib.lib().gcr_infonce_engine(a_p.shape[1]) == 0
         one_pass = want_col and normalize and inv_tau <= 40.0 and not COL_DETERMINISTIC and not exd and on_f32
         o = None
-        if FWD_O and not want_col and ctx.needs_input_grad[0] and a_p.shape[0] > 0 and \
+        if FWD_O and not want_col and grad_a and a_p.shape[0] > 0 and \
                 infonce_fwd_o_supported(a_p.shape[1], eng):
             lse, o = infonce_fwd_o_raw(a_p, sa, b_p, sb, inv_tau, exclude_diagonal=exd, engine_flag=eng)
             col = None
@@ -637,7 +637,7 @@ class _InfoNCEStats(torch.autograd.Function):
             ga = ga[:, :d].contiguous()
         if gb is not None and gb.shape[1] != d:
             gb = gb[:, :d].contiguous()
-        return ga, gb, None, None, None, None, None
+        return ga, gb, None, None, None, None, None, None
 
 
 def infonce_stats(a, b, pos=None, temperature=0.2, normalize=True, want_col=False, exclude_diagonal=False):
@@ -658,7 +658,11 @@ def infonce_stats(a, b, pos=None, temperature=0.2, normalize=True, want_col=Fals
         pos = _as_index(pos, a.device)
         if pos.shape != (a.shape[0],):
             raise ValueError("pos must be [M]")
-    return _InfoNCEStats.apply(a, b, pos, 1.0 / float(temperature), bool(normalize), bool(want_col), bool(exclude_diagonal))
+    # the flash-style forward (lse + weighted row sum) only pays off when the anchors will get a gradient: decided
+    # here, where the caller's grad mode is still visible (inside Function.forward it is always off)
+    grad_a = torch.is_grad_enabled() and a.requires_grad
+    return _InfoNCEStats.apply(a, b, pos, 1.0 / float(temperature), bool(normalize), bool(want_col), bool(exclude_diagonal),
+                               grad_a)
 
 
 def edge_mask_exact_bits(nnz, n_keep, seed, device):

@@ -26,6 +26,16 @@ from . import functional as Fn
 from .graph import CsrGraph
 
 
+# True: issue the collectives even at world size 1 (they degenerate to copies).  Used by the single-rank RCCL test
+# (tests/test_distributed_gpu.py): the only way to run every collective call of this module on the real `nccl`
+# backend on a one-GPU box.
+FORCE_COLLECTIVES = False
+
+
+def _multi(world):
+    return world > 1 or (FORCE_COLLECTIVES and dist.is_initialized())
+
+
 def _hip_spmm(graph, x, acc_in=None, acc_scale=1.0, want_y=True, keep_bits=None, val_scale=1.0, y_out=None):
     """`y_out`: a caller-owned (pooled) buffer for y instead of a fresh allocation."""
     y = None
@@ -162,13 +172,14 @@ def sharded_propagate_raw(g: ShardedBipartiteGraph, x_user, x_item_shard, n_laye
     # Horner form z <- x + A z (z_0 = x): after K steps z = sum_{k<=K} A^k x; both halves of a step
     # read the OLD z, every step writes one array per side (no separate layer output + running sum)
     z_u, z_i = x_user, x_item_shard
-    pooled = world > 1 and spmm is _hip_spmm          # injected (test) SpMMs allocate their own outputs
-    z_item_full = g.buffers.get("z_item_full", g.items_padded, d, dev) if world > 1 else None
+    multi = _multi(world)
+    pooled = multi and spmm is _hip_spmm              # injected (test) SpMMs allocate their own outputs
+    z_item_full = g.buffers.get("z_item_full", g.items_padded, d, dev) if multi else None
     part_buf = g.buffers.get("part_i", g.items_padded, d, dev) if pooled else None
-    y_buf = g.buffers.get("y_i", g.items_per_rank, d, dev) if world > 1 else None
+    y_buf = g.buffers.get("y_i", g.items_per_rank, d, dev) if multi else None
     for k in range(n_layers):
         s = scale if k == n_layers - 1 else 1.0
-        if world > 1:
+        if multi:
             h_ag = _all_gather(z_item_full, z_i.contiguous(), g.group, overlap)
         else:
             z_item_full, h_ag = z_i, None
@@ -178,7 +189,7 @@ def sharded_propagate_raw(g: ShardedBipartiteGraph, x_user, x_item_shard, n_laye
             part_i, _ = spmm(g.r_iu, z_u, **kw_iu)
         if h_ag is not None:
             h_ag.wait()
-        if world > 1:
+        if multi:
             y_i = y_buf
             h_rs = _reduce_scatter(y_i, part_i, g.group, overlap)
         else:
@@ -240,7 +251,7 @@ class _GatherItems(torch.autograd.Function):
 
 
 def gather_items(item_shard, group=None):
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or not _multi(dist.get_world_size(group)):
         return item_shard
     return _GatherItems.apply(item_shard, group)
 
@@ -267,7 +278,7 @@ class _AllReduceSum(torch.autograd.Function):
 
 
 def all_reduce_sum(part, group=None):
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or not _multi(dist.get_world_size(group)):
         return part
     return _AllReduceSum.apply(part, group)
 
@@ -275,7 +286,7 @@ def all_reduce_sum(part, group=None):
 def allreduce_replicated_grads(params, group=None):
     """Replicated parameters (MHCN's gating / attention weights, a replicated item table) receive a partial
     gradient on every rank (each rank back-propagates its own users' share of the loss): sum them."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or not _multi(dist.get_world_size(group)):
         return
     for p in params:
         if p.grad is not None:
@@ -352,7 +363,7 @@ class _ShardedChannelLayer(torch.autograd.Function):
         n_c = len(ch.blocks)
         fulls, handles = [], []
         for c in range(n_c):
-            if world > 1:
+            if _multi(world):
                 full = ch.buffers.get(f"x_full{c}", ch.users_padded, d, dev)
                 handles.append(_all_gather(full, xs[c].contiguous(), ch.group, True))
             else:
@@ -403,7 +414,7 @@ class _ShardedChannelLayer(torch.autograd.Function):
                 handles.append(None)
                 continue
             d = dz.shape[1]
-            if world > 1:
+            if _multi(world):
                 buf = ch.buffers.get(f"g_part{c}", ch.users_padded, d, dz.device) if ctx.spmm_t_fn is _hip_spmm_t else None
                 part = ctx.spmm_t_fn(ch.blocks[c], dz, buf) if buf is not None else ctx.spmm_t_fn(ch.blocks[c], dz)
                 dx = torch.empty(ch.users_per_rank, d, dtype=torch.float32, device=dz.device)

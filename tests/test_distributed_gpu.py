@@ -201,3 +201,68 @@ def test_sharded_mhcn_two_ranks_one_gpu():
             assert p.exitcode == 0
         res = {r: out[r] for r in range(world)}
     C.check(res, world, 2e-5)
+
+
+# --------------------------------------------------------------------------- the real `nccl` (RCCL) backend, one rank
+def _nccl_worker(port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        import mhcn_sharded_common as C
+        import recommendation_amd as ra
+        from recommendation_amd import distributed as gd
+        from recommendation_amd.mhcn import HipOps
+        u, i = O.synthetic_interactions(N_USERS, N_ITEMS, N_EDGES, seed=1)
+        deg_u, deg_i = np.bincount(u, minlength=N_USERS), np.bincount(i, minlength=N_ITEMS)
+        g = gd.ShardedBipartiteGraph.from_local_interactions(u, i, N_USERS, N_ITEMS, deg_u, deg_i, 0, 1, dev)
+        x_all, w_all = _inputs(g.items_padded)
+        res = {}
+        for force in (False, True):
+            gd.FORCE_COLLECTIVES = force
+            xu = torch.from_numpy(x_all[:N_USERS]).to(dev).requires_grad_(True)
+            xi = torch.from_numpy(x_all[N_USERS:]).to(dev).requires_grad_(True)
+            for overlap in (True, False):
+                xu.grad = xi.grad = None
+                view = gd.ShardedEdgeDrop(g, PE, seed=11, rescale=True)
+                fu, fi = gd.sharded_lightgcn_propagate(g, xu, xi, K, combine="mean", overlap=overlap, view=view)
+                nce = gd.sharded_info_nce_loss(fu, fu * 1.1 + 0.01, 0.2) + gd.sharded_info_nce_loss(fi, fi + 0.02, 0.2)
+                items_full = gd.gather_items(fi)
+                loss = (fu * torch.from_numpy(w_all[:N_USERS]).to(dev)).sum() + \
+                    (items_full * torch.from_numpy(w_all[N_USERS:]).to(dev)).sum() + nce
+                loss.backward()
+                res[(force, overlap)] = [t.detach().cpu().numpy() for t in (fu, fi, xu.grad, xi.grad)] + [float(loss)]
+            # config 5 through the same backend: per-channel all-gather / reduce-scatter / all-reduce calls
+            res[("mhcn", force)] = C.run_rank(0, 1, dev, lambda r, c, v, nr, nc: ra.CsrGraph.from_coo(r, c, v, nr, nc, dev), HipOps)
+        gd.FORCE_COLLECTIVES = False
+        out["res"] = res
+        out["backend"] = dist.get_backend()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_single_rank_rccl_runs_every_collective():
+    """The one-GPU box cannot host two RCCL ranks, but one rank can run every collective call of distributed.py on the
+    real `nccl` backend (FORCE_COLLECTIVES: all_gather_into_tensor, reduce_scatter_tensor, all_reduce, async handles,
+    the per-channel streams) — shapes, dtypes, handle semantics and stream ordering as the 8-GPU run will see them.
+    Results must equal the collective-free world-1 path."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import mhcn_sharded_common as C
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        p = ctx.Process(target=_nccl_worker, args=(_free_port(), out))
+        p.start()
+        p.join(300)
+        assert p.exitcode == 0
+        res, backend = out["res"], out["backend"]
+    assert backend == "nccl"
+    base = res[(False, True)]
+    for key in ((False, False), (True, True), (True, False)):
+        for a, b in zip(res[key][:4], base[:4]):
+            np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-6 * np.abs(b).max())
+        assert res[key][4] == pytest.approx(base[4], rel=1e-6)
+    C.check({0: res[("mhcn", True)]}, 1, 2e-5)
+    C.check({0: res[("mhcn", False)]}, 1, 2e-5)

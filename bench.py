@@ -525,6 +525,8 @@ def main_sharded(args, rank, world, dev, ra):
     100M interactions) split over the N ranks."""
     from recommendation_amd import distributed as gdist
     dist = _init_dist(dev)
+    if os.environ.get("GCR_BENCH_FORCE_COLLECTIVES") == "1":      # one rank, real RCCL calls (degenerate copies)
+        gdist.FORCE_COLLECTIVES = True
     name = args.workload or ("cfg4" if args.scaling == "strong" else "cfg2")
     if name == "cfg5":
         return main_cfg5(args, rank, world, dev, ra)
@@ -593,8 +595,9 @@ def main_cfg5(args, rank, world, dev, ra):
     import torch.distributed as dist
     from recommendation_amd import distributed as gdist
     from recommendation_amd.mhcn import ShardedMHCNEncoder
-    if world > 1:
+    if world > 1 or os.environ.get("GCR_BENCH_FORCE_COLLECTIVES") == "1":
         dist = _init_dist(dev)
+        gdist.FORCE_COLLECTIVES = os.environ.get("GCR_BENCH_FORCE_COLLECTIVES") == "1"
     per_u, n_i, d, k_layers = CFG5["users"], CFG5["items"], args.dim, CFG5["layers"]
     u_pad = per_u * world
     gen = torch.Generator(device=dev).manual_seed(SEED + rank)
@@ -758,7 +761,8 @@ def bench_extra(ra, Fn, graph, x0, k_layers, nnz, dev, n_u, n_i):
     def ncl_step():
         final, layers = Fn.lightgcn_propagate(graph, xp, k_layers, "mean", return_layers=True)
         ue, ie = Fn.split_rows(final, n_u)
-        loss = Ls.bpr_loss(ue[uidx], ie[iidx], ie[jn]) + \
+        bs = Fn.bpr_sums(ue, ie, uidx, iidx, jn, Fn.BPR_NCL)          # gathers + BPR + norms in one kernel, as NCLModel.train_step
+        loss = bs[0] / bsz + 1e-4 * (bs[1].sqrt() + bs[2].sqrt() + bs[3].sqrt()) / bsz / bsz + \
             Ls.ssl_layer_loss(layers[min(2, k_layers)], layers[0], uidx, iidx, n_u, 0.1, 1e-6, 1.0) + \
             Ls.ProtoNCE_loss(layers[0], uidx, iidx, n_u, cent, u2c, cent, i2c, 0.1, 1e-7, bsz)
         opt.zero_grad()

@@ -33,7 +33,8 @@ i2c = torch.randint(0, 1000, (n_i,), device=dev, generator=gen)
 for _ in range(6):
     final, layers = Fn.lightgcn_propagate(graph, xp, 3, "mean", return_layers=True)
     ue, ie = Fn.split_rows(final, n_u)
-    loss = Ls.bpr_loss(ue[uidx], ie[iidx], ie[jn]) + \
+    bs = Fn.bpr_sums(ue, ie, uidx, iidx, jn, Fn.BPR_NCL)
+    loss = bs[0] / bsz + 1e-4 * (bs[1].sqrt() + bs[2].sqrt() + bs[3].sqrt()) / bsz / bsz + \
         Ls.ssl_layer_loss(layers[2], layers[0], uidx, iidx, n_u, 0.1, 1e-6, 1.0) + \
         Ls.ProtoNCE_loss(layers[0], uidx, iidx, n_u, cent, u2c, cent, i2c, 0.1, 1e-7, bsz)
     opt.zero_grad()

@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import torch
 
+from . import functional as Fn
 from . import losses as Ls
 from .encoders import Interaction, LGCNEncoder
 from .evaluate import ranking_evaluation, test as rank_test
@@ -83,14 +84,20 @@ class NCLModel:
         if bool((torch.as_tensor(neg_idx) < 0).any()):
             return None
         rec_user_emb, rec_item_emb, emb_list = self.model()
-        user_emb, pos_emb, neg_emb = rec_user_emb[user_idx], rec_item_emb[pos_idx], rec_item_emb[neg_idx]
-        rec_loss = Ls.bpr_loss(user_emb, pos_emb, neg_emb)
+        # ncl.py:314-317 gathers three [B, d] row blocks and feeds bpr_loss / l2_reg_loss; here the gathers, the BPR
+        # terms and the three squared norms come out of ONE kernel (gcr_bpr_fwd_f32) and its backward scatters row
+        # gradients straight into the tables (no dense zero-filled gradient per gather)
+        n_b = len(user_idx)
+        sums = Fn.bpr_sums(rec_user_emb, rec_item_emb, user_idx, pos_idx, neg_idx, Fn.BPR_NCL)
+        rec_loss = sums[0] / n_b
+        # l2_reg_loss(reg, u, p, n) = reg * (|u|_F + |p|_F + |n|_F) / B   (ncl.py:122-123), then / batch_size (ncl.py:326)
+        l2 = self.reg * (sums[1].sqrt() + sums[2].sqrt() + sums[3].sqrt()) / n_b
         initial_emb = emb_list[0]
         context_emb = emb_list[-1] if self.hyper_layers * 2 >= len(emb_list) else emb_list[self.hyper_layers * 2]
         ssl_loss = self.ssl_layer_loss(context_emb, initial_emb, user_idx, pos_idx)
         self.e_step(rec_user_emb, rec_item_emb)                             # ncl.py:324 (every batch, Q8)
         proto_loss = self.ProtoNCE_loss(initial_emb, user_idx, pos_idx)
-        total = rec_loss + Ls.l2_reg_loss(self.reg, user_emb, pos_emb, neg_emb) / self.batch_size + ssl_loss + proto_loss
+        total = rec_loss + l2 / self.batch_size + ssl_loss + proto_loss
         optimizer.zero_grad()
         total.backward()
         optimizer.step()

@@ -19,7 +19,8 @@ except Exception as e:
 PY
 }
 TR="python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1"
-GCR_BENCH_FORCE_DIST=1 run n1_forced python3 bench.py --steps 5 --warmup 2
+GCR_BENCH_FORCE_DIST=1 GCR_BENCH_FORCE_COLLECTIVES=1 run n1_rccl python3 bench.py --steps 5 --warmup 2
+GCR_BENCH_FORCE_COLLECTIVES=1 run cfg5_n1_rccl python3 bench.py --workload cfg5 --steps 5 --warmup 2
 GCR_BENCH_REHEARSE_ONE_GPU=1 run n2_weak $TR --master-port 29511 bench.py --gpus 2 --steps 3 --warmup 1
 GCR_BENCH_REHEARSE_ONE_GPU=1 run n2_strong $TR --master-port 29512 bench.py --gpus 2 --steps 3 --warmup 1 --scaling strong --workload cfg2 --no-extra
 run cfg5_n1 python3 bench.py --workload cfg5 --steps 5 --warmup 2

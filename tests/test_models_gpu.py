@@ -234,19 +234,19 @@ def test_ncl_model_trains_end_to_end():
     rng.shuffle(pairs)
     train = [[f"u{u}", f"i{i}", 1.0] for u, i in pairs[:6000]]
     test = [[f"u{u}", f"i{i}", 1.0] for u, i in pairs[6000:]]
-    conf = {"model": {"name": "NCL", "type": "graph"}, "embedding.size": 64, "batch.size": 512, "learning.rate": 0.01,
+    conf = {"model": {"name": "NCL", "type": "graph"}, "embedding.size": 64, "batch.size": 512, "learning.rate": 0.005,
             "reg.lambda": 1e-4, "max.epoch": 8, "item.ranking.topN": [10, 20],
-            "NCL": {"n_layers": 3, "tau": 0.1, "ssl_reg": 1e-4, "proto_reg": 1e-4, "alpha": 1.0, "num_clusters": 20,
+            "NCL": {"n_layers": 2, "tau": 0.1, "ssl_reg": 1e-4, "proto_reg": 1e-4, "alpha": 1.0, "num_clusters": 20,
                     "hyper_layers": 1}}
     model = NCLModel(conf, train, test, device="cuda", seed=1)
     metrics = model.train()
     assert set(metrics) == {"Hit Ratio", "Precision", "Recall", "NDCG"}
-    # the dict keeps the last cut-off's values (Top 20), like the reference's comprehension;
-    # chance level is 20 / 120 = 0.17.  96 Adam steps at lr 0.01 on the raw (un-normalised, Q1) adjacency
-    # are a chaotic trajectory: the 1e-7 run-to-run noise of the float atomics (scripts/check_determinism.py:
-    # 5e-7 after 6 steps, no k-means flips) grows into Recall@20 anywhere between 0.27 and 0.75
+    # the dict keeps the last cut-off's values (Top 20), like the reference's comprehension; chance level is
+    # 20 / 120 = 0.17.  Two layers at lr 0.005: Recall@20 0.72-0.84 over repeated runs (scripts/exp/ncl_stability.py).
+    # With three layers of the raw (un-normalised, Q1) adjacency at lr 0.01 the trajectory is chaotic — the 1e-7
+    # run-to-run noise of the float atomics grows into anything between 0.19 and 0.82 — so that is not a test.
     print("NCL end-to-end metrics:", metrics)
-    assert metrics["Recall"] > 0.2, metrics
+    assert metrics["Recall"] > 0.5, metrics
     assert model.user_2cluster.shape == (model.data.user_num,) and int(model.user_2cluster.max()) < 20
     scores = model.predict("u0")
     assert scores.shape == (model.data.item_num,)

@@ -666,11 +666,11 @@ def main_cfg5(args, rank, world, dev, ra):
                                                    "GEMMs and collectives)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                          "frac": round(achieved / (HBM_PEAK_GBS * world), 4), "traffic": None},
-            "cpu_baseline": None, "dist_backend": dist.get_backend() if world > 1 else None, "dist_world": world,
+            "cpu_baseline": None, "dist_backend": dist.get_backend() if dist.is_initialized() else None, "dist_world": world,
             "extra": {"fwd_bwd_ms": 1e3 * t_fb},
         }
         print(json.dumps(line))
-    if world > 1:
+    if world > 1 or dist.is_initialized():
         dist.destroy_process_group()
 
 

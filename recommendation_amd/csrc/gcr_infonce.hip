@@ -1110,7 +1110,22 @@ __global__ __launch_bounds__(256, 2) void infonce_pipe_b3_kernel(
     float sla = 0.f, swa = 0.f, slb = 0.f, swb = 0.f;
     auto load_tile = [&](int64_t t, float4 (&r)[S::NLD], float& sl, float& sw) {
       const int64_t j0 = min(t, last) * kTileJ;
-      stage_load<D>(y, y_scale, ny, j0, tid, r);
+      // wave-uniform tile base + 32-bit per-thread offsets (a ragged last tile clamps its rows to the last valid
+      // one and zeroes their scale): no 64-bit vector arithmetic in the loop
+      const int rem = (int)min((int64_t)kTileJ, ny - j0);
+      const float* tb = y + j0 * D;
+      const float* ts = y_scale != nullptr ? y_scale + j0 : nullptr;
+#pragma unroll
+      for (int u = 0; u < S::NLD; ++u) {
+        const int idx = tid + 256 * u;
+        const int row = idx / (D / 4), c4 = idx % (D / 4);
+        const int rr = min(row, rem - 1);
+        float4 v = *reinterpret_cast<const float4*>(tb + rr * D + 4 * c4);
+        float sc = ts != nullptr ? ts[rr] : 1.0f;
+        sc = row < rem ? sc : 0.f;
+        v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+        r[u] = v;
+      }
       if (MODE == 0 && tid < kTileJ) {
         const int64_t j = j0 + tid;
         const bool on = j < ny && w_y != nullptr;
@@ -1226,8 +1241,10 @@ __global__ __launch_bounds__(256, 2) void infonce_pipe_b3_kernel(
     __syncthreads();
 
     // step t: tile t's P planes in `pc`, tile t+2 in `st` registers; produces P(t+1) in `pn`, loads tile t+3 to `ld`
-    auto step = [&](int64_t t, int k3, unsigned (&pc)[2][3][4], unsigned (&pn)[2][3][4], const float4 (&st)[S::NLD],
-                    float st_l, float st_w_v, float4 (&ld)[S::NLD], float& ld_l, float& ld_w) {
+    auto step = [&](auto next_c, int64_t t, int k3, unsigned (&pc)[2][3][4], unsigned (&pn)[2][3][4],
+                    const float4 (&st)[S::NLD], float st_l, float st_w_v, float4 (&ld)[S::NLD], float& ld_l, float& ld_w) {
+      constexpr bool real_next = decltype(next_c)::value;    // false only for the split's last tile (compile time:
+                                                             // no branch may sit between the MFMAs of a phase)
       const int par = (int)((t - tile0) & 1);            // parity of tile t (the per-tile statistics are double-buffered)
       load_tile(t + 3, ld, ld_l, ld_w);
       unsigned char* rm_out = lds_rm[(k3 + 2) % 3];      // tile t in rm[k3], t+1 in rm[k3 + 1], t+2 goes to rm[k3 + 2]
@@ -1261,7 +1278,6 @@ __global__ __launch_bounds__(256, 2) void infonce_pipe_b3_kernel(
           }
         }
       }
-      const bool real_next = t + 1 < tile1;                // the tile after the split's last one is a clamped repeat
       if (MODE == 0 || real_next) prepare(acc, t + 1);
       __builtin_amdgcn_sched_barrier(0);
       // phase B: second product of tile t || P(t+1)
@@ -1306,13 +1322,19 @@ __global__ __launch_bounds__(256, 2) void infonce_pipe_b3_kernel(
     };
     int k3 = 0;
     int64_t tt = tile0;
-    for (; tt + 1 < tile1; tt += 2) {
-      step(tt, k3, pqa, pqb, ra, sla, swa, rb, slb, swb);
+    for (; tt + 2 < tile1; tt += 2) {
+      step(std::true_type{}, tt, k3, pqa, pqb, ra, sla, swa, rb, slb, swb);
       k3 = (k3 + 1) % 3;
-      step(tt + 1, k3, pqb, pqa, rb, slb, swb, ra, sla, swa);
+      step(std::true_type{}, tt + 1, k3, pqb, pqa, rb, slb, swb, ra, sla, swa);
       k3 = (k3 + 1) % 3;
     }
-    if (tt < tile1) step(tt, k3, pqa, pqb, ra, sla, swa, rb, slb, swb);
+    if (tt + 1 < tile1) {                                  // two tiles left
+      step(std::true_type{}, tt, k3, pqa, pqb, ra, sla, swa, rb, slb, swb);
+      k3 = (k3 + 1) % 3;
+      step(std::false_type{}, tt + 1, k3, pqb, pqa, rb, slb, swb, ra, sla, swa);
+    } else {                                               // one tile left
+      step(std::false_type{}, tt, k3, pqa, pqb, ra, sla, swa, rb, slb, swb);
+    }
   }
 
   float* gout = gpart + (int64_t)split * mx * D;

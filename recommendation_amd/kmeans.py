@@ -6,8 +6,8 @@ is implemented is faiss' published `Clustering::train` with its defaults: if n >
 centroids are trained on a random subsample of 256 k points (max_points_per_centroid), initial
 centroids = a random sample of k training points, niter = 20 Lloyd iterations with L2 nearest
 centroid, then EVERY point is assigned against the final centroids (the `index.search`).  Differences:
-the random draws are torch's, not faiss' generator, and an empty cluster keeps its previous centroid
-(faiss re-splits a big cluster instead).  The assignment runs on the MFMA tile engine
+the random draws are torch's / numpy's, not faiss' generator (an empty cluster is re-seeded from a big one with
+faiss' `split_clusters` rule).  The assignment runs on the MFMA tile engine
 (gcr_kmeans_assign_f32), the update is float-atomic row adds.
 """
 from __future__ import annotations
@@ -68,8 +68,34 @@ def run_kmeans(x, k, niter=20, seed=1234, init_centroids=None, max_points_per_ce
                                            _lib.dptr(half_sq), _lib.dptr(sums), _lib.dptr(counts), stream),
                    "gcr_kmeans_update_f32")
 
+    def split_empty(it):
+        """faiss `split_clusters` (Clustering.cpp): every empty cluster takes over a copy of a big cluster's centroid —
+        chosen by walking the clusters and accepting cluster j with probability (size_j - 1) / (n - k) — and the two
+        copies are pushed apart by the symmetric perturbation (1 +- 1/1024) alternating over the dimensions; the sizes
+        are split in half.  Rare (never at the bench sizes), so it runs on the host: one count read-back per iteration."""
+        if not bool((counts == 0).any()):
+            return
+        import numpy as np
+        cnt = counts.cpu().numpy().astype(np.float64)
+        rng = np.random.default_rng(int(seed) * 7919 + it)
+        eps = 1.0 / 1024.0
+        sign = torch.ones(d, device=x.device)
+        sign[1::2] = -1.0
+        for ci in np.nonzero(cnt == 0)[0]:
+            cj = 0
+            for _ in range(64 * k):                       # bounded walk (faiss loops until a draw succeeds)
+                if rng.random() < (cnt[cj] - 1.0) / max(n_train - k, 1):
+                    break
+                cj = (cj + 1) % k
+            cent[ci] = cent[cj] * (1.0 + eps * sign)
+            cent[cj] = cent[cj] * (1.0 - eps * sign)
+            cnt[ci] = cnt[cj] // 2
+            cnt[cj] -= cnt[ci]
+        update(None, 0)                                   # refresh 0.5 |c|^2
+
     update(None, 0)                      # half_sq of the initial centroids
-    for _ in range(niter):
+    for it in range(niter):
         update(kmeans_assign(xt, cent, half_sq), n_train)
+        split_empty(it)
     assign = kmeans_assign(xp, cent, half_sq)       # kmeans.index.search(x, 1) against the final centroids
     return cent[:, :d_orig].contiguous(), assign

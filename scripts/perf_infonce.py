@@ -1,22 +1,41 @@
 #!/usr/bin/env python3
-"""Ad-hoc throughput probe of the InfoNCE kernels (pairs/s and fp32-MFMA TFLOP/s)."""
-import sys, os, time
+"""Bare-kernel timings of the InfoNCE tile engines at the NCL structure-contrast shape (2048 x 1M x 64) and the
+symmetric 100K x 100K shape: forward (lse), flash forward (lse + weighted row sum), table-side backward; HIP events
+on the launch stream, median of 5 rounds."""
+import os, statistics, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from recommendation_amd import _lib
+if "--lib" in sys.argv:            # A/B of two builds of the library on one box: --lib recommendation_amd/libgcr_x.so
+    _lib.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
 from recommendation_amd import functional as Fn
 
-def timeit(fn, reps=10):
+
+def ms(fn, reps=5):
     fn(); torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps): fn()
-    e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps * 1e-3
+    out = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        out.append(e0.elapsed_time(e1) / reps)
+    return statistics.median(out)
+
 
 g = torch.Generator(device="cuda").manual_seed(0)
-for (m, n, d) in [(2048, 1_000_000, 64), (2048, 100_000, 64), (2048, 2048, 64), (8192, 8192, 64), (100_000, 100_000, 64),
-                  (2048, 1_000_000, 128), (16384, 16384, 128)]:
-    a = torch.randn(m, d, device="cuda", generator=g); b = torch.randn(n, d, device="cuda", generator=g)
+shapes = [(2048, 1_000_000, 64)] if "--quick" in sys.argv else \
+    [(2048, 1_000_000, 64), (100_000, 100_000, 64), (2048, 100_000, 128), (2048, 1_000_000, 32)]
+for (m, n, d) in shapes:
+    a = torch.randn(m, d, device="cuda", generator=g)
+    b = torch.randn(n, d, device="cuda", generator=g)
     sa, sb = Fn.row_inv_norm(a), Fn.row_inv_norm(b)
-    t = timeit(lambda: Fn.infonce_lse_raw(a, sa, b, sb, 5.0), 5 if m * n > 1e9 else 20)
-    print(f"fwd M={m} N={n} d={d}: {t*1e3:.3f} ms  {m*n/t/1e9:.1f} Gpairs/s  {2*m*n*d/t/1e12:.1f} TFLOP/s", flush=True)
+    lse = Fn.infonce_lse_raw(a, sa, b, sb, 10.0)
+    w = torch.ones(m, device="cuda")
+    t_f = ms(lambda: Fn.infonce_lse_raw(a, sa, b, sb, 10.0))
+    t_o = ms(lambda: Fn.infonce_fwd_o_raw(a, sa, b, sb, 10.0))
+    t_b = ms(lambda: Fn._infonce_bwd_raw(b, sb, a, sa, 10.0, None, None, lse, w))
+    fl = 2.0 * m * n * d / 1e9
+    print(f"M={m} N={n} d={d}: fwd {t_f:.3f} ms ({fl / t_f:.0f} TF)  fwd_o {t_o:.3f} ms ({2 * fl / t_o:.0f} TF)  "
+          f"bwd(table) {t_b:.3f} ms ({2 * fl / t_b:.0f} TF)", flush=True)

@@ -100,3 +100,18 @@ def test_training_subsample_like_faiss():
     np.testing.assert_allclose(c_sub.cpu().numpy(), centers, atol=0.35)            # means of ~256 samples each
     d2 = torch.cdist(x[::97].double(), c_sub.double()) ** 2
     assert bool((d2.gather(1, a_sub[::97, None]).squeeze(1) <= d2.min(1).values * (1 + 1e-5) + 1e-6).all())
+
+
+def test_empty_cluster_is_reseeded_from_a_big_one():
+    """faiss' split_clusters rule (Clustering.cpp): a centroid that attracts no point takes over a perturbed copy of a
+    populated cluster's centroid instead of staying dead (ncl.py:352 relies on faiss.Kmeans for this)."""
+    from recommendation_amd.kmeans import run_kmeans
+    rng = np.random.default_rng(1)
+    d, k = 64, 4
+    centers = rng.standard_normal((3, d)) * 5
+    x = (centers[rng.integers(0, 3, 3000)] + 0.3 * rng.standard_normal((3000, d))).astype(np.float32)
+    init = np.concatenate([centers, np.full((1, d), 1e3)]).astype(np.float32)      # the 4th start is far from every point
+    cent, assign = run_kmeans(torch.from_numpy(x).cuda(), k, niter=10, init_centroids=torch.from_numpy(init).cuda())
+    counts = np.bincount(assign.cpu().numpy(), minlength=k)
+    assert (counts > 0).all(), counts
+    assert float(cent.abs().max()) < 100.0                  # the dead centroid at 1e3 is gone

@@ -87,6 +87,9 @@ class Sp:
         """Element-wise product with another sparse matrix (scipy `.multiply`)."""
         if (self.n_rows, self.n_cols) != (mask.n_rows, mask.n_cols):
             raise ValueError("shape mismatch")
+        if self.nnz == 0 or mask.nnz == 0:
+            return Sp(torch.zeros(self.n_rows + 1, dtype=torch.int64, device=self.device), self.col[:0], self.val[:0],
+                      self.n_rows, self.n_cols)
         m = torch.empty(max(self.nnz, 1), dtype=torch.float32, device=self.device)
         _lib.check(_lib.lib().gcr_csr_lookup_f32(_lib.dptr(self.row_of()), _lib.dptr(self.col), self.nnz, _lib.dptr(mask.rowptr),
                                                  _lib.dptr(mask.col), _lib.dptr(mask.val), _lib.dptr(m),

@@ -24,28 +24,26 @@ from .optim import FusedAdam
 from .sampler import next_batch_pairwise
 
 
+# attribute <- key of conf["NCL"] (ncl.py:286-292) and attribute <- (key of conf, default) (ncl.py:293-298): the schema a
+# drop-in has to keep, as data
+_NCL_ARGS = {"n_layers": "n_layers", "ssl_temp": "tau", "ssl_reg": "ssl_reg", "proto_reg": "proto_reg",
+             "hyper_layers": "hyper_layers", "alpha": "alpha", "k": "num_clusters"}
+_CONF_DEFAULTS = {"batch_size": ("batch.size", 2048), "emb_size": ("embedding.size", 64), "lRate": ("learning.rate", 0.001),
+                  "reg": ("reg.lambda", 0.0001), "max_epoch": ("max.epoch", 1),
+                  "ranking": ("item.ranking.topN", [10, 20, 30, 50])}
+
+
 class NCLModel:
     def __init__(self, conf, train_set, test_set, device=None, seed=0):
-        self.config = conf
+        self.config, self.seed = conf, seed
         self.model_name = conf.get("model", {}).get("name", "NCL")
-        self.ranking = conf.get("item.ranking.topN", [10, 20, 30, 50])
-        self.topN = [int(n) for n in self.ranking]
+        for attr, (key, default) in _CONF_DEFAULTS.items():
+            setattr(self, attr, conf.get(key, default))
+        for attr, key in _NCL_ARGS.items():
+            setattr(self, attr, conf["NCL"][key])
+        self.topN = list(map(int, self.ranking))
         self.max_N = max(self.topN)
         self.data = Interaction(conf, train_set, test_set, device=device)
-        args = conf["NCL"]
-        self.n_layers = args["n_layers"]
-        self.ssl_temp = args["tau"]
-        self.ssl_reg = args["ssl_reg"]
-        self.proto_reg = args["proto_reg"]
-        self.hyper_layers = args["hyper_layers"]
-        self.alpha = args["alpha"]
-        self.k = args["num_clusters"]
-        self.batch_size = conf.get("batch.size", 2048)
-        self.emb_size = conf.get("embedding.size", 64)
-        self.lRate = conf.get("learning.rate", 0.001)
-        self.reg = conf.get("reg.lambda", 0.0001)
-        self.max_epoch = conf.get("max.epoch", 1)
-        self.seed = seed
         self.model = LGCNEncoder(self.data, self.emb_size, self.n_layers)
         self.user_centroids = self.user_2cluster = self.item_centroids = self.item_2cluster = None
         self.bestPerformance = []

@@ -560,14 +560,6 @@ def _infonce_bwd_raw(x, x_scale, y, y_scale, inv_tau, lse_x, w_x, lse_y, w_y, ex
     return g
 
 
-def infonce_bwd_pair_raw(a, sa, b, sb, inv_tau, lse_a, w_a, lse_b, w_b, exclude_diagonal=False, engine_flag=None):
-    """Both input gradients of the softmax part: (ga, gb) w.r.t. the scaled rows of a and b.  (lse_a, w_a) is
-    the row side (anchors' forward lse and upstream dL/dlse), (lse_b, w_b) the column side; either may be None."""
-    ga = _infonce_bwd_raw(a, sa, b, sb, inv_tau, lse_a, w_a, lse_b, w_b, exclude_diagonal, engine_flag)
-    gb = _infonce_bwd_raw(b, sb, a, sa, inv_tau, lse_b, w_b, lse_a, w_a, exclude_diagonal, engine_flag)
-    return ga, gb
-
-
 class _InfoNCEStats(torch.autograd.Function):
     """(a, b) -> row_lse [M], pos_logit [M] (and col_lse [N]) of S = inv_tau * ahat bhat^T, with the
     flash-style HIP backward.  Every loss of the InfoNCE family is a few [M]-vector ops on top."""

@@ -360,3 +360,43 @@ def test_flash_forward_path_gives_the_same_gradients(Fn, engine, monkeypatch, m,
         _gclose(grads[flag][1], g2, rel=2e-4)
     # table side: the same launch, fed an lse that differs in the last bits (online merge vs two-stage merge)
     assert float((grads[True][1] - grads[False][1]).abs().max()) <= 1e-5 * float(grads[False][1].abs().max())
+
+
+def test_two_product_loop_random_shapes(Fn, engine):
+    """The cross-tile pipelined loop (prologue of two tiles, steps in pairs, a peeled last step, a ring of three LDS
+    images) over 48 random (M, N, d, 1/tau) incl. tile counts 1..6 per split and ragged last tiles: flash forward
+    (lse, o) and the table-side / anchor-side backward against float64."""
+    if engine != "b3":
+        pytest.skip("the pipelined loop is the split-operand engine's")
+    rng = np.random.default_rng(2024)
+    for case in range(48):
+        d = int(rng.choice([32, 64]))
+        m = int(rng.integers(1, 400))
+        n = int(rng.choice([rng.integers(1, 200), rng.integers(1, 3000), 32 * rng.integers(1, 7)]))
+        inv_tau = float(rng.choice([1.0, 5.0, 10.0, 20.0]))
+        a = (rng.standard_normal((m, d)) * rng.uniform(0.1, 2.0)).astype(np.float32)
+        b = (rng.standard_normal((n, d)) * rng.uniform(0.1, 2.0)).astype(np.float32)
+        at, bt = _t(a), _t(b)
+        sa, sb = Fn.row_inv_norm(at), Fn.row_inv_norm(bt)
+        lse, o = Fn.infonce_fwd_o_raw(at, sa, bt, sb, inv_tau)
+        an = a.astype(np.float64) / np.linalg.norm(a.astype(np.float64), axis=1, keepdims=True)
+        bn = b.astype(np.float64) / np.linalg.norm(b.astype(np.float64), axis=1, keepdims=True)
+        s = inv_tau * an @ bn.T
+        mx = s.max(1, keepdims=True)
+        p = np.exp(s - mx)
+        ref_lse = (mx + np.log(p.sum(1, keepdims=True)))[:, 0]
+        sm = p / p.sum(1, keepdims=True)
+        tag = (case, m, n, d, inv_tau)
+        np.testing.assert_allclose(lse.cpu().numpy(), ref_lse, rtol=1e-5, atol=1e-5, err_msg=str(tag))
+        ref_o = sm @ bn
+        assert np.abs(o.cpu().numpy() - ref_o).max() <= 1e-5 * max(np.abs(ref_o).max(), 1e-3), tag
+        # backward, both roles of the loop: rows of b stationary with the anchors' statistics on the streamed side,
+        # and rows of a stationary with their own statistics
+        w = rng.standard_normal(m).astype(np.float32)
+        wt = _t(w)
+        gb = Fn._infonce_bwd_raw(bt, sb, at, sa, inv_tau, None, None, lse, wt).cpu().numpy()
+        ref_gb = inv_tau * (sm * w[:, None].astype(np.float64)).T @ an
+        assert np.abs(gb - ref_gb).max() <= 2e-5 * max(np.abs(ref_gb).max(), 1e-6), tag
+        ga = Fn._infonce_bwd_raw(at, sa, bt, sb, inv_tau, lse, wt, None, None).cpu().numpy()
+        ref_ga = inv_tau * (sm * w[:, None].astype(np.float64)) @ bn
+        assert np.abs(ga - ref_ga).max() <= 2e-5 * max(np.abs(ref_ga).max(), 1e-6), tag

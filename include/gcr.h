@@ -438,6 +438,14 @@ int32_t gcr_spgemm_expand_f32(const int64_t* a_rowptr, const int32_t* a_col, con
 int32_t gcr_csr_lookup_f32(const int32_t* row_of, const int32_t* col, int64_t nnz, const int64_t* m_rowptr,
                            const int32_t* m_col, const float* m_val, float* out, void* stream);
 
+/* out[i, :] = table[idx[i], :] (0 for an id outside [0, n_rows)) and its backward out[idx[i], :] += src[i, :] (256-B
+ * float-atomic row segments, duplicate ids add up, bad ids skipped): the batch-row gathers of the loss functions
+ * (`emb[user_idx]`, ncl.py:314-316,360-361,370-373) without the sort that a generic index_put(accumulate) runs. */
+int32_t gcr_gather_rows_f32(const float* table, const int64_t* idx, int64_t n, int32_t d, int64_t n_rows, float* out,
+                            void* stream);
+int32_t gcr_scatter_add_rows_f32(const float* src, const int64_t* idx, int64_t n, int32_t d, int64_t n_rows, float* out,
+                                 void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Memory-system probes (measurement aids for the roofline block of bench.py; SURVEY.md §8d asks for
  * a device-copy bandwidth measured on the box next to the vendor peak).  16 B per lane.

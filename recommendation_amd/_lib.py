@@ -72,6 +72,8 @@ SIGNATURES = {
     "gcr_mask_columns_f32": (c_int32, [_P, c_int64, c_int32, _P, _P, _P]),
     "gcr_spgemm_expand_f32": (c_int32, [_P, _P, _P, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gcr_csr_lookup_f32": (c_int32, [_P, _P, c_int64, _P, _P, _P, _P, _P]),
+    "gcr_gather_rows_f32": (c_int32, [_P, _P, c_int64, c_int32, c_int64, _P, _P]),
+    "gcr_scatter_add_rows_f32": (c_int32, [_P, _P, c_int64, c_int32, c_int64, _P, _P]),
     "gcr_probe_copy_f32": (c_int32, [_P, _P, c_int64, _P]),
     "gcr_probe_read_f32": (c_int32, [_P, c_int64, _P, _P]),
     "gcr_probe_gather_rows_f32": (c_int32, [_P, c_int64, _P, c_int64, _P, _P]),

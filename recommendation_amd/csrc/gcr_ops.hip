@@ -104,6 +104,28 @@ __global__ __launch_bounds__(256) void csr_lookup_kernel(const int32_t* __restri
   }
 }
 
+// out[idx[i], :] += src[i, :]: one wave per source row, 256-B float-atomic row segments (duplicate ids add up; ids
+// outside [0, n_rows) are skipped)
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx,
+                                                               int64_t n, int d, int64_t n_rows, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += (int64_t)gridDim.x * 4) {
+    const int64_t r = idx[i];
+    if (r < 0 || r >= n_rows) continue;
+    for (int c = lane; c < d; c += 64) atomicAdd(out + r * d + c, src[i * d + c]);
+  }
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table, const int64_t* __restrict__ idx,
+                                                          int64_t n, int d, int64_t n_rows, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += (int64_t)gridDim.x * 4) {
+    const int64_t r = idx[i];
+    const bool ok = r >= 0 && r < n_rows;
+    for (int c = lane; c < d; c += 64) out[i * d + c] = ok ? table[r * d + c] : 0.f;
+  }
+}
+
 int ops_grid(int64_t n, int per_block) {
   const int64_t g = (n + per_block - 1) / per_block;
   return (int)(g < 1 ? 1 : (g > 65536 ? 65536 : g));
@@ -156,5 +178,25 @@ extern "C" int32_t gcr_csr_lookup_f32(const int32_t* row_of, const int32_t* col,
   GCR_CHECK_ARG(row_of && col && m_rowptr && m_col && out);
   hipLaunchKernelGGL(csr_lookup_kernel, dim3(ops_grid(nnz, 256)), dim3(256), 0, (hipStream_t)stream, row_of, col, nnz,
                      m_rowptr, m_col, m_val, out);
+  return GCR_LAUNCH_STATUS();
+}
+
+extern "C" int32_t gcr_gather_rows_f32(const float* table, const int64_t* idx, int64_t n, int32_t d, int64_t n_rows,
+                                       float* out, void* stream) {
+  GCR_CHECK_ARG(n >= 0 && d >= 1 && n_rows >= 0);
+  if (n == 0) return GCR_OK;
+  GCR_CHECK_ARG(table && idx && out);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(ops_grid(n, 4)), dim3(256), 0, (hipStream_t)stream, table, idx, n, d, n_rows,
+                     out);
+  return GCR_LAUNCH_STATUS();
+}
+
+extern "C" int32_t gcr_scatter_add_rows_f32(const float* src, const int64_t* idx, int64_t n, int32_t d, int64_t n_rows,
+                                            float* out, void* stream) {
+  GCR_CHECK_ARG(n >= 0 && d >= 1 && n_rows >= 0);
+  if (n == 0) return GCR_OK;
+  GCR_CHECK_ARG(src && idx && out);
+  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(ops_grid(n, 4)), dim3(256), 0, (hipStream_t)stream, src, idx, n, d,
+                     n_rows, out);
   return GCR_LAUNCH_STATUS();
 }

@@ -702,3 +702,38 @@ def feature_masking(x, pf, seed, keep_bits=None):
     if keep_bits is None:
         keep_bits = edge_mask_bits(x.shape[1], pf, seed, x.device)
     return _MaskColumns.apply(x, keep_bits), keep_bits
+
+
+# ---------------------------------------------------------------------------------------------
+# batch-row gathers of the loss functions
+# ---------------------------------------------------------------------------------------------
+class _GatherRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, table, idx):
+        table = table.contiguous()
+        out = torch.empty(idx.numel(), table.shape[1], dtype=torch.float32, device=table.device)
+        _lib.check(_lib.lib().gcr_gather_rows_f32(_lib.dptr(table), _lib.dptr(idx), idx.numel(), table.shape[1], table.shape[0],
+                                                  _lib.dptr(out), _lib.cur_stream(table.device)), "gcr_gather_rows_f32")
+        ctx.save_for_backward(idx)
+        ctx.shape = table.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        gt = torch.zeros(ctx.shape, dtype=torch.float32, device=g.device)
+        g = g.contiguous()
+        _lib.check(_lib.lib().gcr_scatter_add_rows_f32(_lib.dptr(g), _lib.dptr(idx), idx.numel(), g.shape[1], ctx.shape[0],
+                                                       _lib.dptr(gt), _lib.cur_stream(g.device)), "gcr_scatter_add_rows_f32")
+        return gt, None
+
+
+def gather_rows(table, idx):
+    """`table[idx]` for a float32 [N, d] table and int64 ids (`rec_user_emb[user_idx]`, `context[user]` ...; ncl.py:314-316,
+    360-361,370-373) whose backward scatters the row gradients with float atomics (gcr_scatter_add_rows_f32) instead of
+    the sort + segmented reduction of a generic index_put(accumulate=True) (which grows with the batch; at B = 2048
+    the two cost the same within noise, profiles/r02_ncl_step_kernel_stats.csv)."""
+    _lib.require_cuda(table)
+    if table.dim() != 2 or table.dtype != torch.float32:
+        raise ValueError("table must be float32 [N, d]")
+    return _GatherRows.apply(table, _as_index(idx, table.device).reshape(-1))

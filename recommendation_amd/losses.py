@@ -43,7 +43,7 @@ def ssl_layer_loss(context, initial, user, item, user_num, ssl_temp, ssl_reg, al
     item = torch.as_tensor(item, device=dev, dtype=torch.int64)
     # batch rows gathered straight from the stacked table in ONE gather (one sparse backward into
     # `context` instead of slice + gather twice)
-    rows = context[torch.cat([user, item + user_num])]
+    rows = Fn.gather_rows(context, torch.cat([user, item + user_num]))
     lse_u, pos_u = Fn.infonce_stats(rows[:user.numel()], iu, user, ssl_temp, normalize=True)
     lse_i, pos_i = Fn.infonce_stats(rows[user.numel():], ii, item, ssl_temp, normalize=True)
     return ssl_reg * ((lse_u - pos_u).sum() + alpha * (lse_i - pos_i).sum())
@@ -57,7 +57,7 @@ def ProtoNCE_loss(initial_emb, user_idx, item_idx, user_num, user_centroids, use
     item_idx = torch.as_tensor(item_idx, device=dev, dtype=torch.int64)
     u2c = user_centroids.to(dev)[user_2cluster.to(dev)[user_idx]]
     i2c = item_centroids.to(dev)[item_2cluster.to(dev)[item_idx]]
-    rows = initial_emb[torch.cat([user_idx, item_idx + user_num])]
+    rows = Fn.gather_rows(initial_emb, torch.cat([user_idx, item_idx + user_num]))
     loss_user = InfoNCE(rows[:user_idx.numel()], u2c, ssl_temp) * batch_size
     loss_item = InfoNCE(rows[user_idx.numel():], i2c, ssl_temp) * batch_size
     return proto_reg * (loss_user + loss_item)

@@ -95,3 +95,20 @@ def test_motif_adjacency_matches_reference(golden):
     assert np.array_equal((A @ B - M).to_dense().cpu().numpy(), a @ b - m)
     assert np.array_equal(A.T.to_dense().cpu().numpy(), a.T)
     assert ((A @ B - M).val != 0).all()
+
+
+@pytest.mark.parametrize("n,d,b", [(1000, 64, 4096), (37, 32, 5), (500, 128, 300), (10, 48, 0)])
+def test_gather_rows_forward_and_scatter_backward(n, d, b):
+    """Fn.gather_rows == table[idx]; its backward == the dense index_put(accumulate) gradient (duplicates add up)."""
+    from recommendation_amd import functional as Fn
+    g = torch.Generator(device="cuda").manual_seed(n + b)
+    t0 = torch.randn(n, d, device="cuda", generator=g)
+    idx = torch.randint(0, n, (b,), device="cuda", generator=g)
+    w = torch.randn(b, d, device="cuda", generator=g)
+    ta, tb = t0.clone().requires_grad_(True), t0.clone().requires_grad_(True)
+    ya, yb = ta[idx], Fn.gather_rows(tb, idx)
+    assert torch.equal(ya, yb)
+    (ya * w).sum().backward()
+    (yb * w).sum().backward()
+    tol = 1e-6 * max(float(ta.grad.abs().max()), 1.0) if b else 0.0
+    assert float((ta.grad - tb.grad).abs().max()) <= tol

@@ -261,18 +261,26 @@ def infonce_roofline(Fn, x0, n_u, dev):
     mult = 6 if engine == 1 else 1                       # bf16 split: six bf16 MFMA products per f32 product
     peak = BF16_MFMA_PEAK_TF if engine == 1 else FP32_MFMA_PEAK_TF
 
+    # the two-product launches take the caller's unit-rows promise (rows normalised by sa / sb, as every contrast
+    # loss does): two f16 planes per operand, THREE 16-bit MFMA products per f32 product instead of six
+    ef = Fn._resolve_engine(unit_rows=True)
+    mult2 = 3 if (engine == 1 and d <= 64 and ef & Fn.INFONCE_UNIT_ROWS) else mult
+    planes = "EngH2: 2 f16 planes, 3 products per f32 product" if mult2 == 3 else "EngB3: 3 bf16 planes, 6 products"
+
     def leg(kernel, t_ms, units):
         return {"kernel": kernel, "avg_launch_ms": round(t_ms, 4), "flops_alg_per_launch": units * flops,
-                "achieved_alg": round(units * flops / t_ms / 1e9, 1), "achieved": round(mult * units * flops / t_ms / 1e9, 1),
-                "frac": round(mult * units * flops / t_ms / 1e9 / peak, 4), "mfma_busy_pct": None}
+                "mfma_products_per_f32_product": mult2,
+                "achieved_alg": round(units * flops / t_ms / 1e9, 1), "achieved": round(mult2 * units * flops / t_ms / 1e9, 1),
+                "frac": round(mult2 * units * flops / t_ms / 1e9 / peak, 4), "mfma_busy_pct": None}
 
     # training path of a row-softmax loss (ncl.py:358-367): flash-style forward (lse + weighted row sum, the
     # anchor-side gradient is a scale of it) and ONE backward launch for the table side
-    t_b = _event_ms(lambda: Fn._infonce_bwd_raw(table, sb, anchors, sa, inv_tau, None, None, lse, w), 5)
+    t_b = _event_ms(lambda: Fn._infonce_bwd_raw(table, sb, anchors, sa, inv_tau, None, None, lse, w, engine_flag=ef), 5)
     fwd_o = None
     if Fn.infonce_fwd_o_supported(d):
-        t_fo = _event_ms(lambda: Fn.infonce_fwd_o_raw(anchors, sa, table, sb, inv_tau), 5)
-        fwd_o = leg("infonce_fwdo_b3_kernel<64> (score + softmax-weighted row sum, 2 MFMA products per pair)", t_fo, 2)
+        t_fo = _event_ms(lambda: Fn.infonce_fwd_o_raw(anchors, sa, table, sb, inv_tau, engine_flag=ef), 5)
+        fwd_o = leg(f"infonce_pipe_kernel<{planes.split(':')[0]}, 64, MODE 1> (score + softmax-weighted row sum; {planes})",
+                    t_fo, 2)
     out = {
         "bound": "mfma", "kernel": "infonce_fwd_b3_kernel<64>" if engine == 1 else "infonce_fwd_kernel<64>",
         "engine": "split-operand bf16 MFMA (3 planes per f32 operand, 6 products per f32 product, f32 accumulate)"
@@ -281,10 +289,12 @@ def infonce_roofline(Fn, x0, n_u, dev):
         "avg_launch_ms": round(t_f, 4), "pairs_per_s": m * n_u / t_f * 1e3,
         "achieved_alg": round(flops / t_f / 1e9, 1), "achieved": round(mult * flops / t_f / 1e9, 1),
         "peak": peak, "unit": "TFLOP/s", "frac": round(mult * flops / t_f / 1e9 / peak, 4),
-        "note": "achieved = MFMA flops issued (6 x algorithmic on the bf16 split) / launch time; peak = dense bf16 MFMA",
+        "note": "achieved = 16-bit MFMA flops issued (algorithmic x products per f32 product: 6 on three bf16 planes, "
+                "3 on two f16 planes) / launch time; peak = dense bf16 / f16 MFMA",
         "mfma_busy_pct": None,
         "fwd_o": fwd_o,
-        "bwd": leg("infonce_bwd_b3_kernel<64> (table-side gradient: score recomputed once + one product)", t_b, 2),
+        "bwd": leg(f"infonce_pipe_kernel<{planes.split(':')[0]}, 64, MODE 0> (table-side gradient: score recomputed once + "
+                   f"one product; {planes})", t_b, 2),
     }
     pmc = _committed_pmc("infonce", infonce_source_digest())
     if pmc:

@@ -443,6 +443,13 @@ __global__ __launch_bounds__(256, 2) void infonce_fwd_b3_kernel(const float* __r
 // the backward (which must recompute the forward's logits with the forward's engine, or sum_j P_ij = 1
 // only holds to ~1e-6 and near-cancelling gradients lose digits).
 bool use_b3(int d, bool force_f32 = false) { return d <= 128 && !force_f32; }
+// the two-plane f16 format of the pipelined two-product loop (EngH2 below): rows of at most unit norm (the caller's
+// promise), d <= 64, 1/tau within the pre-scale's head-room
+constexpr float kH2MaxInvTau = 64.0f;
+bool use_h2(int d, float inv_tau, bool unit_rows, bool force_f32) {
+  return use_b3(d, force_f32) && unit_rows && d <= 64 && inv_tau > 0.f && inv_tau <= kH2MaxInvTau;
+}
+constexpr int64_t kBwdHeader = 256;   // d <= 64: the backward's workspace starts with the two floats of h2_wscale_kernel
 
 // natural-log LSE of the scaled logits from the per-split (max2, sum2) partials
 __global__ void infonce_merge_kernel(const float2* __restrict__ part, int nsplit, int64_t m_rows,
@@ -1068,16 +1075,117 @@ __device__ __forceinline__ uint2 lds_read_tr16(const unsigned char* p) {      //
   return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p));
 }
 
-template <int D, int MODE, bool EXD, int SIDES>
-__global__ __launch_bounds__(256, 2) void infonce_pipe_b3_kernel(
+// ------------------------------------------------------------------------------------------
+// The two operand formats of the pipelined loop.
+//   EngB3  three bf16 planes, six product terms (gcr_b3.h): any finite f32 operand, f32 accuracy.
+//   EngH2  two f16 planes, THREE product terms: x = hi + lo with hi = f16(x), lo = f16(x - hi) (RNE,
+//          v_cvt_pk_f16_f32) leaves <= 2^-22 |x|; hi*hi + hi*lo + lo*hi drops lo*lo (2^-22): half the matrix-core work of
+//          EngB3 at an error of a few f32 roundings per product.  f16 has a 5-bit exponent, so the format is only used for
+//          operands whose range is known — rows of at most unit norm (the caller's promise GCR_INFONCE_UNIT_ROWS; every
+//          contrast loss of the reference normalises) and probabilities — each pre-scaled by a power of two that puts its
+//          largest value just under 2^15..2^16:
+//            stationary rows (<= inv_tau log2 e, inv_tau <= kH2MaxInvTau)   x 2^4      (|.| <= 1478)
+//            streamed rows   (<= 1)                                          x 2^8
+//            scores                                                          accumulator x 2^-12 (folded into the FMA in
+//                                                                            front of exp2)
+//            P, MODE 1 (<= 2^kDefer = 2 relative to the lagging reference)   x 2^14
+//            P, MODE 0 (w e^{s - lse} <= 2 max|w|)                           x 2^14 / 2^ceil(log2 max|w|) (max|w| from a
+//                                                                            one-block pre-pass, h2_wscale_kernel)
+//          Values below the f16 normal range (2^-14 after scaling: a row element under 2^-22, a probability 2^-28 under
+//          the reference) go sub-normal, which v_cvt_pk_f16_f32 produces and v_mfma_f32_32x32x16_f16 honours
+//          (scripts/exp/f16_denorm_probe.hip, run on the box): their absolute error stays <= 2^-25 of the scaled unit.
+// ------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+struct EngB3 {
+  static constexpr int NPL = 3, NTERM = 6;
+  static constexpr float kSX = 1.0f, kSY = 1.0f;         // operand pre-scales
+  static constexpr float kSInv = 1.0f;                   // accumulator -> log2-domain score
+  static constexpr float kPExp = 0.0f;                   // log2 of the scale of P
+  static constexpr float kDeferE = kDefer;
+  static __host__ __device__ constexpr int ta(int t) { constexpr int v[6] = {2, 0, 1, 1, 0, 0}; return v[t]; }   // streamed-side
+  static __host__ __device__ constexpr int tb(int t) { constexpr int v[6] = {0, 2, 1, 0, 1, 0}; return v[t]; }   // plane / other
+  static __device__ __forceinline__ void split(float a, float b, unsigned (&p)[3]) { split3(a, b, p[0], p[1], p[2]); }
+  static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) { return mfma_bf16(a, b, c); }
+};
+
+struct EngH2 {
+  static constexpr int NPL = 2, NTERM = 3;
+  static constexpr float kSX = 16.0f, kSY = 256.0f;
+  static constexpr float kSInv = 1.0f / 4096.0f;
+  static constexpr float kPExp = 14.0f;
+  static constexpr float kDeferE = 1.0f;
+  static __host__ __device__ constexpr int ta(int t) { constexpr int v[3] = {1, 0, 0}; return v[t]; }
+  static __host__ __device__ constexpr int tb(int t) { constexpr int v[3] = {0, 1, 0}; return v[t]; }
+  static __device__ __forceinline__ void split(float a, float b, unsigned (&p)[2]) {
+    const f16x2 hi = __builtin_convertvector((f32x2){a, b}, f16x2);                 // v_cvt_pk_f16_f32, RNE
+    p[0] = __builtin_bit_cast(unsigned, hi);
+    p[1] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a - (float)hi[0], b - (float)hi[1]}, f16x2));
+  }
+  static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+
+// stationary operand planes of engine E: frag[p][c] = 8 consecutive features [h*KH + 8c, +8) of plane p
+template <class E, int D>
+__device__ __forceinline__ void load_stationary_e(const float* __restrict__ a, const float* __restrict__ a_scale,
+                                                  int64_t m_rows, int64_t row, int h, float mult,
+                                                  u32x4 (&frag)[E::NPL][ShapeB3<D>::KC]) {
+  using S = ShapeB3<D>;
+  const bool valid = row < m_rows;
+  const float s = valid ? (a_scale != nullptr ? a_scale[row] : 1.0f) * mult : 0.f;
+  const float* p = a + (valid ? row : 0) * D + h * S::KH;
+#pragma unroll
+  for (int c = 0; c < S::KC; ++c) {
+    const float4 v0 = valid ? *reinterpret_cast<const float4*>(p + 8 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 v1 = valid ? *reinterpret_cast<const float4*>(p + 8 * c + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned q[4][E::NPL];
+    E::split(v0.x * s, v0.y * s, q[0]);
+    E::split(v0.z * s, v0.w * s, q[1]);
+    E::split(v1.x * s, v1.y * s, q[2]);
+    E::split(v1.z * s, v1.w * s, q[3]);
+#pragma unroll
+    for (int pl = 0; pl < E::NPL; ++pl) frag[pl][c] = (u32x4){q[0][pl], q[1][pl], q[2][pl], q[3][pl]};
+  }
+}
+
+// max |w| over both weight vectors -> hw[0] = 2^14 / 2^ceil(log2 max|w|) (what the weights are multiplied by before
+// they meet e^{s - lse} <= 1, so that P stays in f16 range), hw[1] = 1 / (hw[0] * 2^8) (undoes it, and the streamed
+// operand's 2^8, on the way out).  One block.
+__global__ __launch_bounds__(1024) void h2_wscale_kernel(const float* __restrict__ w_x, int64_t mx,
+                                                         const float* __restrict__ w_y, int64_t ny, float* __restrict__ hw) {
+  __shared__ float red[16];
+  float m = 0.f;
+  if (w_x != nullptr)
+    for (int64_t i = threadIdx.x; i < mx; i += 1024) m = fmaxf(m, fabsf(w_x[i]));
+  if (w_y != nullptr)
+    for (int64_t i = threadIdx.x; i < ny; i += 1024) m = fmaxf(m, fabsf(w_y[i]));
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 16; ++k) m = fmaxf(m, red[k]);
+    int e = 0;
+    if (m > 0.f && m < INFINITY) (void)frexpf(m, &e);                 // m = f * 2^e, f in [0.5, 1): |w| 2^-e < 1
+    e = min(max(e, -100), 100);
+    hw[0] = ldexpf(1.0f, 14 - e);
+    hw[1] = ldexpf(1.0f, e - 22);
+  }
+}
+
+template <class E, int D, int MODE, bool EXD, int SIDES>
+__global__ __launch_bounds__(256, 2) void infonce_pipe_kernel(
     const float* __restrict__ x, const float* __restrict__ x_scale, int64_t mx, const float* __restrict__ y,
     const float* __restrict__ y_scale, int64_t ny, float scale2, float out_scale, const float* __restrict__ lse_x,
     const float* __restrict__ w_x, const float* __restrict__ lse_y, const float* __restrict__ w_y, int nsplit,
-    int64_t tiles_per_split, float* __restrict__ gpart, float2* __restrict__ part) {
+    int64_t tiles_per_split, float* __restrict__ gpart, float2* __restrict__ part, const float* __restrict__ hw) {
   using S = ShapeB3<D>;
   using B = BwdB3<D>;
   static_assert(D <= 64, "the pipelined loop keeps five plane sets in LDS");
-  constexpr int RM = 3 * S::PLANE;
+  constexpr int NPL = E::NPL, NTERM = E::NTERM;
+  constexpr int RM = NPL * S::PLANE;
   __shared__ __align__(16) unsigned char lds_rm[3][RM];      // ring: tile t (B, transposed reads), t+1 (A), t+2 (staging)
   __shared__ __align__(16) float st_lse[2][kTileJ];
   __shared__ __align__(16) float st_w[2][kTileJ];
@@ -1087,10 +1195,12 @@ __global__ __launch_bounds__(256, 2) void infonce_pipe_b3_kernel(
   const int split = blockIdx.x % nsplit;
   const int64_t row_i = (mblk * 4 + wave) * 32 + i32;
 
-  u32x4 bq[1][3][S::KC];
-  load_stationary_b3<D>(x, x_scale, mx, row_i, h, scale2, bq[0]);
+  u32x4 bq[1][NPL][S::KC];
+  load_stationary_e<E, D>(x, x_scale, mx, row_i, h, scale2 * E::kSX, bq[0]);
+  // MODE 0 on EngH2: weights pre-scaled into f16 range (h2_wscale_kernel); hw == nullptr otherwise
+  const float w_mul = hw != nullptr ? hw[0] : 1.0f;
   const bool on_x = MODE == 0 && row_i < mx && w_x != nullptr;
-  const float wl = on_x ? w_x[row_i] : 0.f;
+  const float wl = on_x ? w_x[row_i] * w_mul : 0.f;
   const float lse2l = on_x ? lse_x[row_i] * kLog2e : 1.0e30f;
   float m_run = kNegBig, l_run = 0.f;                   // MODE 1
   f32x16 gacc[B::CT];
@@ -1103,8 +1213,7 @@ __global__ __launch_bounds__(256, 2) void infonce_pipe_b3_kernel(
   const int64_t tile0 = (int64_t)split * tiles_per_split;
   const int64_t tile1 = min(total_tiles, tile0 + tiles_per_split);
   if (tile0 < tile1) {
-    constexpr int NP = 3 * S::NLD, NS1 = 6 * S::KC, NG = B::CT * 12;
-    constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+    constexpr int NP = 3 * S::NLD, NS1 = NTERM * S::KC, NG = B::CT * 2 * NTERM;
     const int64_t last = tile1 - 1;
     float4 ra[S::NLD], rb[S::NLD];
     float sla = 0.f, swa = 0.f, slb = 0.f, swb = 0.f;
@@ -1121,7 +1230,7 @@ __global__ __launch_bounds__(256, 2) void infonce_pipe_b3_kernel(
         const int row = idx / (D / 4), c4 = idx % (D / 4);
         const int rr = min(row, rem - 1);
         float4 v = *reinterpret_cast<const float4*>(tb + rr * D + 4 * c4);
-        float sc = ts != nullptr ? ts[rr] : 1.0f;
+        float sc = ts != nullptr ? ts[rr] * E::kSY : E::kSY;
         sc = row < rem ? sc : 0.f;
         v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
         r[u] = v;
@@ -1129,24 +1238,24 @@ __global__ __launch_bounds__(256, 2) void infonce_pipe_b3_kernel(
       if (MODE == 0 && tid < kTileJ) {
         const int64_t j = j0 + tid;
         const bool on = j < ny && w_y != nullptr;
-        sw = on ? w_y[j] : 0.f;
+        sw = on ? w_y[j] * w_mul : 0.f;
         sl = on ? lse_y[j] * kLog2e : 1.0e30f;
       }
     };
     // one third of the staging of one float4: split (x, y), split (z, w), row-major plane stores
-    auto stage_part = [&](int pi, const float4 (&st)[S::NLD], unsigned (&sa)[S::NLD][3], unsigned (&sb)[S::NLD][3],
+    auto stage_part = [&](int pi, const float4 (&st)[S::NLD], unsigned (&sa)[S::NLD][NPL], unsigned (&sb)[S::NLD][NPL],
                           unsigned char* rm, int sbuf, float sl, float sw) {
       const int u = pi / 3, k = pi % 3;
       const int idx = tid + 256 * u;
       const int row = idx / (D / 4), c4 = idx % (D / 4);
       if (k == 0) {
-        split3(st[u].x, st[u].y, sa[u][0], sa[u][1], sa[u][2]);
+        E::split(st[u].x, st[u].y, sa[u]);
       } else if (k == 1) {
-        split3(st[u].z, st[u].w, sb[u][0], sb[u][1], sb[u][2]);
+        E::split(st[u].z, st[u].w, sb[u]);
       } else {
         unsigned char* p = rm + row * S::ROWB + c4 * 8;
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint2*>(p + pl * S::PLANE) = make_uint2(sa[u][pl], sb[u][pl]);
+        for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<uint2*>(p + pl * S::PLANE) = make_uint2(sa[u][pl], sb[u][pl]);
         if (MODE == 0 && u == 0 && tid < kTileJ) {
           st_lse[sbuf][tid] = sl;
           st_w[sbuf][tid] = sw;
@@ -1154,24 +1263,27 @@ __global__ __launch_bounds__(256, 2) void infonce_pipe_b3_kernel(
       }
     };
     auto stage_all = [&](const float4 (&st)[S::NLD], unsigned char* rm, int sbuf, float sl, float sw) {
-      unsigned sa[S::NLD][3], sb[S::NLD][3];
+      unsigned sa[S::NLD][NPL], sb[S::NLD][NPL];
 #pragma unroll
       for (int pi = 0; pi < NP; ++pi) stage_part(pi, st, sa, sb, rm, sbuf, sl, sw);
     };
     // micro-unit m of P(t) from the finished scores of tile t: MODE 0: 0..15 one register each, 16..23 one split3
     // each; MODE 1: the same after `prepare` fixed the reference point.
-    float m_use = kNegBig, alpha = 1.0f, psum = 0.f;
+    float m_use = kNegBig, alpha = 1.0f, psum = 0.f, p_off = 0.f;
     bool rescale = false;
     auto prepare = [&](f32x16& acc, int64_t t) {        // masks (ragged tile / excluded diagonal); MODE 1: reference point
       const int64_t j0 = t * kTileJ;
-      if (EXD || j0 + kTileJ > ny) {
+      const int lim = (int)min((int64_t)kTileJ, ny - j0);   // rows of this tile that exist (wave-uniform)
+      if (EXD || lim < kTileJ) {
+        // a real (scalar) branch: if-converted, the 16 selects with their compares would run for every tile
+        if (!EXD) asm volatile("" ::: "memory");
         const int xr = EXD ? diag_offset(row_i, j0, h) : -1;
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int r = 4 * g + e;
-            const bool dead = (j0 + acc_row(r, h) >= ny) || (EXD && xr == e + 8 * g);
+            const bool dead = (acc_row(r, h) >= lim) || (EXD && xr == e + 8 * g);
             acc[r] = dead ? -INFINITY : acc[r];
           }
       }
@@ -1180,29 +1292,33 @@ __global__ __launch_bounds__(256, 2) void infonce_pipe_b3_kernel(
 #pragma unroll
         for (int g = 1; g < 4; ++g)
           tmax = fmaxf(tmax, fmaxf(fmaxf(acc[4 * g], acc[4 * g + 1]), fmaxf(acc[4 * g + 2], acc[4 * g + 3])));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        rescale = __any(tmax > m_run + kDefer);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * E::kSInv;
+        rescale = __any(tmax > m_run + E::kDeferE);
         m_use = rescale ? fmaxf(m_run, tmax) : m_run;
         alpha = __builtin_amdgcn_exp2f(m_run - m_use);
         psum = 0.f;
+        p_off = E::kPExp - m_use;
       }
     };
-    auto p_unit = [&](int m, f32x16& acc, int sbuf, unsigned (&pq)[2][3][4]) {
+    auto p_unit = [&](int m, f32x16& acc, int sbuf, unsigned (&pq)[2][NPL][4]) {
       if (m < 16) {
         const int r = m;
         if (MODE == 1) {
-          acc[r] = __builtin_amdgcn_exp2f(acc[r] - m_use);
+          acc[r] = __builtin_amdgcn_exp2f(fmaf(acc[r], E::kSInv, p_off));
           psum += acc[r];
         } else {
           const float lre = st_lse[sbuf][acc_row(r, h)], wre = st_w[sbuf][acc_row(r, h)];
           const float sc = acc[r];
-          if (SIDES == 1) acc[r] = wl * __builtin_amdgcn_exp2f(sc - lse2l);
-          else if (SIDES == 2) acc[r] = wre * __builtin_amdgcn_exp2f(sc - lre);
-          else acc[r] = wl * __builtin_amdgcn_exp2f(sc - lse2l) + wre * __builtin_amdgcn_exp2f(sc - lre);
+          if (SIDES == 1) acc[r] = wl * __builtin_amdgcn_exp2f(fmaf(sc, E::kSInv, -lse2l));
+          else if (SIDES == 2) acc[r] = wre * __builtin_amdgcn_exp2f(fmaf(sc, E::kSInv, -lre));
+          else acc[r] = wl * __builtin_amdgcn_exp2f(fmaf(sc, E::kSInv, -lse2l)) + wre * __builtin_amdgcn_exp2f(fmaf(sc, E::kSInv, -lre));
         }
       } else {
         const int e = m - 16;                            // pair (2e, 2e + 1): k-chunk e / 4, dword e % 4
-        split3(acc[2 * e], acc[2 * e + 1], pq[e >> 2][0][e & 3], pq[e >> 2][1][e & 3], pq[e >> 2][2][e & 3]);
+        unsigned q[NPL];
+        E::split(acc[2 * e], acc[2 * e + 1], q);
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) pq[e >> 2][pl][e & 3] = q[pl];
       }
     };
     auto finish_p = [&]() {                               // MODE 1: between two B phases
@@ -1219,13 +1335,21 @@ __global__ __launch_bounds__(256, 2) void infonce_pipe_b3_kernel(
       }
     };
     auto score_plain = [&](const unsigned char* rm, f32x16& acc) {
-      f32x16 a1[1];
-      score_tile_b3<D, 1>(rm, i32, h, bq, a1);
-      acc = a1[0];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const unsigned char* base = rm + i32 * S::ROWB + h * (S::KH * 2);
+#pragma unroll
+      for (int c = 0; c < S::KC; ++c) {
+        u32x4 ap[NPL];
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) ap[pl] = *reinterpret_cast<const u32x4*>(base + pl * S::PLANE + 16 * c);
+#pragma unroll
+        for (int term = 0; term < NTERM; ++term) acc = E::mfma(ap[E::ta(term)], bq[0][E::tb(term)][c], acc);
+      }
     };
 
     // ---- prologue: tiles 0 and 1 staged, P(tile0) ready, tile 2 in registers, tile 3 loading
-    unsigned pqa[2][3][4], pqb[2][3][4];
+    unsigned pqa[2][NPL][4], pqb[2][NPL][4];
     f32x16 acc;
     load_tile(tile0, ra, sla, swa);
     stage_all(ra, lds_rm[0], 0, sla, swa);
@@ -1241,36 +1365,36 @@ __global__ __launch_bounds__(256, 2) void infonce_pipe_b3_kernel(
     __syncthreads();
 
     // step t: tile t's P planes in `pc`, tile t+2 in `st` registers; produces P(t+1) in `pn`, loads tile t+3 to `ld`
-    auto step = [&](auto next_c, int64_t t, int k3, unsigned (&pc)[2][3][4], unsigned (&pn)[2][3][4],
+    auto step = [&](auto next_c, int64_t t, int k3, unsigned (&pc)[2][NPL][4], unsigned (&pn)[2][NPL][4],
                     const float4 (&st)[S::NLD], float st_l, float st_w_v, float4 (&ld)[S::NLD], float& ld_l, float& ld_w) {
       constexpr bool real_next = decltype(next_c)::value;    // false only for the split's last tile (compile time:
                                                              // no branch may sit between the MFMAs of a phase)
       const int par = (int)((t - tile0) & 1);            // parity of tile t (the per-tile statistics are double-buffered)
       load_tile(t + 3, ld, ld_l, ld_w);
       unsigned char* rm_out = lds_rm[(k3 + 2) % 3];      // tile t in rm[k3], t+1 in rm[k3 + 1], t+2 goes to rm[k3 + 2]
-      unsigned sa[S::NLD][3], sb[S::NLD][3];
+      unsigned sa[S::NLD][NPL], sb[S::NLD][NPL];
       // phase A: S^T of tile t+1 || staging of tile t+2
       {
         const unsigned char* base = lds_rm[(k3 + 1) % 3] + i32 * S::ROWB + h * (S::KH * 2);
-        u32x4 ap[2][3];
+        u32x4 ap[2][NPL];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) ap[0][pl] = *reinterpret_cast<const u32x4*>(base + pl * S::PLANE);
+        for (int pl = 0; pl < NPL; ++pl) ap[0][pl] = *reinterpret_cast<const u32x4*>(base + pl * S::PLANE);
 #pragma unroll
         for (int c = 0; c < S::KC; ++c) {
           if (c + 1 < S::KC) {
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
+            for (int pl = 0; pl < NPL; ++pl)
               ap[(c + 1) & 1][pl] = *reinterpret_cast<const u32x4*>(base + pl * S::PLANE + 16 * (c + 1));
           }
 #pragma unroll
-          for (int term = 0; term < 6; ++term) {
-            const int slot = c * 6 + term;
+          for (int term = 0; term < NTERM; ++term) {
+            const int slot = c * NTERM + term;
             f32x16 cin = acc;
             if (slot == 0) {
 #pragma unroll
               for (int r = 0; r < 16; ++r) cin[r] = 0.f;
             }
-            acc = mfma_bf16(ap[c & 1][TA[term]], bq[0][TB[term]][c], cin);
+            acc = E::mfma(ap[c & 1][E::ta(term)], bq[0][E::tb(term)][c], cin);
 #pragma unroll
             for (int pi = slot * NP / NS1; pi < (slot + 1) * NP / NS1; ++pi)
               stage_part(pi, st, sa, sb, rm_out, par, st_l, st_w_v);
@@ -1287,29 +1411,29 @@ __global__ __launch_bounds__(256, 2) void infonce_pipe_b3_kernel(
       // 2-byte stores.  Fragment element j of lane half h is tile row 16 kc + 8 (j >> 2) + 4 h + (j & 3), the
       // k order of the accumulator-as-operand P planes.
       const unsigned char* tbase = lds_rm[k3] + (4 * h + ((lane & 15) >> 2)) * S::ROWB + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
-      auto load_ya = [&](int grp, u32x4 (&ya)[3]) {     // grp = kc * CT + c
+      auto load_ya = [&](int grp, u32x4 (&ya)[NPL]) {     // grp = kc * CT + c
         const int kc = grp / B::CT, c = grp % B::CT;
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
+        for (int pl = 0; pl < NPL; ++pl) {
           const unsigned char* p = tbase + pl * S::PLANE + (16 * kc) * S::ROWB + 64 * c;
           const uint2 lo = lds_read_tr16(p);
           const uint2 hi = lds_read_tr16(p + 8 * S::ROWB);
           ya[pl] = (u32x4){lo.x, lo.y, hi.x, hi.y};
         }
       };
-      u32x4 ya[2][3];
+      u32x4 ya[2][NPL];
       load_ya(0, ya[0]);
 #pragma unroll
       for (int grp = 0; grp < 2 * B::CT; ++grp) {
         const int kc = grp / B::CT, c = grp % B::CT;
         if (grp + 1 < 2 * B::CT) load_ya(grp + 1, ya[(grp + 1) & 1]);
-        u32x4 pp[3];
+        u32x4 pp[NPL];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) pp[pl] = (u32x4){pc[kc][pl][0], pc[kc][pl][1], pc[kc][pl][2], pc[kc][pl][3]};
+        for (int pl = 0; pl < NPL; ++pl) pp[pl] = (u32x4){pc[kc][pl][0], pc[kc][pl][1], pc[kc][pl][2], pc[kc][pl][3]};
 #pragma unroll
-        for (int term = 0; term < 6; ++term) {
-          gacc[c] = mfma_bf16(ya[grp & 1][TA[term]], pp[TB[term]], gacc[c]);
-          const int slot = grp * 6 + term;
+        for (int term = 0; term < NTERM; ++term) {
+          gacc[c] = E::mfma(ya[grp & 1][E::ta(term)], pp[E::tb(term)], gacc[c]);
+          const int slot = grp * NTERM + term;
           if (MODE == 0 || real_next) {
 #pragma unroll
             for (int m = slot * 24 / NG; m < (slot + 1) * 24 / NG; ++m) p_unit(m, acc, par ^ 1, pn);
@@ -1340,15 +1464,18 @@ __global__ __launch_bounds__(256, 2) void infonce_pipe_b3_kernel(
   float* gout = gpart + (int64_t)split * mx * D;
   if (MODE == 1) {
     const float l_o = __shfl_xor(l_run, 32, 64);
-    if (h == 0 && row_i < mx) part[(int64_t)split * mx + row_i] = make_float2(m_run, l_run + l_o);
+    // the sum carries the scale of P (2^kPExp), the rows P's and the streamed operand's
+    if (h == 0 && row_i < mx)
+      part[(int64_t)split * mx + row_i] = make_float2(m_run, (l_run + l_o) * __builtin_amdgcn_exp2f(-E::kPExp));
   }
+  const float o_mul = out_scale * (hw != nullptr ? hw[1] : 1.0f);
   if (row_i < mx) {
 #pragma unroll
     for (int c = 0; c < B::CT; ++c)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        float4 v = make_float4(gacc[c][4 * g + 0] * out_scale, gacc[c][4 * g + 1] * out_scale,
-                               gacc[c][4 * g + 2] * out_scale, gacc[c][4 * g + 3] * out_scale);
+        float4 v = make_float4(gacc[c][4 * g + 0] * o_mul, gacc[c][4 * g + 1] * o_mul,
+                               gacc[c][4 * g + 2] * o_mul, gacc[c][4 * g + 3] * o_mul);
         *reinterpret_cast<float4*>(gout + row_i * D + 32 * c + 8 * g + 4 * h) = v;
       }
   }
@@ -1454,21 +1581,33 @@ int32_t reduce_splits(const FwdPlan& p, const float* gpart, int64_t mx, int d, f
 template <int D>
 int32_t launch_bwd(const float* x, const float* x_scale, int64_t mx, const float* y, const float* y_scale, int64_t ny,
                    float inv_tau, const float* lse_x, const float* w_x, const float* lse_y, const float* w_y, float* g,
-                   void* workspace, bool exd, bool force_f32, hipStream_t s) {
+                   void* workspace, bool exd, bool force_f32, bool unit_rows, hipStream_t s) {
   if constexpr (D <= 128) {
     if (use_b3(D, force_f32)) {
       // d <= 64: the cross-tile pipelined loop (infonce_pipe_b3_kernel); d = 128: single-buffered (one tile with its
       // transposed copy is 54 KB of LDS)
       const FwdPlan p = plan_bwd_rows(mx, ny, D, BwdB3<D>::ROWS_PER_BLOCK);
-      float* gpart = p.nsplit == 1 ? g : reinterpret_cast<float*>(workspace);
+      float* gpart = p.nsplit == 1 ? g : reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + (D <= 64 ? kBwdHeader : 0));
       const dim3 grid((unsigned)(p.m_blocks * p.nsplit));
       const bool has_x = w_x != nullptr && lse_x != nullptr, has_y = w_y != nullptr && lse_y != nullptr;
+      const bool h2 = use_h2(D, inv_tau, unit_rows, force_f32);
+      float* hw = reinterpret_cast<float*>(workspace);
+      if (h2) {
+        hipLaunchKernelGGL(h2_wscale_kernel, dim3(1), dim3(1024), 0, s, w_x, mx, w_y, ny, hw);
+        int32_t st = GCR_LAUNCH_STATUS();
+        if (st != GCR_OK) return st;
+      }
 #define GCR_BWD3(EX, SD)                                                                                                \
-  if constexpr (D <= 64)                                                                                                \
-    hipLaunchKernelGGL((infonce_pipe_b3_kernel<D, 0, EX, SD>), grid, dim3(256), 0, s, x, x_scale, mx, y, y_scale, ny,   \
-                       inv_tau * kLog2e, inv_tau, lse_x, w_x, lse_y, w_y, p.nsplit, p.tiles_per_split, gpart,           \
-                       (float2*)nullptr);                                                                               \
-  else                                                                                                                  \
+  if constexpr (D <= 64) {                                                                                              \
+    if (h2)                                                                                                             \
+      hipLaunchKernelGGL((infonce_pipe_kernel<EngH2, D, 0, EX, SD>), grid, dim3(256), 0, s, x, x_scale, mx, y, y_scale, \
+                         ny, inv_tau * kLog2e, inv_tau, lse_x, w_x, lse_y, w_y, p.nsplit, p.tiles_per_split, gpart,     \
+                         (float2*)nullptr, (const float*)hw);                                                           \
+    else                                                                                                                \
+      hipLaunchKernelGGL((infonce_pipe_kernel<EngB3, D, 0, EX, SD>), grid, dim3(256), 0, s, x, x_scale, mx, y, y_scale, \
+                         ny, inv_tau * kLog2e, inv_tau, lse_x, w_x, lse_y, w_y, p.nsplit, p.tiles_per_split, gpart,     \
+                         (float2*)nullptr, (const float*)nullptr);                                                      \
+  } else                                                                                                                \
     hipLaunchKernelGGL((infonce_bwd_b3_kernel<D, EX, SD>), grid, dim3(256), 0, s, x, x_scale, mx, y, y_scale,    \
                        ny, inv_tau * kLog2e, inv_tau, lse_x, w_x, lse_y, w_y, p.nsplit, p.tiles_per_split, gpart)
       if (exd) {
@@ -1487,7 +1626,7 @@ int32_t launch_bwd(const float* x, const float* x_scale, int64_t mx, const float
     }
   }
   const FwdPlan p = plan_bwd<D>(mx, ny);
-  float* gpart = p.nsplit == 1 ? g : reinterpret_cast<float*>(workspace);
+  float* gpart = p.nsplit == 1 ? g : reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + (D <= 64 ? kBwdHeader : 0));
   for (int pass = 0; pass < BwdShape<D>::PASSES; ++pass) {
     if (exd)
       hipLaunchKernelGGL((infonce_bwd_kernel<D, true>), dim3((unsigned)(p.m_blocks * p.nsplit)), dim3(256), 0, s, x,
@@ -1555,19 +1694,25 @@ int32_t launch_fwd(const float* a, const float* a_scale, int64_t m, const float*
 
 template <int D>
 int32_t launch_fwd_o(const float* a, const float* a_scale, int64_t m, const float* b, const float* b_scale, int64_t n,
-                     float inv_tau, float* lse, float* o, void* workspace, bool exd, hipStream_t s) {
+                     float inv_tau, float* lse, float* o, void* workspace, bool exd, bool unit_rows, hipStream_t s) {
   const FwdPlan p = plan_bwd_rows(m, n, D, BwdB3<D>::ROWS_PER_BLOCK);
   float2* part = reinterpret_cast<float2*>(workspace);
   float* opart = reinterpret_cast<float*>(part + (int64_t)p.nsplit * m);
   const dim3 grid((unsigned)(p.m_blocks * p.nsplit));
   if constexpr (D <= 64) {
     const float* none = nullptr;
-    if (exd)
-      hipLaunchKernelGGL((infonce_pipe_b3_kernel<D, 1, true, 0>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale, n,
-                         inv_tau * kLog2e, 1.0f, none, none, none, none, p.nsplit, p.tiles_per_split, opart, part);
-    else
-      hipLaunchKernelGGL((infonce_pipe_b3_kernel<D, 1, false, 0>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale, n,
-                         inv_tau * kLog2e, 1.0f, none, none, none, none, p.nsplit, p.tiles_per_split, opart, part);
+    const float h2_out = 1.0f / (EngH2::kSY * 16384.0f);             // streamed operand x 2^8, P x 2^kPExp
+#define GCR_FWDO(ENG, EX, OS)                                                                                            \
+  hipLaunchKernelGGL((infonce_pipe_kernel<ENG, D, 1, EX, 0>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale, n,        \
+                     inv_tau * kLog2e, OS, none, none, none, none, p.nsplit, p.tiles_per_split, opart, part, none)
+    if (use_h2(D, inv_tau, unit_rows, false)) {
+      if (exd) GCR_FWDO(EngH2, true, h2_out);
+      else GCR_FWDO(EngH2, false, h2_out);
+    } else {
+      if (exd) GCR_FWDO(EngB3, true, 1.0f);
+      else GCR_FWDO(EngB3, false, 1.0f);
+    }
+#undef GCR_FWDO
   } else {
     if (exd)
       hipLaunchKernelGGL((infonce_fwdo_b3_kernel<D, true>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale, n,
@@ -2011,7 +2156,7 @@ extern "C" int32_t gcr_infonce_fwd_ex_f32(const float* a, const float* a_scale, 
                                           float* col_sum, float col_bound, void* workspace, uint32_t flags,
                                           void* stream) {
   GCR_CHECK_ARG(m >= 0 && n >= 1);
-  GCR_CHECK_ARG((flags & ~(uint32_t)(GCR_INFONCE_EXCLUDE_DIAGONAL | GCR_INFONCE_ENGINE_F32)) == 0);
+  GCR_CHECK_ARG((flags & ~(uint32_t)(GCR_INFONCE_EXCLUDE_DIAGONAL | GCR_INFONCE_ENGINE_F32 | GCR_INFONCE_UNIT_ROWS)) == 0);
   const bool exd = (flags & GCR_INFONCE_EXCLUDE_DIAGONAL) != 0;
   const bool force_f32 = (flags & GCR_INFONCE_ENGINE_F32) != 0;
   GCR_CHECK_ARG(!(exd && col_sum != nullptr));
@@ -2042,16 +2187,17 @@ extern "C" int32_t gcr_infonce_fwd_o_f32(const float* a, const float* a_scale, i
                                          const float* b_scale, int64_t n, int32_t d, float inv_tau, float* lse,
                                          float* o, void* workspace, uint32_t flags, void* stream) {
   GCR_CHECK_ARG(m >= 0 && n >= 1);
-  GCR_CHECK_ARG((flags & ~(uint32_t)(GCR_INFONCE_EXCLUDE_DIAGONAL | GCR_INFONCE_ENGINE_F32)) == 0);
+  GCR_CHECK_ARG((flags & ~(uint32_t)(GCR_INFONCE_EXCLUDE_DIAGONAL | GCR_INFONCE_ENGINE_F32 | GCR_INFONCE_UNIT_ROWS)) == 0);
   if (!gcr_infonce_fwd_o_supported(d, flags)) return GCR_EUNSUPPORTED;
   if (m == 0) return GCR_OK;
   GCR_CHECK_ARG(a != nullptr && b != nullptr && lse != nullptr && o != nullptr && workspace != nullptr);
   const bool exd = (flags & GCR_INFONCE_EXCLUDE_DIAGONAL) != 0;
+  const bool unit = (flags & GCR_INFONCE_UNIT_ROWS) != 0;
   hipStream_t s = (hipStream_t)stream;
   switch (d) {
-    case 32: return launch_fwd_o<32>(a, a_scale, m, b, b_scale, n, inv_tau, lse, o, workspace, exd, s);
-    case 64: return launch_fwd_o<64>(a, a_scale, m, b, b_scale, n, inv_tau, lse, o, workspace, exd, s);
-    default: return launch_fwd_o<128>(a, a_scale, m, b, b_scale, n, inv_tau, lse, o, workspace, exd, s);
+    case 32: return launch_fwd_o<32>(a, a_scale, m, b, b_scale, n, inv_tau, lse, o, workspace, exd, unit, s);
+    case 64: return launch_fwd_o<64>(a, a_scale, m, b, b_scale, n, inv_tau, lse, o, workspace, exd, unit, s);
+    default: return launch_fwd_o<128>(a, a_scale, m, b, b_scale, n, inv_tau, lse, o, workspace, exd, unit, s);
   }
 }
 
@@ -2097,7 +2243,7 @@ extern "C" int64_t gcr_infonce_bwd_workspace_bytes(int64_t mx, int64_t ny, int32
     const FwdPlan q = plan_bwd_rows(mx, ny, d, 128);
     if (q.nsplit > nsplit) nsplit = q.nsplit;
   }
-  return nsplit > 1 ? nsplit * mx * d * (int64_t)sizeof(float) : 0;
+  return (nsplit > 1 ? nsplit * mx * d * (int64_t)sizeof(float) : 0) + (d <= 64 ? kBwdHeader : 0);
 }
 
 extern "C" int32_t gcr_infonce_bwd_ex_f32(const float* x, const float* x_scale, int64_t mx, const float* y,
@@ -2105,9 +2251,10 @@ extern "C" int32_t gcr_infonce_bwd_ex_f32(const float* x, const float* x_scale, 
                                           const float* lse_x, const float* w_x, const float* lse_y, const float* w_y,
                                           float* g, void* workspace, uint32_t flags, void* stream) {
   GCR_CHECK_ARG(mx >= 0 && ny >= 1);
-  GCR_CHECK_ARG((flags & ~(uint32_t)(GCR_INFONCE_EXCLUDE_DIAGONAL | GCR_INFONCE_ENGINE_F32)) == 0);
+  GCR_CHECK_ARG((flags & ~(uint32_t)(GCR_INFONCE_EXCLUDE_DIAGONAL | GCR_INFONCE_ENGINE_F32 | GCR_INFONCE_UNIT_ROWS)) == 0);
   const bool exd = (flags & GCR_INFONCE_EXCLUDE_DIAGONAL) != 0;
   const bool force_f32 = (flags & GCR_INFONCE_ENGINE_F32) != 0;
+  const bool unit = (flags & GCR_INFONCE_UNIT_ROWS) != 0;
   if (!dim_supported(d)) return GCR_EUNSUPPORTED;
   if (mx == 0) return GCR_OK;
   GCR_CHECK_ARG(x != nullptr && y != nullptr && g != nullptr);
@@ -2115,10 +2262,10 @@ extern "C" int32_t gcr_infonce_bwd_ex_f32(const float* x, const float* x_scale, 
   GCR_CHECK_ARG(workspace != nullptr || gcr_infonce_bwd_workspace_bytes(mx, ny, d) == 0);
   hipStream_t s = (hipStream_t)stream;
   switch (d) {
-    case 32: return launch_bwd<32>(x, x_scale, mx, y, y_scale, ny, inv_tau, lse_x, w_x, lse_y, w_y, g, workspace, exd, force_f32, s);
-    case 64: return launch_bwd<64>(x, x_scale, mx, y, y_scale, ny, inv_tau, lse_x, w_x, lse_y, w_y, g, workspace, exd, force_f32, s);
-    case 128: return launch_bwd<128>(x, x_scale, mx, y, y_scale, ny, inv_tau, lse_x, w_x, lse_y, w_y, g, workspace, exd, force_f32, s);
-    default: return launch_bwd<256>(x, x_scale, mx, y, y_scale, ny, inv_tau, lse_x, w_x, lse_y, w_y, g, workspace, exd, force_f32, s);
+    case 32: return launch_bwd<32>(x, x_scale, mx, y, y_scale, ny, inv_tau, lse_x, w_x, lse_y, w_y, g, workspace, exd, force_f32, unit, s);
+    case 64: return launch_bwd<64>(x, x_scale, mx, y, y_scale, ny, inv_tau, lse_x, w_x, lse_y, w_y, g, workspace, exd, force_f32, unit, s);
+    case 128: return launch_bwd<128>(x, x_scale, mx, y, y_scale, ny, inv_tau, lse_x, w_x, lse_y, w_y, g, workspace, exd, force_f32, unit, s);
+    default: return launch_bwd<256>(x, x_scale, mx, y, y_scale, ny, inv_tau, lse_x, w_x, lse_y, w_y, g, workspace, exd, force_f32, unit, s);
   }
 }
 

@@ -471,18 +471,23 @@ def row_inv_norm(x, eps=1e-12):
 
 
 INFONCE_EXCLUDE_DIAGONAL = 1
+INFONCE_UNIT_ROWS = 2
 INFONCE_ENGINE_F32 = 4
 
-# "auto": the library default (split-operand bf16 engine for d <= 128, f32 MFMA for d = 256); "f32": force
-# the f32 MFMA.  Read ONCE per forward (`_resolve_engine`); the backward reuses what the forward ran on.
+# "auto": the library default — split-operand engine for d <= 128 (its two-product launches on two f16 planes when
+# the rows are normalised by the op itself, d <= 64: the GCR_INFONCE_UNIT_ROWS promise), f32 MFMA for d = 256;
+# "b3": withhold the unit-rows promise (three bf16 planes everywhere); "f32": force the f32 MFMA.
+# Read ONCE per forward (`_resolve_engine`); the backward reuses what the forward ran on.
 INFONCE_ENGINE = "auto"
 
 
-def _resolve_engine(engine=None):
+def _resolve_engine(engine=None, unit_rows=False):
     e = INFONCE_ENGINE if engine is None else engine
-    if e not in ("auto", "f32"):
-        raise ValueError("InfoNCE engine must be 'auto' or 'f32'")
-    return INFONCE_ENGINE_F32 if e == "f32" else 0
+    if e not in ("auto", "b3", "f32"):
+        raise ValueError("InfoNCE engine must be 'auto', 'b3' or 'f32'")
+    if e == "f32":
+        return INFONCE_ENGINE_F32
+    return INFONCE_UNIT_ROWS if (unit_rows and e == "auto") else 0
 
 
 def infonce_lse_raw(a, a_scale, b, b_scale, inv_tau, col_bound=None, exclude_diagonal=False, engine_flag=None):
@@ -575,8 +580,8 @@ class _InfoNCEStats(torch.autograd.Function):
         # is also the path for un-normalised inputs — and for the split-operand engine, whose MFMA
         # work is cheap enough that the second pass costs no more than the column-sum epilogue
         # (11.6 vs 11.6 ms at 100K x 100K, 0.49 vs 0.65 ms at 20K x 20K; scripts/perf_infonce_sym.py)
-        eng = _resolve_engine()                  # once per problem: the backward runs on the same engine
-        on_f32 = eng == INFONCE_ENGINE_F32 or _lib.lib().gcr_infonce_engine(a_p.shape[1]) == 0
+        eng = _resolve_engine(unit_rows=normalize)   # once per problem: the backward runs on the same engine
+        on_f32 = bool(eng & INFONCE_ENGINE_F32) or _lib.lib().gcr_infonce_engine(a_p.shape[1]) == 0
         one_pass = want_col and normalize and inv_tau <= 40.0 and not COL_DETERMINISTIC and not exd and on_f32
         o = None
         if FWD_O and not want_col and grad_a and a_p.shape[0] > 0 and \

@@ -33,9 +33,10 @@ for (m, n, d) in shapes:
     sa, sb = Fn.row_inv_norm(a), Fn.row_inv_norm(b)
     lse = Fn.infonce_lse_raw(a, sa, b, sb, 10.0)
     w = torch.ones(m, device="cuda")
-    t_f = ms(lambda: Fn.infonce_lse_raw(a, sa, b, sb, 10.0))
-    t_o = ms(lambda: Fn.infonce_fwd_o_raw(a, sa, b, sb, 10.0))
-    t_b = ms(lambda: Fn._infonce_bwd_raw(b, sb, a, sa, 10.0, None, None, lse, w))
+    ef = Fn._resolve_engine(unit_rows=True) if "--b3" not in sys.argv else 0     # rows normalised by sa / sb
+    t_f = ms(lambda: Fn.infonce_lse_raw(a, sa, b, sb, 10.0, engine_flag=ef))
+    t_o = ms(lambda: Fn.infonce_fwd_o_raw(a, sa, b, sb, 10.0, engine_flag=ef))
+    t_b = ms(lambda: Fn._infonce_bwd_raw(b, sb, a, sa, 10.0, None, None, lse, w, engine_flag=ef))
     fl = 2.0 * m * n * d / 1e9
     print(f"M={m} N={n} d={d}: fwd {t_f:.3f} ms ({fl / t_f:.0f} TF)  fwd_o {t_o:.3f} ms ({2 * fl / t_o:.0f} TF)  "
           f"bwd(table) {t_b:.3f} ms ({2 * fl / t_b:.0f} TF)", flush=True)

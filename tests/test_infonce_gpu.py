@@ -16,12 +16,14 @@ def Fn():
     return functional
 
 
-@pytest.fixture(autouse=True, params=["b3", "f32"])
+@pytest.fixture(autouse=True, params=["auto", "b3", "f32"])
 def engine(request, monkeypatch, Fn):
-    """Every test of this module runs on both MFMA engines (csrc/gcr_infonce.hip): the split-operand bf16
-    engine (d <= 128, the default) and the f32 MFMA engine (GCR_INFONCE_ENGINE_F32, chosen by the host once
-    per forward and handed to the backward), with the same tolerances."""
-    monkeypatch.setattr(Fn, "INFONCE_ENGINE", "f32" if request.param == "f32" else "auto")
+    """Every test of this module runs three ways (csrc/gcr_infonce.hip), with the same tolerances: "auto", the
+    library default (split-operand engine for d <= 128; its two-product launches on two f16 planes when the op
+    normalises the rows itself and d <= 64 — the GCR_INFONCE_UNIT_ROWS promise); "b3", the promise withheld (three
+    bf16 planes everywhere); "f32", the f32 MFMA engine (GCR_INFONCE_ENGINE_F32).  The host resolves the flags once
+    per forward and hands them to the backward."""
+    monkeypatch.setattr(Fn, "INFONCE_ENGINE", request.param)
     return request.param
 
 
@@ -308,9 +310,10 @@ def test_flash_forward_lse_and_weighted_row_sum(Fn, engine, m, n, d, exd):
     """gcr_infonce_fwd_o_f32: lse and o[i] = sum_j softmax_ij bhat_j from one pass (online max with deferred
     rescale, per-split partials merged) against float64; the anchor-side gradient of a row-softmax loss is
     dL/dlse * inv_tau * o."""
-    if engine != "b3":
+    if engine == "f32":
         assert not Fn.infonce_fwd_o_supported(d, Fn.INFONCE_ENGINE_F32)
         pytest.skip("split-operand engine only; the f32 engine keeps the two-launch backward")
+    ef = Fn._resolve_engine(unit_rows=True)       # rows normalised by the scales: "auto" may use the f16 planes
     rng = np.random.default_rng(m * 7 + n)
     a = (rng.standard_normal((m, d)) * 0.4).astype(np.float32)
     b = (rng.standard_normal((n, d)) * 0.4).astype(np.float32)
@@ -319,7 +322,7 @@ def test_flash_forward_lse_and_weighted_row_sum(Fn, engine, m, n, d, exd):
     at, bt = _t(a), _t(b)
     sa, sb = Fn.row_inv_norm(at), Fn.row_inv_norm(bt)
     inv_tau = 10.0
-    lse, o = Fn.infonce_fwd_o_raw(at, sa, bt, sb, inv_tau, exclude_diagonal=exd)
+    lse, o = Fn.infonce_fwd_o_raw(at, sa, bt, sb, inv_tau, exclude_diagonal=exd, engine_flag=ef)
     an = a.astype(np.float64) / np.linalg.norm(a.astype(np.float64), axis=1, keepdims=True)
     bn = b.astype(np.float64) / np.linalg.norm(b.astype(np.float64), axis=1, keepdims=True)
     s = inv_tau * an @ bn.T
@@ -366,8 +369,9 @@ def test_two_product_loop_random_shapes(Fn, engine):
     """The cross-tile pipelined loop (prologue of two tiles, steps in pairs, a peeled last step, a ring of three LDS
     images) over 48 random (M, N, d, 1/tau) incl. tile counts 1..6 per split and ragged last tiles: flash forward
     (lse, o) and the table-side / anchor-side backward against float64."""
-    if engine != "b3":
+    if engine == "f32":
         pytest.skip("the pipelined loop is the split-operand engine's")
+    ef = Fn._resolve_engine(unit_rows=True)
     rng = np.random.default_rng(2024)
     for case in range(48):
         d = int(rng.choice([32, 64]))
@@ -378,7 +382,7 @@ def test_two_product_loop_random_shapes(Fn, engine):
         b = (rng.standard_normal((n, d)) * rng.uniform(0.1, 2.0)).astype(np.float32)
         at, bt = _t(a), _t(b)
         sa, sb = Fn.row_inv_norm(at), Fn.row_inv_norm(bt)
-        lse, o = Fn.infonce_fwd_o_raw(at, sa, bt, sb, inv_tau)
+        lse, o = Fn.infonce_fwd_o_raw(at, sa, bt, sb, inv_tau, engine_flag=ef)
         an = a.astype(np.float64) / np.linalg.norm(a.astype(np.float64), axis=1, keepdims=True)
         bn = b.astype(np.float64) / np.linalg.norm(b.astype(np.float64), axis=1, keepdims=True)
         s = inv_tau * an @ bn.T
@@ -394,9 +398,9 @@ def test_two_product_loop_random_shapes(Fn, engine):
         # and rows of a stationary with their own statistics
         w = rng.standard_normal(m).astype(np.float32)
         wt = _t(w)
-        gb = Fn._infonce_bwd_raw(bt, sb, at, sa, inv_tau, None, None, lse, wt).cpu().numpy()
+        gb = Fn._infonce_bwd_raw(bt, sb, at, sa, inv_tau, None, None, lse, wt, engine_flag=ef).cpu().numpy()
         ref_gb = inv_tau * (sm * w[:, None].astype(np.float64)).T @ an
         assert np.abs(gb - ref_gb).max() <= 2e-5 * max(np.abs(ref_gb).max(), 1e-6), tag
-        ga = Fn._infonce_bwd_raw(at, sa, bt, sb, inv_tau, lse, wt, None, None).cpu().numpy()
+        ga = Fn._infonce_bwd_raw(at, sa, bt, sb, inv_tau, lse, wt, None, None, engine_flag=ef).cpu().numpy()
         ref_ga = inv_tau * (sm * w[:, None].astype(np.float64)) @ bn
         assert np.abs(ga - ref_ga).max() <= 2e-5 * max(np.abs(ref_ga).max(), 1e-6), tag

@@ -62,14 +62,14 @@ def test_neighbor_discrimination_matches_dense(b, k, d):
         np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=1e-5 * np.abs(want).max())
 
 
-@pytest.mark.parametrize("engine", ["b3", "f32"])
+@pytest.mark.parametrize("engine", ["auto", "b3", "f32"])
 @pytest.mark.parametrize("m", [7, 257])
 def test_grace_dual_branch_infonce_matches_reference(golden, monkeypatch, engine, m):
     """losses.grace_infonce_loss against the reference's own DualBranchContrast outputs (values and both
     gradients), all three mask variants, both MFMA engines."""
     from recommendation_amd.losses import grace_infonce_loss
     from recommendation_amd import functional as _Fn
-    monkeypatch.setattr(_Fn, "INFONCE_ENGINE", "f32" if engine == "f32" else "auto")
+    monkeypatch.setattr(_Fn, "INFONCE_ENGINE", engine)
     g = golden("grace.npz")
     for tau in (0.2, 0.5):
         for intra, keep in ((0, 0), (1, 0), (1, 1)):
@@ -83,14 +83,14 @@ def test_grace_dual_branch_infonce_matches_reference(golden, monkeypatch, engine
                 np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=1e-5 * np.abs(want).max() + 1e-9)
 
 
-@pytest.mark.parametrize("engine", ["b3", "f32"])
+@pytest.mark.parametrize("engine", ["auto", "b3", "f32"])
 @pytest.mark.parametrize("m,d", [(1, 64), (31, 64), (33, 64), (64, 64), (65, 32), (129, 64), (300, 128), (1000, 64), (2100, 64)])
 def test_exclude_diagonal_lse_and_grads(monkeypatch, engine, m, d):
     """GCR_INFONCE_EXCLUDE_DIAGONAL on square self-similarity problems across tile boundaries: row LSE
     over j != i and its gradient against dense float64 torch."""
     from recommendation_amd import functional as Fn
     from recommendation_amd import functional as _Fn
-    monkeypatch.setattr(_Fn, "INFONCE_ENGINE", "f32" if engine == "f32" else "auto")
+    monkeypatch.setattr(_Fn, "INFONCE_ENGINE", engine)
     rng = np.random.default_rng(m + d)
     x = (rng.standard_normal((m, d)) * 0.5).astype(np.float32)
     w = rng.standard_normal(m)

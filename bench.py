@@ -252,20 +252,21 @@ def infonce_roofline(Fn, x0, n_u, dev):
         0.1 * torch.randn(m, d, device=dev, generator=gen) * table.std()
     sa, sb = Fn.row_inv_norm(anchors), Fn.row_inv_norm(table)
     inv_tau = 10.0
-    lse = Fn.infonce_lse_raw(anchors, sa, table, sb, inv_tau)
+    # the rows are normalised by sa / sb, as in every contrast loss of the reference: the launches carry the
+    # unit-rows promise and (d <= 64) run on two f16 planes per operand, THREE 16-bit MFMA products per f32 product
+    # instead of the six of the three-bf16-plane format
+    ef = Fn._resolve_engine(unit_rows=True)
+    lse = Fn.infonce_lse_raw(anchors, sa, table, sb, inv_tau, engine_flag=ef)
     w = torch.ones(m, device=dev)
-    t_f = _event_ms(lambda: Fn.infonce_lse_raw(anchors, sa, table, sb, inv_tau), 10)
+    t_f = _event_ms(lambda: Fn.infonce_lse_raw(anchors, sa, table, sb, inv_tau, engine_flag=ef), 10)
     flops = 2.0 * m * n_u * d
     from recommendation_amd import _lib
     engine = int(_lib.lib().gcr_infonce_engine(d))
-    mult = 6 if engine == 1 else 1                       # bf16 split: six bf16 MFMA products per f32 product
+    h2 = engine == 1 and d <= 64 and bool(ef & Fn.INFONCE_UNIT_ROWS) and inv_tau <= 64.0
+    mult = 3 if h2 else (6 if engine == 1 else 1)        # 16-bit MFMA products per f32 product
     peak = BF16_MFMA_PEAK_TF if engine == 1 else FP32_MFMA_PEAK_TF
-
-    # the two-product launches take the caller's unit-rows promise (rows normalised by sa / sb, as every contrast
-    # loss does): two f16 planes per operand, THREE 16-bit MFMA products per f32 product instead of six
-    ef = Fn._resolve_engine(unit_rows=True)
-    mult2 = 3 if (engine == 1 and d <= 64 and ef & Fn.INFONCE_UNIT_ROWS) else mult
-    planes = "EngH2: 2 f16 planes, 3 products per f32 product" if mult2 == 3 else "EngB3: 3 bf16 planes, 6 products"
+    mult2 = mult
+    planes = "EngH2: 2 f16 planes, 3 products per f32 product" if h2 else "EngB3: 3 bf16 planes, 6 products"
 
     def leg(kernel, t_ms, units):
         return {"kernel": kernel, "avg_launch_ms": round(t_ms, 4), "flops_alg_per_launch": units * flops,
@@ -282,9 +283,10 @@ def infonce_roofline(Fn, x0, n_u, dev):
         fwd_o = leg(f"infonce_pipe_kernel<{planes.split(':')[0]}, 64, MODE 1> (score + softmax-weighted row sum; {planes})",
                     t_fo, 2)
     out = {
-        "bound": "mfma", "kernel": "infonce_fwd_b3_kernel<64>" if engine == 1 else "infonce_fwd_kernel<64>",
-        "engine": "split-operand bf16 MFMA (3 planes per f32 operand, 6 products per f32 product, f32 accumulate)"
-                  if engine == 1 else "f32 MFMA",
+        "bound": "mfma",
+        "kernel": f"infonce_fwd_e_kernel<{planes.split(':')[0]}, 64>" if engine == 1 else "infonce_fwd_kernel<64>",
+        "engine": ("split-operand 16-bit MFMA, f32 accumulate (" + planes + ")") if engine == 1 else "f32 MFMA",
+        "mfma_products_per_f32_product": mult,
         "shape": f"{m} x {n_u} x {d}", "pairs_per_launch": m * n_u, "flops_alg_per_launch": flops,
         "avg_launch_ms": round(t_f, 4), "pairs_per_s": m * n_u / t_f * 1e3,
         "achieved_alg": round(flops / t_f / 1e9, 1), "achieved": round(mult * flops / t_f / 1e9, 1),
@@ -739,11 +741,12 @@ def bench_extra(ra, Fn, graph, x0, k_layers, nnz, dev, n_u, n_i):
         "shapes": f"{bsz} x {n_u} + {bsz} x {n_i} + 2 x {bsz} x {bsz}, d={d}",
         "pairs_per_s_fwd": pairs / t_f, "fwd_ms": 1e3 * t_f, "fwd_tflops": 2 * pairs * d / t_f / 1e12,
         "pairs_per_s_fwd_bwd": pairs / t_fb, "fwd_bwd_ms": 1e3 * t_fb,
-        "engine": "split-operand bf16 MFMA (3 planes per f32 operand, 6 terms per product, f32 accumulate)",
-        "fwd_mfma_issued_tflops": round(6 * 2 * pairs * d / t_f / 1e12, 1),
-        "fwd_frac_of_bf16_mfma_peak": round(6 * 2 * pairs * d / t_f / 1e12 / BF16_MFMA_PEAK_TF, 4),
+        "engine": "split-operand 16-bit MFMA, f32 accumulate: two f16 planes / 3 terms per product (rows normalised by "
+                  "the loss, d <= 64); three bf16 planes / 6 terms otherwise",
+        "fwd_mfma_issued_tflops": round(3 * 2 * pairs * d / t_f / 1e12, 1),
+        "fwd_frac_of_bf16_mfma_peak": round(3 * 2 * pairs * d / t_f / 1e12 / BF16_MFMA_PEAK_TF, 4),
         "note": "fwd includes gathers, row norms, positive logits and the loss reductions; fwd_tflops counts the "
-                "algorithmic 2*M*N*d, the engine issues 6x that on the bf16 MFMA"}
+                "algorithmic 2*M*N*d, the engine issues 3x that on the f16 MFMA"}
     del xi, xc, ctx
 
     # BPR + sampler (B = 2048 as ncl.py:293; and lightgcn.py's full batch B = E)

@@ -50,7 +50,8 @@ __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >
 // clamped to the last row and multiplied by 0.
 template <int D>
 __device__ __forceinline__ void stage_load(const float* __restrict__ b, const float* __restrict__ b_scale,
-                                           int64_t n_rows, int64_t j0, int tid, float4 (&regs)[Shape<D>::NLD]) {
+                                           int64_t n_rows, int64_t j0, int tid, float4 (&regs)[Shape<D>::NLD],
+                                           float mult = 1.0f) {
 #pragma unroll
   for (int u = 0; u < Shape<D>::NLD; ++u) {
     const int idx = tid + 256 * u;
@@ -58,7 +59,7 @@ __device__ __forceinline__ void stage_load(const float* __restrict__ b, const fl
     const int64_t j = j0 + row;
     const int64_t jj = j < n_rows ? j : n_rows - 1;
     float4 v = *reinterpret_cast<const float4*>(b + jj * D + 4 * c4);
-    float s = b_scale != nullptr ? b_scale[jj] : 1.0f;
+    float s = b_scale != nullptr ? b_scale[jj] * mult : mult;
     s = j < n_rows ? s : 0.f;
     v.x *= s; v.y *= s; v.z *= s; v.w *= s;
     regs[u] = v;
@@ -257,8 +258,133 @@ __global__ __launch_bounds__(256, (D <= 64 ? 3 : 2)) void infonce_fwd_kernel(con
 
 #include "gcr_b3.h"  // (included inside the anonymous namespace: split-operand helpers shared with gcr_rank.hip)
 
-template <int D, bool COLSUM, bool EXD = false>
-__global__ __launch_bounds__(256, 2) void infonce_fwd_b3_kernel(const float* __restrict__ a,
+// deferred rescale of the flash forwards: the reference point of a row's running sums only moves when a tile's
+// maximum exceeds it by more than 2^kDefer
+constexpr float kDefer = 8.0f;
+
+// ------------------------------------------------------------------------------------------
+// The two operand formats of the split-operand kernels (forward, and the pipelined two-product loop).
+//   EngB3  three bf16 planes, six product terms (gcr_b3.h): any finite f32 operand, f32 accuracy.
+//   EngH2  two f16 planes, THREE product terms: x = hi + lo with hi = f16(x), lo = f16(x - hi) (RNE,
+//          v_cvt_pk_f16_f32) leaves <= 2^-22 |x|; hi*hi + hi*lo + lo*hi drops lo*lo (2^-22): half the matrix-core work of
+//          EngB3 at an error of a few f32 roundings per product.  f16 has a 5-bit exponent, so the format is only used for
+//          operands whose range is known — rows of at most unit norm (the caller's promise GCR_INFONCE_UNIT_ROWS; every
+//          contrast loss of the reference normalises) and probabilities — each pre-scaled by a power of two that puts its
+//          largest value just under 2^15..2^16:
+//            stationary rows (<= inv_tau log2 e, inv_tau <= kH2MaxInvTau)   x 2^4      (|.| <= 1478)
+//            streamed rows   (<= 1)                                          x 2^8
+//            scores                                                          accumulator x 2^-12 (folded into the FMA in
+//                                                                            front of exp2)
+//            P, MODE 1 (<= 2^kDefer = 2 relative to the lagging reference)   x 2^14
+//            P, MODE 0 (w e^{s - lse} <= 2 max|w|)                           x 2^14 / 2^ceil(log2 max|w|) (max|w| from a
+//                                                                            one-block pre-pass, h2_wscale_kernel)
+//          Values below the f16 normal range (2^-14 after scaling: a row element under 2^-22, a probability 2^-28 under
+//          the reference) go sub-normal, which v_cvt_pk_f16_f32 produces and v_mfma_f32_32x32x16_f16 honours
+//          (scripts/exp/f16_denorm_probe.hip, run on the box): their absolute error stays <= 2^-25 of the scaled unit.
+// ------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+struct EngB3 {
+  static constexpr int NPL = 3, NTERM = 6;
+  static constexpr int kMinBlocks = 2;
+  static constexpr float kSX = 1.0f, kSY = 1.0f;         // operand pre-scales
+  static constexpr float kSInv = 1.0f;                   // accumulator -> log2-domain score
+  static constexpr float kPExp = 0.0f;                   // log2 of the scale of P
+  static constexpr float kDeferE = kDefer;
+  static __host__ __device__ constexpr int ta(int t) { constexpr int v[6] = {2, 0, 1, 1, 0, 0}; return v[t]; }   // streamed-side
+  static __host__ __device__ constexpr int tb(int t) { constexpr int v[6] = {0, 2, 1, 0, 1, 0}; return v[t]; }   // plane / other
+  static __device__ __forceinline__ void split(float a, float b, unsigned (&p)[3]) { split3(a, b, p[0], p[1], p[2]); }
+  static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) { return mfma_bf16(a, b, c); }
+};
+
+struct EngH2 {
+  static constexpr int NPL = 2, NTERM = 3;
+  static constexpr int kMinBlocks = 2;          // 3 would cap the kernel at 168 VGPRs: 11-52 spilled dwords, 4-12 % slower
+  static constexpr float kSX = 16.0f, kSY = 256.0f;
+  static constexpr float kSInv = 1.0f / 4096.0f;
+  static constexpr float kPExp = 14.0f;
+  static constexpr float kDeferE = 1.0f;
+  static __host__ __device__ constexpr int ta(int t) { constexpr int v[3] = {1, 0, 0}; return v[t]; }
+  static __host__ __device__ constexpr int tb(int t) { constexpr int v[3] = {0, 1, 0}; return v[t]; }
+  static __device__ __forceinline__ void split(float a, float b, unsigned (&p)[2]) {
+    const f16x2 hi = __builtin_convertvector((f32x2){a, b}, f16x2);                 // v_cvt_pk_f16_f32, RNE
+    p[0] = __builtin_bit_cast(unsigned, hi);
+    p[1] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a - (float)hi[0], b - (float)hi[1]}, f16x2));
+  }
+  static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+
+// stationary operand planes of engine E: frag[p][c] = 8 consecutive features [h*KH + 8c, +8) of plane p
+template <class E, int D>
+__device__ __forceinline__ void load_stationary_e(const float* __restrict__ a, const float* __restrict__ a_scale,
+                                                  int64_t m_rows, int64_t row, int h, float mult,
+                                                  u32x4 (&frag)[E::NPL][ShapeB3<D>::KC]) {
+  using S = ShapeB3<D>;
+  const bool valid = row < m_rows;
+  const float s = valid ? (a_scale != nullptr ? a_scale[row] : 1.0f) * mult : 0.f;
+  const float* p = a + (valid ? row : 0) * D + h * S::KH;
+#pragma unroll
+  for (int c = 0; c < S::KC; ++c) {
+    const float4 v0 = valid ? *reinterpret_cast<const float4*>(p + 8 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 v1 = valid ? *reinterpret_cast<const float4*>(p + 8 * c + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned q[4][E::NPL];
+    E::split(v0.x * s, v0.y * s, q[0]);
+    E::split(v0.z * s, v0.w * s, q[1]);
+    E::split(v1.x * s, v1.y * s, q[2]);
+    E::split(v1.z * s, v1.w * s, q[3]);
+#pragma unroll
+    for (int pl = 0; pl < E::NPL; ++pl) frag[pl][c] = (u32x4){q[0][pl], q[1][pl], q[2][pl], q[3][pl]};
+  }
+}
+
+// one staged float4 of the streamed tile -> NPL row-major planes in LDS
+template <class E, int D>
+__device__ __forceinline__ void stage_store_e_one(unsigned char* __restrict__ tile, int tid, const float4& v, int u) {
+  using S = ShapeB3<D>;
+  const int idx = tid + 256 * u;
+  const int row = idx / (D / 4), c4 = idx % (D / 4);
+  unsigned qa[E::NPL], qb[E::NPL];
+  E::split(v.x, v.y, qa);
+  E::split(v.z, v.w, qb);
+  unsigned char* p = tile + row * S::ROWB + c4 * 8;
+#pragma unroll
+  for (int pl = 0; pl < E::NPL; ++pl) *reinterpret_cast<uint2*>(p + pl * S::PLANE) = make_uint2(qa[pl], qb[pl]);
+}
+
+template <class E, int D>
+__device__ __forceinline__ void stage_store_e(unsigned char* __restrict__ tile, int tid,
+                                              const float4 (&regs)[ShapeB3<D>::NLD]) {
+#pragma unroll
+  for (int u = 0; u < ShapeB3<D>::NLD; ++u) stage_store_e_one<E, D>(tile, tid, regs[u], u);
+}
+
+// S^T tile (streamed rows x stationary rows), NTERM products per k-chunk, smallest terms first
+template <class E, int D, int NT>
+__device__ __forceinline__ void score_tile_e(const unsigned char* __restrict__ tile, int i32, int h,
+                                             const u32x4 (&bq)[NT][E::NPL][ShapeB3<D>::KC], f32x16 (&acc)[NT]) {
+  using S = ShapeB3<D>;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const unsigned char* base = tile + i32 * S::ROWB + h * (S::KH * 2);
+#pragma unroll
+  for (int c = 0; c < S::KC; ++c) {
+    u32x4 ap[E::NPL];
+#pragma unroll
+    for (int pl = 0; pl < E::NPL; ++pl) ap[pl] = *reinterpret_cast<const u32x4*>(base + pl * S::PLANE + 16 * c);
+#pragma unroll
+    for (int term = 0; term < E::NTERM; ++term)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = E::mfma(ap[E::ta(term)], bq[t][E::tb(term)][c], acc[t]);
+  }
+}
+
+
+template <class E, int D, bool COLSUM, bool EXD = false>
+__global__ __launch_bounds__(256, 2) void infonce_fwd_e_kernel(const float* __restrict__ a,
                                                                 const float* __restrict__ a_scale, int64_t m_rows,
                                                                 const float* __restrict__ b,
                                                                 const float* __restrict__ b_scale, int64_t n_rows,
@@ -266,16 +392,18 @@ __global__ __launch_bounds__(256, 2) void infonce_fwd_b3_kernel(const float* __r
                                                                 float2* __restrict__ part, float* __restrict__ col_sum,
                                                                 float col_bound2) {
   using S = ShapeB3<D>;
-  __shared__ __align__(16) unsigned char lds[2][3 * S::PLANE];
+  constexpr int NPL = E::NPL, NTERM = E::NTERM;
+  __shared__ __align__(16) unsigned char lds[2][NPL * S::PLANE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i32 = lane & 31, h = lane >> 5;
   const int64_t mblk = blockIdx.x / nsplit;
   const int split = blockIdx.x % nsplit;
   const int64_t i0 = (mblk * 4 + wave) * (32 * S::NT);
 
-  u32x4 bq[S::NT][3][S::KC];
+  u32x4 bq[S::NT][NPL][S::KC];
 #pragma unroll
-  for (int t = 0; t < S::NT; ++t) load_stationary_b3<D>(a, a_scale, m_rows, i0 + 32 * t + i32, h, scale2, bq[t]);
+  for (int t = 0; t < S::NT; ++t)
+    load_stationary_e<E, D>(a, a_scale, m_rows, i0 + 32 * t + i32, h, scale2 * E::kSX, bq[t]);
 
   float m_run[S::NT], l_run[S::NT], a_valid[S::NT];
 #pragma unroll
@@ -295,14 +423,20 @@ __global__ __launch_bounds__(256, 2) void infonce_fwd_b3_kernel(const float* __r
     for (int r = 0; r < 16; ++r) {
       float e = 0.f;
 #pragma unroll
-      for (int t = 0; t < S::NT; ++t) e += a_valid[t] * __builtin_amdgcn_exp2f(acc[t][r] - col_bound2);
+      for (int t = 0; t < S::NT; ++t) e += a_valid[t] * __builtin_amdgcn_exp2f(acc[t][r] - col_bound2);   // acc already scaled
       e = half_wave_sum_to_last_lane(e);
       const int64_t j = j0 + acc_row(r, h);
       if (i32 == 31 && j < n_rows) atomicAdd(col_sum + j, e);
     }
   };
   // the table's last tile is the only one that can be ragged
-  auto epilogue_any = [&](const f32x16 (&acc)[S::NT], int64_t tt) {
+  auto epilogue_any = [&](f32x16 (&acc)[S::NT], int64_t tt) {
+    if (E::kSInv != 1.0f) {                               // accumulator -> log2-domain scores
+#pragma unroll
+      for (int t = 0; t < S::NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] *= E::kSInv;
+    }
     if (EXD) {
       int xr[S::NT];
 #pragma unroll
@@ -323,21 +457,19 @@ __global__ __launch_bounds__(256, 2) void infonce_fwd_b3_kernel(const float* __r
     // sched_barrier.  A wave issues in order, so this is what lets ONE wave keep the matrix pipe busy
     // under its own exp2 / max / add stream (two waves of a SIMD otherwise fall into lock-step and
     // serialise: measured 48 % MFMA utilisation before, scripts/perf_infonce_engine_ab.py).
-    constexpr int NS = 6 * S::KC * S::NT;                         // MFMA slots per step
+    constexpr int NS = NTERM * S::KC * S::NT;                     // MFMA slots per step
     constexpr int NU = 22 * S::NT + S::NLD + (COLSUM ? 16 : 0);   // VALU micro-units per step
-    constexpr int TA[6] = {2, 0, 1, 1, 0, 0};                     // table plane / anchor plane of the six terms,
-    constexpr int TB[6] = {0, 2, 1, 0, 1, 0};                     // smallest products first
     const int64_t last = tile1 - 1;
     f32x16 acc_a[S::NT], acc_b[S::NT];
-    stage_load<D>(b, b_scale, n_rows, tile0 * kTileJ, tid, regs);
-    stage_store_b3<D>(lds[0], tid, regs);
-    stage_load<D>(b, b_scale, n_rows, min(tile0 + 1, last) * kTileJ, tid, regs);
+    stage_load<D>(b, b_scale, n_rows, tile0 * kTileJ, tid, regs, E::kSY);
+    stage_store_e<E, D>(lds[0], tid, regs);
+    stage_load<D>(b, b_scale, n_rows, min(tile0 + 1, last) * kTileJ, tid, regs, E::kSY);
     __syncthreads();
-    score_tile_b3<D, S::NT>(lds[0], i32, h, bq, acc_a);
-    stage_store_b3<D>(lds[1], tid, regs);
+    score_tile_e<E, D, S::NT>(lds[0], i32, h, bq, acc_a);
+    stage_store_e<E, D>(lds[1], tid, regs);
     __syncthreads();
     auto step = [&](f32x16 (&cur)[S::NT], f32x16 (&nxt)[S::NT], int64_t tt, int nb) {
-      stage_load<D>(b, b_scale, n_rows, min(tt + 2, last) * kTileJ, tid, regs);
+      stage_load<D>(b, b_scale, n_rows, min(tt + 2, last) * kTileJ, tid, regs, E::kSY);
       const unsigned char* base = lds[nb] + i32 * S::ROWB + h * (S::KH * 2);
       unsigned char* out = lds[nb ^ 1];
       float tmax[S::NT], m_new[S::NT], sum[S::NT];
@@ -356,13 +488,13 @@ __global__ __launch_bounds__(256, 2) void infonce_fwd_b3_kernel(const float* __r
             const int r = m - 22 * S::NT - S::NLD;
             float e = 0.f;
 #pragma unroll
-            for (int q = 0; q < S::NT; ++q) e += a_valid[q] * __builtin_amdgcn_exp2f(cur[q][r] - col_bound2);
+            for (int q = 0; q < S::NT; ++q) e += a_valid[q] * __builtin_amdgcn_exp2f(fmaf(cur[q][r], E::kSInv, -col_bound2));
             e = half_wave_sum_to_last_lane(e);
             const int64_t j = tt * kTileJ + acc_row(r, h);
             if (i32 == 31 && j < n_rows) atomicAdd(col_sum + j, e);
           }
         } else if (m >= 22 * S::NT) {
-          stage_store_b3_one<D>(out, tid, regs[m - 22 * S::NT], m - 22 * S::NT);
+          stage_store_e_one<E, D>(out, tid, regs[m - 22 * S::NT], m - 22 * S::NT);
         } else if (u < 4) {
           if (EXD) {                                    // excluded diagonal pair: -inf before it is seen by max / exp2
 #pragma unroll
@@ -371,36 +503,36 @@ __global__ __launch_bounds__(256, 2) void infonce_fwd_b3_kernel(const float* __r
           const float x = fmaxf(fmaxf(cur[t][4 * u], cur[t][4 * u + 1]), fmaxf(cur[t][4 * u + 2], cur[t][4 * u + 3]));
           tmax[t] = u == 0 ? x : fmaxf(tmax[t], x);
         } else if (u == 4) {
-          m_new[t] = fmaxf(m_run[t], tmax[t]);
+          m_new[t] = fmaxf(m_run[t], tmax[t] * E::kSInv);
           sum[t] = 0.f;
         } else if (u < 21) {
-          sum[t] += __builtin_amdgcn_exp2f(cur[t][u - 5] - m_new[t]);
+          sum[t] += __builtin_amdgcn_exp2f(fmaf(cur[t][u - 5], E::kSInv, -m_new[t]));
         } else {
           l_run[t] = l_run[t] * __builtin_amdgcn_exp2f(m_run[t] - m_new[t]) + sum[t];
           m_run[t] = m_new[t];
         }
       };
-      u32x4 ap[2][3];
+      u32x4 ap[2][NPL];
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) ap[0][pl] = *reinterpret_cast<const u32x4*>(base + pl * S::PLANE);
+      for (int pl = 0; pl < NPL; ++pl) ap[0][pl] = *reinterpret_cast<const u32x4*>(base + pl * S::PLANE);
 #pragma unroll
       for (int c = 0; c < S::KC; ++c) {
         if (c + 1 < S::KC) {
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl)
+          for (int pl = 0; pl < NPL; ++pl)
             ap[(c + 1) & 1][pl] = *reinterpret_cast<const u32x4*>(base + pl * S::PLANE + 16 * (c + 1));
         }
 #pragma unroll
-        for (int term = 0; term < 6; ++term) {
+        for (int term = 0; term < NTERM; ++term) {
 #pragma unroll
           for (int t = 0; t < S::NT; ++t) {
-            const int slot = (c * 6 + term) * S::NT + t;
+            const int slot = (c * NTERM + term) * S::NT + t;
             f32x16 cin = nxt[t];
             if (c == 0 && term == 0) {
 #pragma unroll
               for (int r = 0; r < 16; ++r) cin[r] = 0.f;
             }
-            nxt[t] = mfma_bf16(ap[c & 1][TA[term]], bq[t][TB[term]][c], cin);
+            nxt[t] = E::mfma(ap[c & 1][E::ta(term)], bq[t][E::tb(term)][c], cin);
 #pragma unroll
             for (int u = slot * NU / NS; u < (slot + 1) * NU / NS; ++u) micro(u);
             __builtin_amdgcn_sched_barrier(0);
@@ -919,7 +1051,6 @@ __global__ __launch_bounds__(256, 2) void infonce_bwd_b3_kernel(
 // Rescaling the accumulators is deferred while no logit exceeds the reference point by more than
 // 2^kDefer (wave-uniform branch): after the first tiles it almost never runs.
 // ------------------------------------------------------------------------------------------
-constexpr float kDefer = 8.0f;
 
 template <int D, bool EXD = false>
 __global__ __launch_bounds__(256, 2) void infonce_fwdo_b3_kernel(
@@ -1075,81 +1206,6 @@ __device__ __forceinline__ uint2 lds_read_tr16(const unsigned char* p) {      //
   return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p));
 }
 
-// ------------------------------------------------------------------------------------------
-// The two operand formats of the pipelined loop.
-//   EngB3  three bf16 planes, six product terms (gcr_b3.h): any finite f32 operand, f32 accuracy.
-//   EngH2  two f16 planes, THREE product terms: x = hi + lo with hi = f16(x), lo = f16(x - hi) (RNE,
-//          v_cvt_pk_f16_f32) leaves <= 2^-22 |x|; hi*hi + hi*lo + lo*hi drops lo*lo (2^-22): half the matrix-core work of
-//          EngB3 at an error of a few f32 roundings per product.  f16 has a 5-bit exponent, so the format is only used for
-//          operands whose range is known — rows of at most unit norm (the caller's promise GCR_INFONCE_UNIT_ROWS; every
-//          contrast loss of the reference normalises) and probabilities — each pre-scaled by a power of two that puts its
-//          largest value just under 2^15..2^16:
-//            stationary rows (<= inv_tau log2 e, inv_tau <= kH2MaxInvTau)   x 2^4      (|.| <= 1478)
-//            streamed rows   (<= 1)                                          x 2^8
-//            scores                                                          accumulator x 2^-12 (folded into the FMA in
-//                                                                            front of exp2)
-//            P, MODE 1 (<= 2^kDefer = 2 relative to the lagging reference)   x 2^14
-//            P, MODE 0 (w e^{s - lse} <= 2 max|w|)                           x 2^14 / 2^ceil(log2 max|w|) (max|w| from a
-//                                                                            one-block pre-pass, h2_wscale_kernel)
-//          Values below the f16 normal range (2^-14 after scaling: a row element under 2^-22, a probability 2^-28 under
-//          the reference) go sub-normal, which v_cvt_pk_f16_f32 produces and v_mfma_f32_32x32x16_f16 honours
-//          (scripts/exp/f16_denorm_probe.hip, run on the box): their absolute error stays <= 2^-25 of the scaled unit.
-// ------------------------------------------------------------------------------------------
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-struct EngB3 {
-  static constexpr int NPL = 3, NTERM = 6;
-  static constexpr float kSX = 1.0f, kSY = 1.0f;         // operand pre-scales
-  static constexpr float kSInv = 1.0f;                   // accumulator -> log2-domain score
-  static constexpr float kPExp = 0.0f;                   // log2 of the scale of P
-  static constexpr float kDeferE = kDefer;
-  static __host__ __device__ constexpr int ta(int t) { constexpr int v[6] = {2, 0, 1, 1, 0, 0}; return v[t]; }   // streamed-side
-  static __host__ __device__ constexpr int tb(int t) { constexpr int v[6] = {0, 2, 1, 0, 1, 0}; return v[t]; }   // plane / other
-  static __device__ __forceinline__ void split(float a, float b, unsigned (&p)[3]) { split3(a, b, p[0], p[1], p[2]); }
-  static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) { return mfma_bf16(a, b, c); }
-};
-
-struct EngH2 {
-  static constexpr int NPL = 2, NTERM = 3;
-  static constexpr float kSX = 16.0f, kSY = 256.0f;
-  static constexpr float kSInv = 1.0f / 4096.0f;
-  static constexpr float kPExp = 14.0f;
-  static constexpr float kDeferE = 1.0f;
-  static __host__ __device__ constexpr int ta(int t) { constexpr int v[3] = {1, 0, 0}; return v[t]; }
-  static __host__ __device__ constexpr int tb(int t) { constexpr int v[3] = {0, 1, 0}; return v[t]; }
-  static __device__ __forceinline__ void split(float a, float b, unsigned (&p)[2]) {
-    const f16x2 hi = __builtin_convertvector((f32x2){a, b}, f16x2);                 // v_cvt_pk_f16_f32, RNE
-    p[0] = __builtin_bit_cast(unsigned, hi);
-    p[1] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a - (float)hi[0], b - (float)hi[1]}, f16x2));
-  }
-  static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-  }
-};
-
-// stationary operand planes of engine E: frag[p][c] = 8 consecutive features [h*KH + 8c, +8) of plane p
-template <class E, int D>
-__device__ __forceinline__ void load_stationary_e(const float* __restrict__ a, const float* __restrict__ a_scale,
-                                                  int64_t m_rows, int64_t row, int h, float mult,
-                                                  u32x4 (&frag)[E::NPL][ShapeB3<D>::KC]) {
-  using S = ShapeB3<D>;
-  const bool valid = row < m_rows;
-  const float s = valid ? (a_scale != nullptr ? a_scale[row] : 1.0f) * mult : 0.f;
-  const float* p = a + (valid ? row : 0) * D + h * S::KH;
-#pragma unroll
-  for (int c = 0; c < S::KC; ++c) {
-    const float4 v0 = valid ? *reinterpret_cast<const float4*>(p + 8 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 v1 = valid ? *reinterpret_cast<const float4*>(p + 8 * c + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    unsigned q[4][E::NPL];
-    E::split(v0.x * s, v0.y * s, q[0]);
-    E::split(v0.z * s, v0.w * s, q[1]);
-    E::split(v1.x * s, v1.y * s, q[2]);
-    E::split(v1.z * s, v1.w * s, q[3]);
-#pragma unroll
-    for (int pl = 0; pl < E::NPL; ++pl) frag[pl][c] = (u32x4){q[0][pl], q[1][pl], q[2][pl], q[3][pl]};
-  }
-}
-
 // max |w| over both weight vectors -> hw[0] = 2^14 / 2^ceil(log2 max|w|) (what the weights are multiplied by before
 // they meet e^{s - lse} <= 1, so that P stays in f16 range), hw[1] = 1 / (hw[0] * 2^8) (undoes it, and the streamed
 // operand's 2^8, on the way out).  One block.
@@ -1176,7 +1232,7 @@ __global__ __launch_bounds__(1024) void h2_wscale_kernel(const float* __restrict
 }
 
 template <class E, int D, int MODE, bool EXD, int SIDES>
-__global__ __launch_bounds__(256, 2) void infonce_pipe_kernel(
+__global__ __launch_bounds__(256, E::kMinBlocks) void infonce_pipe_kernel(
     const float* __restrict__ x, const float* __restrict__ x_scale, int64_t mx, const float* __restrict__ y,
     const float* __restrict__ y_scale, int64_t ny, float scale2, float out_scale, const float* __restrict__ lse_x,
     const float* __restrict__ w_x, const float* __restrict__ lse_y, const float* __restrict__ w_y, int nsplit,
@@ -1647,7 +1703,7 @@ int anchors_per_block_for(int d) { return d <= 128 ? 256 : 128; }
 template <int D>
 int32_t launch_fwd(const float* a, const float* a_scale, int64_t m, const float* b, const float* b_scale, int64_t n,
                    float inv_tau, float* lse, float* col_sum, float col_bound, void* workspace, bool exd, bool force_f32,
-                   hipStream_t s) {
+                   bool unit_rows, hipStream_t s) {
   float2* part = reinterpret_cast<float2*>(workspace);
   if (col_sum != nullptr) {
     hipError_t err = hipMemsetAsync(col_sum, 0, sizeof(float) * (size_t)n, s);
@@ -1660,15 +1716,26 @@ int32_t launch_fwd(const float* a, const float* a_scale, int64_t m, const float*
       p = plan_fwd(m, n, ShapeB3<D>::ANCHORS_PER_BLOCK, 512);
       const dim3 grid((unsigned)(p.m_blocks * p.nsplit));
       const float cb2 = col_sum != nullptr ? col_bound * kLog2e : 0.f;
-      if (exd)
-        hipLaunchKernelGGL((infonce_fwd_b3_kernel<D, false, true>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale, n,
-                           inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part, col_sum, cb2);
-      else if (col_sum != nullptr)
-        hipLaunchKernelGGL((infonce_fwd_b3_kernel<D, true, false>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale, n,
-                           inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part, col_sum, cb2);
-      else
-        hipLaunchKernelGGL((infonce_fwd_b3_kernel<D, false, false>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale, n,
-                           inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part, col_sum, cb2);
+#define GCR_FWD_E(ENG)                                                                                                  \
+  if (exd)                                                                                                              \
+    hipLaunchKernelGGL((infonce_fwd_e_kernel<ENG, D, false, true>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale,   \
+                       n, inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part, col_sum, cb2);                           \
+  else if (col_sum != nullptr)                                                                                          \
+    hipLaunchKernelGGL((infonce_fwd_e_kernel<ENG, D, true, false>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale,   \
+                       n, inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part, col_sum, cb2);                           \
+  else                                                                                                                  \
+    hipLaunchKernelGGL((infonce_fwd_e_kernel<ENG, D, false, false>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale,  \
+                       n, inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part, col_sum, cb2)
+      if constexpr (D <= 64) {
+        if (use_h2(D, inv_tau, unit_rows, force_f32)) {
+          GCR_FWD_E(EngH2);
+        } else {
+          GCR_FWD_E(EngB3);
+        }
+      } else {
+        GCR_FWD_E(EngB3);
+      }
+#undef GCR_FWD_E
       launched = true;
     }
   }
@@ -2159,6 +2226,7 @@ extern "C" int32_t gcr_infonce_fwd_ex_f32(const float* a, const float* a_scale, 
   GCR_CHECK_ARG((flags & ~(uint32_t)(GCR_INFONCE_EXCLUDE_DIAGONAL | GCR_INFONCE_ENGINE_F32 | GCR_INFONCE_UNIT_ROWS)) == 0);
   const bool exd = (flags & GCR_INFONCE_EXCLUDE_DIAGONAL) != 0;
   const bool force_f32 = (flags & GCR_INFONCE_ENGINE_F32) != 0;
+  const bool unit = (flags & GCR_INFONCE_UNIT_ROWS) != 0;
   GCR_CHECK_ARG(!(exd && col_sum != nullptr));
   if (!dim_supported(d)) return GCR_EUNSUPPORTED;
   if (m == 0) return GCR_OK;
@@ -2166,10 +2234,10 @@ extern "C" int32_t gcr_infonce_fwd_ex_f32(const float* a, const float* a_scale, 
   GCR_CHECK_ARG(m < (1ll << 40) && n < (1ll << 40));
   hipStream_t s = (hipStream_t)stream;
   switch (d) {
-    case 32: return launch_fwd<32>(a, a_scale, m, b, b_scale, n, inv_tau, lse, col_sum, col_bound, workspace, exd, force_f32, s);
-    case 64: return launch_fwd<64>(a, a_scale, m, b, b_scale, n, inv_tau, lse, col_sum, col_bound, workspace, exd, force_f32, s);
-    case 128: return launch_fwd<128>(a, a_scale, m, b, b_scale, n, inv_tau, lse, col_sum, col_bound, workspace, exd, force_f32, s);
-    default: return launch_fwd<256>(a, a_scale, m, b, b_scale, n, inv_tau, lse, col_sum, col_bound, workspace, exd, force_f32, s);
+    case 32: return launch_fwd<32>(a, a_scale, m, b, b_scale, n, inv_tau, lse, col_sum, col_bound, workspace, exd, force_f32, unit, s);
+    case 64: return launch_fwd<64>(a, a_scale, m, b, b_scale, n, inv_tau, lse, col_sum, col_bound, workspace, exd, force_f32, unit, s);
+    case 128: return launch_fwd<128>(a, a_scale, m, b, b_scale, n, inv_tau, lse, col_sum, col_bound, workspace, exd, force_f32, unit, s);
+    default: return launch_fwd<256>(a, a_scale, m, b, b_scale, n, inv_tau, lse, col_sum, col_bound, workspace, exd, force_f32, unit, s);
   }
 }
 

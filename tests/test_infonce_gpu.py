@@ -31,7 +31,8 @@ def _lse(Fn, a, b, inv_tau, normalize):
     at, bt = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
     sa = Fn.row_inv_norm(at) if normalize else None
     sb = Fn.row_inv_norm(bt) if normalize else None
-    return Fn.infonce_lse_raw(Fn._pad_dim(at).contiguous(), sa, Fn._pad_dim(bt).contiguous(), sb, inv_tau).cpu().numpy()
+    return Fn.infonce_lse_raw(Fn._pad_dim(at).contiguous(), sa, Fn._pad_dim(bt).contiguous(), sb, inv_tau,
+                              engine_flag=Fn._resolve_engine(unit_rows=normalize)).cpu().numpy()
 
 
 @pytest.mark.parametrize("m,n,d", [(1, 1, 64), (7, 7, 64), (257, 257, 64), (64, 1000, 64), (300, 33, 64),
@@ -245,8 +246,9 @@ def test_one_pass_column_lse_matches_two_pass_and_oracle(Fn, m, n, d, temp):
     b = rng.standard_normal((n, d)).astype(np.float32)
     at, bt = Fn._pad_dim(torch.from_numpy(a).cuda()).contiguous(), Fn._pad_dim(torch.from_numpy(b).cuda()).contiguous()
     sa, sb = Fn.row_inv_norm(at), Fn.row_inv_norm(bt)
-    lse1, col1 = Fn.infonce_lse_raw(at, sa, bt, sb, 1 / temp, col_bound=1.0001 / temp)
-    col2 = Fn.infonce_lse_raw(bt, sb, at, sa, 1 / temp)
+    ef = Fn._resolve_engine(unit_rows=True)
+    lse1, col1 = Fn.infonce_lse_raw(at, sa, bt, sb, 1 / temp, col_bound=1.0001 / temp, engine_flag=ef)
+    col2 = Fn.infonce_lse_raw(bt, sb, at, sa, 1 / temp, engine_flag=ef)
     _, s = O.row_lse_scores(a, b, 1 / temp, True)
     ref_col = np.log(np.exp(s - s.max(0)).sum(0)) + s.max(0)
     np.testing.assert_allclose(col1.cpu().numpy(), ref_col, rtol=1e-5, atol=1e-5)
@@ -337,7 +339,7 @@ def test_flash_forward_lse_and_weighted_row_sum(Fn, engine, m, n, d, exd):
     np.testing.assert_allclose(lse.cpu().numpy(), ref_lse, rtol=1e-5, atol=1e-5)
     assert np.abs(o.cpu().numpy() - ref_o).max() <= 1e-5 * max(np.abs(ref_o).max(), 1e-3)
     # the same lse as the plain forward (same MFMA sequence for the scores)
-    plain = Fn.infonce_lse_raw(at, sa, bt, sb, inv_tau, exclude_diagonal=exd)
+    plain = Fn.infonce_lse_raw(at, sa, bt, sb, inv_tau, exclude_diagonal=exd, engine_flag=ef)
     assert float((plain - lse).abs().max()) <= 2e-6 * max(1.0, float(lse.abs().max()))
 
 

@@ -119,7 +119,8 @@ if pmc:
     for r in csv.DictReader(open(pmc)):
         k = r["Kernel_Name"]
         if "infonce_fwd" in k or "infonce_bwd" in k or "infonce_pipe" in k:
-            name = k.split("::")[-1].split("(")[0]          # infonce_fwd_b3_kernel<64, false, true> ...
+            # "void (anonymous namespace)::infonce_pipe_kernel<(anonymous namespace)::EngH2, 64, 1, false, 0>(float ..."
+            name = k.replace("(anonymous namespace)::", "").replace("void ", "").split(">(")[0] + ">"
             agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
     util = {}
     with open(os.path.join(here, f"{tag}_infonce_pmc_mfma.csv"), "w") as f:
@@ -138,8 +139,8 @@ if pmc:
     info_path = os.path.join(root, "gpurun_out", "pmc_probe_infonce.json")
     if util and os.path.exists(info_path):
         info = json.load(open(info_path))
-        # infonce_pipe_b3_kernel<D, MODE, EXD, SIDES>: MODE 0 = backward, MODE 1 = forward with the weighted row sum
-        is_pipe = lambda k, mode: "infonce_pipe_b3_kernel<" in k and k.split("<")[1].split(",")[1].strip() == str(mode)   # noqa: E731
+        # infonce_pipe_kernel<E, D, MODE, EXD, SIDES>: MODE 0 = backward, MODE 1 = forward with the weighted row sum
+        is_pipe = lambda k, mode: "infonce_pipe_kernel<" in k and k.split("<")[1].split(",")[2].strip() == str(mode)   # noqa: E731
         fwd = [v for k, v in util.items() if "infonce_fwd_" in k]
         fwdo = [v for k, v in util.items() if "infonce_fwdo_" in k or is_pipe(k, 1)]
         bwd = [v for k, v in util.items() if "infonce_bwd" in k or is_pipe(k, 0)]

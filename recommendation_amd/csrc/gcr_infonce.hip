@@ -293,6 +293,7 @@ struct EngB3 {
   static constexpr float kDeferE = kDefer;
   static __host__ __device__ constexpr int ta(int t) { constexpr int v[6] = {2, 0, 1, 1, 0, 0}; return v[t]; }   // streamed-side
   static __host__ __device__ constexpr int tb(int t) { constexpr int v[6] = {0, 2, 1, 0, 1, 0}; return v[t]; }   // plane / other
+  template <bool MIX = true>
   static __device__ __forceinline__ void split(float a, float b, unsigned (&p)[3]) { split3(a, b, p[0], p[1], p[2]); }
   static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) { return mfma_bf16(a, b, c); }
 };
@@ -306,10 +307,23 @@ struct EngH2 {
   static constexpr float kDeferE = 1.0f;
   static __host__ __device__ constexpr int ta(int t) { constexpr int v[3] = {1, 0, 0}; return v[t]; }
   static __host__ __device__ constexpr int tb(int t) { constexpr int v[3] = {0, 1, 0}; return v[t]; }
+  // MIX: the residuals a - hi[0], b - hi[1] by one mixed-precision FMA each (v_fma_mix_f32 reads the f16 half in
+  // place, no f16 -> f32 convert; the compiler does not form it from the plain expression).  Measured on one box
+  // (2048 x 1M x 64): flash forward 1.81 -> 1.70 ms with it, the backward loop 1.77 -> 1.88 without — so the
+  // backward (MODE 0) keeps the convert + subtract
+  template <bool MIX = true>
   static __device__ __forceinline__ void split(float a, float b, unsigned (&p)[2]) {
     const f16x2 hi = __builtin_convertvector((f32x2){a, b}, f16x2);                 // v_cvt_pk_f16_f32, RNE
     p[0] = __builtin_bit_cast(unsigned, hi);
-    p[1] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a - (float)hi[0], b - (float)hi[1]}, f16x2));
+    float ra, rb;
+    if (MIX) {
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(p[0]), "v"(a));
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(p[0]), "v"(b));
+    } else {
+      ra = a - (float)hi[0];
+      rb = b - (float)hi[1];
+    }
+    p[1] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){ra, rb}, f16x2));
   }
   static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
@@ -1231,6 +1245,10 @@ __global__ __launch_bounds__(1024) void h2_wscale_kernel(const float* __restrict
   }
 }
 
+// (LDS rows of 36 dwords: the 16 rows of every ds_read_b128 lane group start in 16 different bank quads, but rows q
+// and q + 2 of the four that one ds_read_b64_tr_b16 gathers share 8 banks — every transposing read takes two passes,
+// 22-28 % of the loop's LDS cycles are conflicts (SQ_LDS_BANK_CONFLICT).  Placing tile row 16kc + 8g + 4h + q in LDS row
+// 16kc + 4q + 2g + h removes them and was measured: no change in time (the LDS is 22-27 % busy), so the plain order stays.)
 template <class E, int D, int MODE, bool EXD, int SIDES>
 __global__ __launch_bounds__(256, E::kMinBlocks) void infonce_pipe_kernel(
     const float* __restrict__ x, const float* __restrict__ x_scale, int64_t mx, const float* __restrict__ y,
@@ -1305,9 +1323,9 @@ __global__ __launch_bounds__(256, E::kMinBlocks) void infonce_pipe_kernel(
       const int idx = tid + 256 * u;
       const int row = idx / (D / 4), c4 = idx % (D / 4);
       if (k == 0) {
-        E::split(st[u].x, st[u].y, sa[u]);
+        E::template split<MODE == 1>(st[u].x, st[u].y, sa[u]);
       } else if (k == 1) {
-        E::split(st[u].z, st[u].w, sb[u]);
+        E::template split<MODE == 1>(st[u].z, st[u].w, sb[u]);
       } else {
         unsigned char* p = rm + row * S::ROWB + c4 * 8;
 #pragma unroll
@@ -1372,7 +1390,7 @@ __global__ __launch_bounds__(256, E::kMinBlocks) void infonce_pipe_kernel(
       } else {
         const int e = m - 16;                            // pair (2e, 2e + 1): k-chunk e / 4, dword e % 4
         unsigned q[NPL];
-        E::split(acc[2 * e], acc[2 * e + 1], q);
+        E::template split<MODE == 1>(acc[2 * e], acc[2 * e + 1], q);
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) pq[e >> 2][pl][e & 3] = q[pl];
       }

@@ -406,3 +406,28 @@ def test_two_product_loop_random_shapes(Fn, engine):
         ga = Fn._infonce_bwd_raw(at, sa, bt, sb, inv_tau, lse, wt, None, None, engine_flag=ef).cpu().numpy()
         ref_ga = inv_tau * (sm * w[:, None].astype(np.float64)) @ bn
         assert np.abs(ga - ref_ga).max() <= 2e-5 * max(np.abs(ref_ga).max(), 1e-6), tag
+
+
+@pytest.mark.parametrize("m,d", [(33, 64), (65, 64), (129, 64), (257, 64), (300, 32), (1000, 64)])
+def test_exclude_diagonal_backward_raw_multi_tile(Fn, engine, m, d):
+    """gcr_infonce_bwd_ex_f32 with GCR_INFONCE_EXCLUDE_DIAGONAL on a self-similarity problem of 2..32 tiles (the pipelined
+    loop's MODE 0 with the diagonal mask in every step), statistics on the streamed side and on the stationary side,
+    against float64."""
+    ef = Fn._resolve_engine(unit_rows=True)
+    rng = np.random.default_rng(m + d)
+    x = (rng.standard_normal((m, d)) * 0.5).astype(np.float32)
+    w = rng.standard_normal(m).astype(np.float32)
+    xt = _t(x)
+    s = Fn.row_inv_norm(xt)
+    inv_tau = 4.0
+    xn = x.astype(np.float64) / np.linalg.norm(x.astype(np.float64), axis=1, keepdims=True)
+    sc = inv_tau * xn @ xn.T
+    np.fill_diagonal(sc, -np.inf)
+    lse = np.log(np.exp(sc).sum(1))
+    p = np.exp(sc - lse[:, None]) * w[:, None].astype(np.float64)
+    lt, wt = _t(lse.astype(np.float32)), _t(w)
+    gy = Fn._infonce_bwd_raw(xt, s, xt, s, inv_tau, None, None, lt, wt, exclude_diagonal=True, engine_flag=ef).cpu().numpy()
+    gx = Fn._infonce_bwd_raw(xt, s, xt, s, inv_tau, lt, wt, None, None, exclude_diagonal=True, engine_flag=ef).cpu().numpy()
+    ref_y, ref_x = inv_tau * p.T @ xn, inv_tau * p @ xn
+    assert np.abs(gy - ref_y).max() <= 1e-5 * np.abs(ref_y).max()
+    assert np.abs(gx - ref_x).max() <= 1e-5 * np.abs(ref_x).max()

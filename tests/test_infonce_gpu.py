@@ -431,3 +431,50 @@ def test_exclude_diagonal_backward_raw_multi_tile(Fn, engine, m, d):
     ref_y, ref_x = inv_tau * p.T @ xn, inv_tau * p @ xn
     assert np.abs(gy - ref_y).max() <= 1e-5 * np.abs(ref_y).max()
     assert np.abs(gx - ref_x).max() <= 1e-5 * np.abs(ref_x).max()
+
+
+def test_loop_instantiations_random_square(Fn, engine):
+    """Every remaining instantiation of the two-product loop on 40 random square self-similarity problems (1..13 tiles,
+    ragged last tiles, d in {32, 64}): flash forward and backward with the excluded diagonal, and the backward with
+    statistics on BOTH sides (the symmetric loss's P = w_i e^{s - lse_i} + v_j e^{s - col_j}), against float64."""
+    if engine == "f32":
+        pytest.skip("the pipelined loop is the split-operand engine's")
+    ef = Fn._resolve_engine(unit_rows=True)
+    rng = np.random.default_rng(77)
+    for case in range(40):
+        d = int(rng.choice([32, 64]))
+        m = int(rng.choice([rng.integers(2, 100), rng.integers(2, 420), 32 * rng.integers(1, 9) + 1]))
+        inv_tau = float(rng.choice([2.0, 5.0, 10.0]))
+        x = (rng.standard_normal((m, d)) * rng.uniform(0.2, 1.5)).astype(np.float32)
+        y = (x + 0.3 * rng.standard_normal((m, d))).astype(np.float32)
+        w, v = rng.standard_normal(m).astype(np.float32), rng.standard_normal(m).astype(np.float32)
+        xt, yt = _t(x), _t(y)
+        sx, sy = Fn.row_inv_norm(xt), Fn.row_inv_norm(yt)
+        xn = x.astype(np.float64) / np.linalg.norm(x.astype(np.float64), axis=1, keepdims=True)
+        yn = y.astype(np.float64) / np.linalg.norm(y.astype(np.float64), axis=1, keepdims=True)
+        tag = (case, m, d, inv_tau)
+        # excluded diagonal: flash forward + both backward roles on the self-similarity of x
+        s = inv_tau * xn @ xn.T
+        np.fill_diagonal(s, -np.inf)
+        lse = np.log(np.exp(s - s.max(1, keepdims=True)).sum(1)) + s.max(1)
+        sm = np.exp(s - lse[:, None])
+        got_lse, got_o = Fn.infonce_fwd_o_raw(xt, sx, xt, sx, inv_tau, exclude_diagonal=True, engine_flag=ef)
+        np.testing.assert_allclose(got_lse.cpu().numpy(), lse, rtol=1e-5, atol=1e-5, err_msg=str(tag))
+        ref_o = sm @ xn
+        assert np.abs(got_o.cpu().numpy() - ref_o).max() <= 1e-5 * max(np.abs(ref_o).max(), 1e-3), tag
+        lt, wt = _t(lse.astype(np.float32)), _t(w)
+        for stats_on_streamed in (True, False):
+            args = (None, None, lt, wt) if stats_on_streamed else (lt, wt, None, None)
+            g = Fn._infonce_bwd_raw(xt, sx, xt, sx, inv_tau, *args, exclude_diagonal=True, engine_flag=ef).cpu().numpy()
+            pw = sm * w[:, None].astype(np.float64)
+            ref = inv_tau * (pw.T if stats_on_streamed else pw) @ xn
+            assert np.abs(g - ref).max() <= 2e-5 * max(np.abs(ref).max(), 1e-6), (tag, stats_on_streamed)
+        # statistics on both sides (x rows vs y rows): row lse of x, column lse over x for each y
+        s2 = inv_tau * xn @ yn.T
+        row = np.log(np.exp(s2 - s2.max(1, keepdims=True)).sum(1)) + s2.max(1)
+        col = np.log(np.exp(s2 - s2.max(0, keepdims=True)).sum(0)) + s2.max(0)
+        p2 = np.exp(s2 - row[:, None]) * w[:, None].astype(np.float64) + np.exp(s2 - col[None, :]) * v[None, :].astype(np.float64)
+        gx = Fn._infonce_bwd_raw(xt, sx, yt, sy, inv_tau, _t(row.astype(np.float32)), wt, _t(col.astype(np.float32)), _t(v),
+                                 engine_flag=ef).cpu().numpy()
+        ref_gx = inv_tau * p2 @ yn
+        assert np.abs(gx - ref_gx).max() <= 2e-5 * max(np.abs(ref_gx).max(), 1e-6), tag

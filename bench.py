@@ -298,6 +298,19 @@ def infonce_roofline(Fn, x0, n_u, dev):
         "bwd": leg(f"infonce_pipe_kernel<{planes.split(':')[0]}, 64, MODE 0> (table-side gradient: score recomputed once + "
                    f"one product; {planes})", t_b, 2),
     }
+    if h2:
+        # the same three launches with the promise withheld (three bf16 planes, six products): what the format buys,
+        # measured in the same process
+        t3_f = _event_ms(lambda: Fn.infonce_lse_raw(anchors, sa, table, sb, inv_tau, engine_flag=0), 5)
+        t3_b = _event_ms(lambda: Fn._infonce_bwd_raw(table, sb, anchors, sa, inv_tau, None, None, lse, w, engine_flag=0), 3)
+        t3_o = _event_ms(lambda: Fn.infonce_fwd_o_raw(anchors, sa, table, sb, inv_tau, engine_flag=0), 3)
+        out["three_bf16_plane_format"] = {
+            "avg_launch_ms": {"fwd": round(t3_f, 4), "fwd_o": round(t3_o, 4), "bwd": round(t3_b, 4)},
+            "issued_frac_of_peak": {"fwd": round(6 * flops / t3_f / 1e9 / peak, 4), "fwd_o": round(12 * flops / t3_o / 1e9 / peak, 4),
+                                    "bwd": round(12 * flops / t3_b / 1e9 / peak, 4)},
+            "note": "EngH2 issues half the MFMA flops for the same f32 result, so its issued fraction of peak is lower "
+                    "while its launches are 1.35-1.55x shorter; the limiter moved from the matrix pipe to vector issue "
+                    "and waits (DESIGN 4.2b, profiles/r02_infonce_stall_counters.csv)"}
     pmc = _committed_pmc("infonce", infonce_source_digest())
     if pmc:
         out["mfma_busy_pct"] = pmc.get("fwd_mfma_busy_pct")

@@ -1446,7 +1446,6 @@ __global__ __launch_bounds__(256, E::kMinBlocks) void infonce_pipe_kernel(
     __syncthreads();
     score_plain(lds_rm[0], acc);
     prepare(acc, tile0);
-#pragma unroll
     load_stats(0);
 #pragma unroll
     for (int m = 0; m < 24; ++m) p_unit(m, acc, pqa);

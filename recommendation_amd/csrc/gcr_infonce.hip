@@ -1374,27 +1374,14 @@ __global__ __launch_bounds__(256, E::kMinBlocks) void infonce_pipe_kernel(
         p_off = E::kPExp - m_use;
       }
     };
-    // MODE 0: the streamed rows' (lse, w) of one tile for this lane's 16 accumulator rows (rows 8g + 4h + 0..3 are
-    // contiguous: four 16-B reads each instead of 32 scalar ones inside the P units, issued before the MFMA phase)
-    float4 lq[4], wq[4];
-    auto load_stats = [&](int sbuf) {
-      if (MODE == 0 && SIDES != 1) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          lq[g] = *reinterpret_cast<const float4*>(&st_lse[sbuf][8 * g + 4 * h]);
-          wq[g] = *reinterpret_cast<const float4*>(&st_w[sbuf][8 * g + 4 * h]);
-        }
-      }
-    };
-    auto f4 = [](const float4& v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); };
-    auto p_unit = [&](int m, f32x16& acc, unsigned (&pq)[2][NPL][4]) {
+    auto p_unit = [&](int m, f32x16& acc, int sbuf, unsigned (&pq)[2][NPL][4]) {
       if (m < 16) {
         const int r = m;
         if (MODE == 1) {
           acc[r] = __builtin_amdgcn_exp2f(fmaf(acc[r], E::kSInv, p_off));
           psum += acc[r];
         } else {
-          const float lre = f4(lq[r >> 2], r & 3), wre = f4(wq[r >> 2], r & 3);
+          const float lre = st_lse[sbuf][acc_row(r, h)], wre = st_w[sbuf][acc_row(r, h)];
           const float sc = acc[r];
           if (SIDES == 1) acc[r] = wl * __builtin_amdgcn_exp2f(fmaf(sc, E::kSInv, -lse2l));
           else if (SIDES == 2) acc[r] = wre * __builtin_amdgcn_exp2f(fmaf(sc, E::kSInv, -lre));
@@ -1446,9 +1433,8 @@ __global__ __launch_bounds__(256, E::kMinBlocks) void infonce_pipe_kernel(
     __syncthreads();
     score_plain(lds_rm[0], acc);
     prepare(acc, tile0);
-    load_stats(0);
 #pragma unroll
-    for (int m = 0; m < 24; ++m) p_unit(m, acc, pqa);
+    for (int m = 0; m < 24; ++m) p_unit(m, acc, 0, pqa);
     finish_p();
     __syncthreads();
 
@@ -1491,7 +1477,6 @@ __global__ __launch_bounds__(256, E::kMinBlocks) void infonce_pipe_kernel(
         }
       }
       if (MODE == 0 || real_next) prepare(acc, t + 1);
-      load_stats(par ^ 1);
       __builtin_amdgcn_sched_barrier(0);
       // phase B: second product of tile t || P(t+1)
       // A operand yhat^T[feature][tile row] straight from the ROW-MAJOR planes with the transposing LDS read
@@ -1525,7 +1510,7 @@ __global__ __launch_bounds__(256, E::kMinBlocks) void infonce_pipe_kernel(
           const int slot = grp * NTERM + term;
           if (MODE == 0 || real_next) {
 #pragma unroll
-            for (int m = slot * 24 / NG; m < (slot + 1) * 24 / NG; ++m) p_unit(m, acc, pn);
+            for (int m = slot * 24 / NG; m < (slot + 1) * 24 / NG; ++m) p_unit(m, acc, par ^ 1, pn);
           }
           __builtin_amdgcn_sched_barrier(0);
         }

@@ -154,18 +154,24 @@ class _Propagate(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_final, *g_layers):
         gt, K, c = ctx.graph.t, ctx.n_layers, ctx.scale
-        base = g_final.contiguous() * c
+        g = g_final.contiguous()
         if K == 0:
-            return base, None, None, None, None
-        gl = [g.contiguous() if g is not None else None for g in g_layers] if ctx.want_layers else [None] * K
-        h = base if gl[K - 1] is None else base + gl[K - 1]
+            return g * c, None, None, None, None
+        # the recurrence on h' = h / c: h'_K = g + g_K / c, h'_k = g + g_k / c + A^T h'_{k+1}, dx0 = c h'_0 — the scale
+        # rides on the last launch's epilogue instead of a pass over g_final
+        gl = [x.contiguous() if x is not None else None for x in g_layers] if ctx.want_layers else [None] * K
+        inv_c = 1.0 / c
+
+        def addend(k):
+            return g if gl[k] is None else torch.add(g, gl[k], alpha=inv_c)
+
+        h = addend(K - 1)
         for k in range(K - 1, 0, -1):
-            acc_in = base if gl[k - 1] is None else base + gl[k - 1]
-            out = torch.empty_like(base)
-            spmm_into(gt, h, acc_in=acc_in, acc_out=out)
+            out = torch.empty_like(g)
+            spmm_into(gt, h, acc_in=addend(k - 1), acc_out=out)
             h = out
-        dx0 = torch.empty_like(base)
-        spmm_into(gt, h, acc_in=base, acc_out=dx0)
+        dx0 = torch.empty_like(g)
+        spmm_into(gt, h, acc_in=g, acc_out=dx0, acc_scale=c)
         return dx0, None, None, None, None
 
 

@@ -300,6 +300,15 @@ class _SplitRows(torch.autograd.Function):
     def backward(ctx, g_top, g_bot):
         ref = g_top if g_top is not None else g_bot
         d = ref.shape[1]
+        # a producer that wrote both halves into ONE [rows, d] buffer (bpr_sums on the two halves of a split table):
+        # hand that buffer back instead of copying the halves together
+        if g_top is not None and g_bot is not None:
+            base = g_top._base
+            if base is not None and base is g_bot._base and tuple(base.shape) == (ctx.rows, d) and base.is_contiguous() \
+                    and g_top.data_ptr() == base.data_ptr() and tuple(g_top.shape) == (ctx.n, d) \
+                    and g_bot.data_ptr() == base.data_ptr() + ctx.n * d * base.element_size() \
+                    and g_top.is_contiguous() and g_bot.is_contiguous():
+                return base, None
         if g_top is None:
             g_top = ref.new_zeros(ctx.n, d)
         if g_bot is None:
@@ -374,6 +383,9 @@ class _BprSums(torch.autograd.Function):
                    "gcr_bpr_fwd_f32")
         ctx.save_for_backward(user_tab, item_tab, u_idx, i_idx, j_idx, dldx)
         ctx.n_neg = n_neg
+        # the two tables are the halves of one stacked [N, d] table (split_rows): the backward then writes both
+        # gradients into one buffer, which _SplitRows.backward hands on without a copy
+        ctx.stacked = user_tab.data_ptr() + user_tab.numel() * 4 == item_tab.data_ptr()
         ctx.mark_non_differentiable(u_idx, i_idx, j_idx)
         return sums
 
@@ -381,8 +393,13 @@ class _BprSums(torch.autograd.Function):
     def backward(ctx, g_sums):
         user_tab, item_tab, u_idx, i_idx, j_idx, dldx = ctx.saved_tensors
         gs = g_sums.contiguous().to(torch.float32)
-        gu = torch.zeros_like(user_tab)
-        gi = torch.zeros_like(item_tab)
+        if ctx.stacked:
+            gfull = torch.zeros(user_tab.shape[0] + item_tab.shape[0], user_tab.shape[1], dtype=torch.float32,
+                                device=user_tab.device)
+            gu, gi = gfull[: user_tab.shape[0]], gfull[user_tab.shape[0]:]
+        else:
+            gu = torch.zeros_like(user_tab)
+            gi = torch.zeros_like(item_tab)
         batch = u_idx.numel()
         if batch >= BPR_SORTED_MIN_BATCH and batch * ctx.n_neg < 2 ** 31:
             ku, pu, _ = _sorted_order(u_idx, user_tab.shape[0], cache=True)

@@ -514,8 +514,9 @@ __global__ __launch_bounds__(256, 2) void infonce_fwd_e_kernel(const float* __re
 #pragma unroll
             for (int e = 0; e < 4; ++e) cur[t][4 * u + e] = (xr[t] == e + 8 * u) ? -INFINITY : cur[t][4 * u + e];
           }
-          const float x = fmaxf(fmaxf(cur[t][4 * u], cur[t][4 * u + 1]), fmaxf(cur[t][4 * u + 2], cur[t][4 * u + 3]));
-          tmax[t] = u == 0 ? x : fmaxf(tmax[t], x);
+          // chained so that each pair of scores costs one v_max3_f32
+          const float x0 = u == 0 ? cur[t][0] : tmax[t];
+          tmax[t] = fmaxf(fmaxf(fmaxf(fmaxf(x0, cur[t][4 * u]), cur[t][4 * u + 1]), cur[t][4 * u + 2]), cur[t][4 * u + 3]);
         } else if (u == 4) {
           m_new[t] = fmaxf(m_run[t], tmax[t] * E::kSInv);
           sum[t] = 0.f;
@@ -1362,10 +1363,9 @@ __global__ __launch_bounds__(256, E::kMinBlocks) void infonce_pipe_kernel(
           }
       }
       if (MODE == 1) {
-        float tmax = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
+        float tmax = acc[0];                              // chained: one v_max3_f32 per pair of scores
 #pragma unroll
-        for (int g = 1; g < 4; ++g)
-          tmax = fmaxf(tmax, fmaxf(fmaxf(acc[4 * g], acc[4 * g + 1]), fmaxf(acc[4 * g + 2], acc[4 * g + 3])));
+        for (int r = 1; r < 16; r += 2) tmax = fmaxf(fmaxf(tmax, acc[r]), acc[r + 1 < 16 ? r + 1 : r]);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * E::kSInv;
         rescale = __any(tmax > m_run + E::kDeferE);
         m_use = rescale ? fmaxf(m_run, tmax) : m_run;

@@ -21,18 +21,19 @@ for (m, d) in [(100_000, 64), (20_000, 64)]:
     a = torch.randn(m, d, device="cuda", generator=g)
     b = a + 0.3 * torch.randn(m, d, device="cuda", generator=g)
     sa, sb = Fn.row_inv_norm(a), Fn.row_inv_norm(b)
-    one = lambda: Fn.infonce_lse_raw(a, sa, b, sb, 5.0, col_bound=5.0)
-    two = lambda: (Fn.infonce_lse_raw(a, sa, b, sb, 5.0), Fn.infonce_lse_raw(b, sb, a, sa, 5.0))
     res = {}
     for rnd in range(5):
-        for eng in ("f32", "b3"):
-            Fn.INFONCE_ENGINE = "f32" if eng == "f32" else "auto"
+        for eng in ("f32", "b3", "auto"):
+            Fn.INFONCE_ENGINE = eng
+            ef = Fn._resolve_engine(unit_rows=True)        # rows normalised by sa / sb
+            one = lambda: Fn.infonce_lse_raw(a, sa, b, sb, 5.0, col_bound=5.0, engine_flag=ef)
+            two = lambda: (Fn.infonce_lse_raw(a, sa, b, sb, 5.0, engine_flag=ef), Fn.infonce_lse_raw(b, sb, a, sa, 5.0, engine_flag=ef))
             for name, fn in (("one-pass", one), ("two-pass", two)):
                 if rnd == 0:
                     out = fn()
                     torch.cuda.synchronize()
                     if name == "one-pass":
-                        ref = Fn.infonce_lse_raw(b, sb, a, sa, 5.0)
+                        ref = Fn.infonce_lse_raw(b, sb, a, sa, 5.0, engine_flag=ef)
                         print(f"  {eng} column lse one-pass vs swapped-role pass: max abs diff {float((out[1] - ref).abs().max()):.2e}")
                 res.setdefault((eng, name), []).append(once(fn, 2))
     for k, v in res.items():

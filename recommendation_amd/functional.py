@@ -602,7 +602,8 @@ class _InfoNCEStats(torch.autograd.Function):
         # COL_DETERMINISTIC forces the bitwise-reproducible second pass with the roles swapped, which
         # is also the path for un-normalised inputs — and for the split-operand engine, whose MFMA
         # work is cheap enough that the second pass costs no more than the column-sum epilogue
-        # (11.6 vs 11.6 ms at 100K x 100K, 0.49 vs 0.65 ms at 20K x 20K; scripts/perf_infonce_sym.py)
+        # (two passes vs one: 11.5 vs 11.2 ms on three bf16 planes, 8.2 vs 13.6 ms on two f16 planes at 100K x 100K;
+        # 0.34-0.49 vs 0.62-0.89 ms at 20K x 20K; scripts/perf_infonce_sym.py)
         eng = _resolve_engine(unit_rows=normalize)   # once per problem: the backward runs on the same engine
         on_f32 = bool(eng & INFONCE_ENGINE_F32) or _lib.lib().gcr_infonce_engine(a_p.shape[1]) == 0
         one_pass = want_col and normalize and inv_tau <= 40.0 and not COL_DETERMINISTIC and not exd and on_f32

@@ -262,7 +262,7 @@ def infonce_roofline(Fn, x0, n_u, dev):
     flops = 2.0 * m * n_u * d
     from recommendation_amd import _lib
     engine = int(_lib.lib().gcr_infonce_engine(d))
-    h2 = engine == 1 and d <= 64 and bool(ef & Fn.INFONCE_UNIT_ROWS) and inv_tau <= 64.0
+    h2 = engine == 1 and d <= 64 and bool(ef & Fn.INFONCE_UNIT_ROWS) and inv_tau <= 20.0
     mult = 3 if h2 else (6 if engine == 1 else 1)        # 16-bit MFMA products per f32 product
     peak = BF16_MFMA_PEAK_TF if engine == 1 else FP32_MFMA_PEAK_TF
     mult2 = mult

@@ -478,3 +478,19 @@ def test_loop_instantiations_random_square(Fn, engine):
                                  engine_flag=ef).cpu().numpy()
         ref_gx = inv_tau * p2 @ yn
         assert np.abs(gx - ref_gx).max() <= 2e-5 * max(np.abs(ref_gx).max(), 1e-6), tag
+
+
+def test_two_operand_formats_agree_on_random_problems(engine):
+    """scripts/stress_infonce_formats.py in small: 80 random problems x every launch kind (forward +- column sums +-
+    excluded diagonal, flash forward, backward with statistics on either or both sides), two f16 planes against three
+    bf16 planes: <= 1e-5 relative (max norm) everywhere."""
+    if engine != "auto":
+        pytest.skip("runs both formats itself")
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "stress_infonce_formats.py")
+    spec = importlib.util.spec_from_file_location("stress_infonce_formats", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    worst = mod.run(80, 20.0, verbose=False)
+    assert max(worst.values()) <= 1e-5, worst

@@ -1253,8 +1253,12 @@ __global__ __launch_bounds__(1024) void h2_wscale_kernel(const float* __restrict
 // and q + 2 of the four that one ds_read_b64_tr_b16 gathers share 8 banks — every transposing read takes two passes,
 // 22-28 % of the loop's LDS cycles are conflicts (SQ_LDS_BANK_CONFLICT).  Placing tile row 16kc + 8g + 4h + q in LDS row
 // 16kc + 4q + 2g + h removes them and was measured: no change in time (the LDS is 22-27 % busy), so the plain order stays.)
-template <class E, int D, int MODE, bool EXD, int SIDES>
-__global__ __launch_bounds__(256, E::kMinBlocks) void infonce_pipe_kernel(
+// NW = 8: a 512-thread workgroup of 256 stationary rows.  Its waves 4..7 run the same stream ONE barrier interval behind
+// waves 0..3 (two barriers per step: after the score phase and after the P phase), so that on every SIMD one wave is in
+// its MFMA-heavy score phase while its partner is in its VALU-heavy P phase, and both halves share one staged tile
+// (each lane stages one float4 of it in its own score phase): half the staging work per MFMA.  Ring of four tiles.
+template <class E, int D, int MODE, bool EXD, int SIDES, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_pipe_kernel(
     const float* __restrict__ x, const float* __restrict__ x_scale, int64_t mx, const float* __restrict__ y,
     const float* __restrict__ y_scale, int64_t ny, float scale2, float out_scale, const float* __restrict__ lse_x,
     const float* __restrict__ w_x, const float* __restrict__ lse_y, const float* __restrict__ w_y, int nsplit,
@@ -1264,14 +1268,19 @@ __global__ __launch_bounds__(256, E::kMinBlocks) void infonce_pipe_kernel(
   static_assert(D <= 64, "the pipelined loop keeps five plane sets in LDS");
   constexpr int NPL = E::NPL, NTERM = E::NTERM;
   constexpr int RM = NPL * S::PLANE;
-  __shared__ __align__(16) unsigned char lds_rm[3][RM];      // ring: tile t (B, transposed reads), t+1 (A), t+2 (staging)
-  __shared__ __align__(16) float st_lse[2][kTileJ];
-  __shared__ __align__(16) float st_w[2][kTileJ];
+  constexpr int THREADS = 64 * NW;
+  constexpr int F4T = kTileJ * D / 4;                        // float4s per streamed tile
+  constexpr int NLDW = (F4T + THREADS - 1) / THREADS;        // ... per thread
+  constexpr int RING = NW == 8 ? 4 : 3;
+  static_assert(NW == 4 || NW == 8, "four or eight waves");
+  __shared__ __align__(16) unsigned char lds_rm[RING][RM];   // ring: tile t (B, transposed reads), t+1 (A), t+2 (staging)
+  __shared__ __align__(16) float st_lse[RING][kTileJ];
+  __shared__ __align__(16) float st_w[RING][kTileJ];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i32 = lane & 31, h = lane >> 5;
   const int64_t mblk = blockIdx.x / nsplit;
   const int split = blockIdx.x % nsplit;
-  const int64_t row_i = (mblk * 4 + wave) * 32 + i32;
+  const int64_t row_i = (mblk * NW + wave) * 32 + i32;
 
   u32x4 bq[1][NPL][S::KC];
   load_stationary_e<E, D>(x, x_scale, mx, row_i, h, scale2 * E::kSX, bq[0]);
@@ -1291,11 +1300,11 @@ __global__ __launch_bounds__(256, E::kMinBlocks) void infonce_pipe_kernel(
   const int64_t tile0 = (int64_t)split * tiles_per_split;
   const int64_t tile1 = min(total_tiles, tile0 + tiles_per_split);
   if (tile0 < tile1) {
-    constexpr int NP = 3 * S::NLD, NS1 = NTERM * S::KC, NG = B::CT * 2 * NTERM;
+    constexpr int NP = 3 * NLDW, NS1 = NTERM * S::KC, NG = B::CT * 2 * NTERM;
     const int64_t last = tile1 - 1;
-    float4 ra[S::NLD], rb[S::NLD];
+    float4 ra[NLDW], rb[NLDW];
     float sla = 0.f, swa = 0.f, slb = 0.f, swb = 0.f;
-    auto load_tile = [&](int64_t t, float4 (&r)[S::NLD], float& sl, float& sw) {
+    auto load_tile = [&](int64_t t, float4 (&r)[NLDW], float& sl, float& sw) {
       const int64_t j0 = min(t, last) * kTileJ;
       // wave-uniform tile base + 32-bit per-thread offsets (a ragged last tile clamps its rows to the last valid
       // one and zeroes their scale): no 64-bit vector arithmetic in the loop
@@ -1303,8 +1312,8 @@ __global__ __launch_bounds__(256, E::kMinBlocks) void infonce_pipe_kernel(
       const float* tb = y + j0 * D;
       const float* ts = y_scale != nullptr ? y_scale + j0 : nullptr;
 #pragma unroll
-      for (int u = 0; u < S::NLD; ++u) {
-        const int idx = tid + 256 * u;
+      for (int u = 0; u < NLDW; ++u) {
+        const int idx = min(tid + THREADS * u, F4T - 1);     // (more threads than float4s: the surplus reloads the last one)
         const int row = idx / (D / 4), c4 = idx % (D / 4);
         const int rr = min(row, rem - 1);
         float4 v = *reinterpret_cast<const float4*>(tb + rr * D + 4 * c4);
@@ -1321,10 +1330,10 @@ __global__ __launch_bounds__(256, E::kMinBlocks) void infonce_pipe_kernel(
       }
     };
     // one third of the staging of one float4: split (x, y), split (z, w), row-major plane stores
-    auto stage_part = [&](int pi, const float4 (&st)[S::NLD], unsigned (&sa)[S::NLD][NPL], unsigned (&sb)[S::NLD][NPL],
+    auto stage_part = [&](int pi, const float4 (&st)[NLDW], unsigned (&sa)[NLDW][NPL], unsigned (&sb)[NLDW][NPL],
                           unsigned char* rm, int sbuf, float sl, float sw) {
       const int u = pi / 3, k = pi % 3;
-      const int idx = tid + 256 * u;
+      const int idx = tid + THREADS * u;
       const int row = idx / (D / 4), c4 = idx % (D / 4);
       if (k == 0) {
         E::template split<MODE == 1>(st[u].x, st[u].y, sa[u]);
@@ -1332,16 +1341,18 @@ __global__ __launch_bounds__(256, E::kMinBlocks) void infonce_pipe_kernel(
         E::template split<MODE == 1>(st[u].z, st[u].w, sb[u]);
       } else {
         unsigned char* p = rm + row * S::ROWB + c4 * 8;
+        if (THREADS * NLDW == F4T || idx < F4T) {
 #pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<uint2*>(p + pl * S::PLANE) = make_uint2(sa[u][pl], sb[u][pl]);
+          for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<uint2*>(p + pl * S::PLANE) = make_uint2(sa[u][pl], sb[u][pl]);
+        }
         if (MODE == 0 && u == 0 && tid < kTileJ) {
           st_lse[sbuf][tid] = sl;
           st_w[sbuf][tid] = sw;
         }
       }
     };
-    auto stage_all = [&](const float4 (&st)[S::NLD], unsigned char* rm, int sbuf, float sl, float sw) {
-      unsigned sa[S::NLD][NPL], sb[S::NLD][NPL];
+    auto stage_all = [&](const float4 (&st)[NLDW], unsigned char* rm, int sbuf, float sl, float sw) {
+      unsigned sa[NLDW][NPL], sb[NLDW][NPL];
 #pragma unroll
       for (int pi = 0; pi < NP; ++pi) stage_part(pi, st, sa, sb, rm, sbuf, sl, sw);
     };
@@ -1443,16 +1454,17 @@ __global__ __launch_bounds__(256, E::kMinBlocks) void infonce_pipe_kernel(
 
     // step t: tile t's P planes in `pc`, tile t+2 in `st` registers; produces P(t+1) in `pn`, loads tile t+3 to `ld`
     auto step = [&](auto next_c, int64_t t, int k3, unsigned (&pc)[2][NPL][4], unsigned (&pn)[2][NPL][4],
-                    const float4 (&st)[S::NLD], float st_l, float st_w_v, float4 (&ld)[S::NLD], float& ld_l, float& ld_w) {
+                    const float4 (&st)[NLDW], float st_l, float st_w_v, float4 (&ld)[NLDW], float& ld_l, float& ld_w) {
       constexpr bool real_next = decltype(next_c)::value;    // false only for the split's last tile (compile time:
                                                              // no branch may sit between the MFMAs of a phase)
-      const int par = (int)((t - tile0) & 1);            // parity of tile t (the per-tile statistics are double-buffered)
       load_tile(t + 3, ld, ld_l, ld_w);
-      unsigned char* rm_out = lds_rm[(k3 + 2) % 3];      // tile t in rm[k3], t+1 in rm[k3 + 1], t+2 goes to rm[k3 + 2]
-      unsigned sa[S::NLD][NPL], sb[S::NLD][NPL];
+      // tile t in ring slot k3, t+1 in k3 + 1, t+2 goes to k3 + 2 (planes and per-tile statistics alike)
+      const int slot1 = (k3 + 1) % RING, slot2 = (k3 + 2) % RING;
+      unsigned char* rm_out = lds_rm[slot2];
+      unsigned sa[NLDW][NPL], sb[NLDW][NPL];
       // phase A: S^T of tile t+1 || staging of tile t+2
       {
-        const unsigned char* base = lds_rm[(k3 + 1) % 3] + i32 * S::ROWB + h * (S::KH * 2);
+        const unsigned char* base = lds_rm[slot1] + i32 * S::ROWB + h * (S::KH * 2);
         u32x4 ap[2][NPL];
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) ap[0][pl] = *reinterpret_cast<const u32x4*>(base + pl * S::PLANE);
@@ -1474,11 +1486,12 @@ __global__ __launch_bounds__(256, E::kMinBlocks) void infonce_pipe_kernel(
             acc = E::mfma(ap[c & 1][E::ta(term)], bq[0][E::tb(term)][c], cin);
 #pragma unroll
             for (int pi = slot * NP / NS1; pi < (slot + 1) * NP / NS1; ++pi)
-              stage_part(pi, st, sa, sb, rm_out, par, st_l, st_w_v);
+              stage_part(pi, st, sa, sb, rm_out, slot2, st_l, st_w_v);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
       }
+      if (NW == 8) __syncthreads();                      // interval boundary: the partner group moves on to its score phase
       if (MODE == 0 || real_next) prepare(acc, t + 1);
       __builtin_amdgcn_sched_barrier(0);
       // phase B: second product of tile t || P(t+1)
@@ -1513,7 +1526,7 @@ __global__ __launch_bounds__(256, E::kMinBlocks) void infonce_pipe_kernel(
           const int slot = grp * NTERM + term;
           if (MODE == 0 || real_next) {
 #pragma unroll
-            for (int m = slot * 24 / NG; m < (slot + 1) * 24 / NG; ++m) p_unit(m, acc, par ^ 1, pn);
+            for (int m = slot * 24 / NG; m < (slot + 1) * 24 / NG; ++m) p_unit(m, acc, slot1, pn);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -1521,21 +1534,25 @@ __global__ __launch_bounds__(256, E::kMinBlocks) void infonce_pipe_kernel(
       if (MODE == 0 || real_next) finish_p();
       __syncthreads();
     };
+    // NW = 8: waves 4..7 take one barrier more before the loop and waves 0..3 one more after it: the same number for
+    // all, the second group one interval behind
+    if (NW == 8 && wave >= 4) __syncthreads();
     int k3 = 0;
     int64_t tt = tile0;
     for (; tt + 2 < tile1; tt += 2) {
       step(std::true_type{}, tt, k3, pqa, pqb, ra, sla, swa, rb, slb, swb);
-      k3 = (k3 + 1) % 3;
+      k3 = (k3 + 1) % RING;
       step(std::true_type{}, tt + 1, k3, pqb, pqa, rb, slb, swb, ra, sla, swa);
-      k3 = (k3 + 1) % 3;
+      k3 = (k3 + 1) % RING;
     }
     if (tt + 1 < tile1) {                                  // two tiles left
       step(std::true_type{}, tt, k3, pqa, pqb, ra, sla, swa, rb, slb, swb);
-      k3 = (k3 + 1) % 3;
+      k3 = (k3 + 1) % RING;
       step(std::false_type{}, tt + 1, k3, pqb, pqa, rb, slb, swb, ra, sla, swa);
     } else {                                               // one tile left
       step(std::false_type{}, tt, k3, pqa, pqb, ra, sla, swa, rb, slb, swb);
     }
+    if (NW == 8 && wave < 4) __syncthreads();
   }
 
   float* gout = gpart + (int64_t)split * mx * D;
@@ -1629,12 +1646,12 @@ __global__ __launch_bounds__(256) void normalize_bwd_kernel(const float* __restr
   }
 }
 
-FwdPlan plan_bwd_rows(int64_t mx, int64_t ny, int d, int rows_per_block) {
-  FwdPlan p = plan_fwd(mx, ny, rows_per_block, 512);
+FwdPlan plan_bwd_rows(int64_t mx, int64_t ny, int d, int rows_per_block, int64_t resident = 512) {
+  FwdPlan p = plan_fwd(mx, ny, rows_per_block, resident);
   // every split keeps an [mx, D] fp32 partial: with many stationary rows the row blocks alone fill
   // the chip, and the partials must stay small (cap 1 GiB)
   const int64_t total_tiles = (ny + kTileJ - 1) / kTileJ;
-  while (p.nsplit > 1 && (p.m_blocks >= 1536 || (int64_t)p.nsplit * mx * d * 4 > (1ll << 30))) {
+  while (p.nsplit > 1 && (p.m_blocks >= 3 * resident || (int64_t)p.nsplit * mx * d * 4 > (1ll << 30))) {
     p.tiles_per_split *= 2;
     p.nsplit = (int)((total_tiles + p.tiles_per_split - 1) / p.tiles_per_split);
   }
@@ -1645,6 +1662,14 @@ template <int D>
 FwdPlan plan_bwd(int64_t mx, int64_t ny) {
   return plan_bwd_rows(mx, ny, D, BwdShape<D>::ROWS_PER_BLOCK);
 }
+
+// The two-f16-plane launches of d = 64 with long tile loops run as 512-thread workgroups of 256 stationary rows, one per
+// CU (infonce_pipe_kernel, NW = 8): measured against the 256-thread form on one box — flash forward 2048 x 1M 1.73 ->
+// 1.60 ms, 100K x 100K 7.93 -> 7.73 ms, backward 100K x 100K 9.20 -> 8.94 ms; but the backward of 2048 x 1M (3906 row
+// blocks of only 64 tiles) 1.78 -> 1.85 ms, and d = 32 (nothing to share: 256 lanes already stage a whole tile) 4-14 %
+// slower.  Hence: d = 64 and at least 256 tiles per split.
+FwdPlan plan_h2_rows8(int64_t mx, int64_t ny, int d) { return plan_bwd_rows(mx, ny, d, 256, 256); }
+bool h2_eight_waves(int d, const FwdPlan& p8) { return d == 64 && p8.tiles_per_split >= 256; }
 
 int32_t reduce_splits(const FwdPlan& p, const float* gpart, int64_t mx, int d, float* g, hipStream_t s) {
   if (p.nsplit <= 1) return GCR_OK;
@@ -1663,11 +1688,13 @@ int32_t launch_bwd(const float* x, const float* x_scale, int64_t mx, const float
     if (use_b3(D, force_f32)) {
       // d <= 64: the cross-tile pipelined loop (infonce_pipe_b3_kernel); d = 128: single-buffered (one tile with its
       // transposed copy is 54 KB of LDS)
-      const FwdPlan p = plan_bwd_rows(mx, ny, D, BwdB3<D>::ROWS_PER_BLOCK);
+      const bool h2 = use_h2(D, inv_tau, unit_rows, force_f32);
+      const FwdPlan p8 = plan_h2_rows8(mx, ny, D);
+      const bool w8 = h2 && h2_eight_waves(D, p8);
+      const FwdPlan p = w8 ? p8 : plan_bwd_rows(mx, ny, D, BwdB3<D>::ROWS_PER_BLOCK);
       float* gpart = p.nsplit == 1 ? g : reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + (D <= 64 ? kBwdHeader : 0));
       const dim3 grid((unsigned)(p.m_blocks * p.nsplit));
       const bool has_x = w_x != nullptr && lse_x != nullptr, has_y = w_y != nullptr && lse_y != nullptr;
-      const bool h2 = use_h2(D, inv_tau, unit_rows, force_f32);
       float* hw = reinterpret_cast<float*>(workspace);
       if (h2) {
         hipLaunchKernelGGL(h2_wscale_kernel, dim3(1), dim3(1024), 0, s, w_x, mx, w_y, ny, hw);
@@ -1676,7 +1703,12 @@ int32_t launch_bwd(const float* x, const float* x_scale, int64_t mx, const float
       }
 #define GCR_BWD3(EX, SD)                                                                                                \
   if constexpr (D <= 64) {                                                                                              \
-    if (h2)                                                                                                             \
+    if (h2 && w8) {                                                                                                     \
+      if constexpr (D == 64)                                                                                            \
+        hipLaunchKernelGGL((infonce_pipe_kernel<EngH2, D, 0, EX, SD, 8>), grid, dim3(512), 0, s, x, x_scale, mx, y,     \
+                           y_scale, ny, inv_tau * kLog2e, inv_tau, lse_x, w_x, lse_y, w_y, p.nsplit, p.tiles_per_split, \
+                           gpart, (float2*)nullptr, (const float*)hw);                                                  \
+    } else if (h2)                                                                                                      \
       hipLaunchKernelGGL((infonce_pipe_kernel<EngH2, D, 0, EX, SD>), grid, dim3(256), 0, s, x, x_scale, mx, y, y_scale, \
                          ny, inv_tau * kLog2e, inv_tau, lse_x, w_x, lse_y, w_y, p.nsplit, p.tiles_per_split, gpart,     \
                          (float2*)nullptr, (const float*)hw);                                                           \
@@ -1783,22 +1815,30 @@ int32_t launch_fwd(const float* a, const float* a_scale, int64_t m, const float*
 template <int D>
 int32_t launch_fwd_o(const float* a, const float* a_scale, int64_t m, const float* b, const float* b_scale, int64_t n,
                      float inv_tau, float* lse, float* o, void* workspace, bool exd, bool unit_rows, hipStream_t s) {
-  const FwdPlan p = plan_bwd_rows(m, n, D, BwdB3<D>::ROWS_PER_BLOCK);
+  const bool h2o = D <= 64 && use_h2(D, inv_tau, unit_rows, false);
+  const FwdPlan p8 = plan_h2_rows8(m, n, D);
+  const bool w8 = h2o && h2_eight_waves(D, p8);
+  const FwdPlan p = w8 ? p8 : plan_bwd_rows(m, n, D, BwdB3<D>::ROWS_PER_BLOCK);
   float2* part = reinterpret_cast<float2*>(workspace);
   float* opart = reinterpret_cast<float*>(part + (int64_t)p.nsplit * m);
   const dim3 grid((unsigned)(p.m_blocks * p.nsplit));
   if constexpr (D <= 64) {
     const float* none = nullptr;
     const float h2_out = 1.0f / (EngH2::kSY * 16384.0f);             // streamed operand x 2^8, P x 2^kPExp
-#define GCR_FWDO(ENG, EX, OS)                                                                                            \
-  hipLaunchKernelGGL((infonce_pipe_kernel<ENG, D, 1, EX, 0>), grid, dim3(256), 0, s, a, a_scale, m, b, b_scale, n,        \
-                     inv_tau * kLog2e, OS, none, none, none, none, p.nsplit, p.tiles_per_split, opart, part, none)
-    if (use_h2(D, inv_tau, unit_rows, false)) {
-      if (exd) GCR_FWDO(EngH2, true, h2_out);
-      else GCR_FWDO(EngH2, false, h2_out);
+#define GCR_FWDO(ENG, EX, OS, NWV)                                                                                       \
+  hipLaunchKernelGGL((infonce_pipe_kernel<ENG, D, 1, EX, 0, NWV>), grid, dim3(64 * NWV), 0, s, a, a_scale, m, b, b_scale, \
+                     n, inv_tau * kLog2e, OS, none, none, none, none, p.nsplit, p.tiles_per_split, opart, part, none)
+    if (w8) {
+      if constexpr (D == 64) {
+        if (exd) GCR_FWDO(EngH2, true, h2_out, 8);
+        else GCR_FWDO(EngH2, false, h2_out, 8);
+      }
+    } else if (h2o) {
+      if (exd) GCR_FWDO(EngH2, true, h2_out, 4);
+      else GCR_FWDO(EngH2, false, h2_out, 4);
     } else {
-      if (exd) GCR_FWDO(EngB3, true, 1.0f);
-      else GCR_FWDO(EngB3, false, 1.0f);
+      if (exd) GCR_FWDO(EngB3, true, 1.0f, 4);
+      else GCR_FWDO(EngB3, false, 1.0f, 4);
     }
 #undef GCR_FWDO
   } else {
@@ -2269,7 +2309,12 @@ extern "C" int32_t gcr_infonce_fwd_o_supported(int32_t d, uint32_t flags) {
 extern "C" int64_t gcr_infonce_fwd_o_workspace_bytes(int64_t m, int64_t n, int32_t d) {
   if (m <= 0 || n <= 0 || !gcr_infonce_fwd_o_supported(d, 0)) return 0;
   const FwdPlan p = plan_bwd_rows(m, n, d, 128);
-  return (int64_t)p.nsplit * m * ((int64_t)sizeof(float2) + (int64_t)d * (int64_t)sizeof(float));
+  int64_t nsplit = p.nsplit;
+  if (d <= 64) {                                          // either operand format (chosen per call)
+    const FwdPlan q = plan_h2_rows8(m, n, d);
+    if (q.nsplit > nsplit) nsplit = q.nsplit;
+  }
+  return nsplit * m * ((int64_t)sizeof(float2) + (int64_t)d * (int64_t)sizeof(float));
 }
 
 extern "C" int32_t gcr_infonce_fwd_o_f32(const float* a, const float* a_scale, int64_t m, const float* b,
@@ -2331,6 +2376,10 @@ extern "C" int64_t gcr_infonce_bwd_workspace_bytes(int64_t mx, int64_t ny, int32
   if (d <= 128) {   // either engine (chosen per call)
     const FwdPlan q = plan_bwd_rows(mx, ny, d, 128);
     if (q.nsplit > nsplit) nsplit = q.nsplit;
+    if (d <= 64) {
+      const FwdPlan q8 = plan_h2_rows8(mx, ny, d);
+      if (q8.nsplit > nsplit) nsplit = q8.nsplit;
+    }
   }
   return (nsplit > 1 ? nsplit * mx * d * (int64_t)sizeof(float) : 0) + (d <= 64 ? kBwdHeader : 0);
 }

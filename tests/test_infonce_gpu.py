@@ -494,3 +494,44 @@ def test_two_operand_formats_agree_on_random_problems(engine):
     spec.loader.exec_module(mod)
     worst = mod.run(80, 20.0, verbose=False)
     assert max(worst.values()) <= 1e-5, worst
+
+
+def test_eight_wave_form_of_the_loop_matches_three_plane_format(Fn, engine):
+    """Problems whose splits are >= 256 tiles long run the two-product loop as 512-thread workgroups (two wave groups
+    one barrier interval apart, sharing each staged tile): flash forward and backward (statistics on the stationary rows,
+    on both sides, excluded diagonal) at 2048 x 300K and 50K x 50K against the three-bf16-plane format, which never
+    takes that form."""
+    if engine != "auto":
+        pytest.skip("compares the two formats itself")
+    g = torch.Generator(device="cuda").manual_seed(9)
+    h2, b3 = Fn.INFONCE_UNIT_ROWS, 0
+
+    def close(x, y, tol=1e-5):
+        assert float((x - y).abs().max()) <= tol * float(y.abs().max())
+
+    m, n, d, inv_tau = 2000, 300_000, 64, 10.0
+    a = torch.randn(m, d, device="cuda", generator=g)
+    b = torch.randn(n, d, device="cuda", generator=g)
+    b[12345] = 3.0 * a[7]
+    sa, sb = Fn.row_inv_norm(a), Fn.row_inv_norm(b)
+    w = torch.randn(m, device="cuda", generator=g)
+    v = torch.randn(n, device="cuda", generator=g)
+    res = {}
+    for eng in (h2, b3):
+        lse, o = Fn.infonce_fwd_o_raw(a, sa, b, sb, inv_tau, engine_flag=eng)
+        col = Fn.infonce_lse_raw(b, sb, a, sa, inv_tau, engine_flag=eng)
+        res[eng] = (lse, o, Fn._infonce_bwd_raw(a, sa, b, sb, inv_tau, lse, w, None, None, engine_flag=eng),
+                    Fn._infonce_bwd_raw(a, sa, b, sb, inv_tau, lse, w, col, v, engine_flag=eng))
+    for x, y in zip(res[h2], res[b3]):
+        close(x, y)
+    k = 50_000
+    x = torch.randn(k, d, device="cuda", generator=g)
+    sx = Fn.row_inv_norm(x)
+    wk = torch.randn(k, device="cuda", generator=g)
+    res = {}
+    for eng in (h2, b3):
+        lse, o = Fn.infonce_fwd_o_raw(x, sx, x, sx, 5.0, exclude_diagonal=True, engine_flag=eng)
+        res[eng] = (lse, o, Fn._infonce_bwd_raw(x, sx, x, sx, 5.0, lse, wk, None, None, exclude_diagonal=True, engine_flag=eng),
+                    Fn._infonce_bwd_raw(x, sx, x, sx, 5.0, None, None, lse, wk, exclude_diagonal=True, engine_flag=eng))
+    for p, q in zip(res[h2], res[b3]):
+        close(p, q)

@@ -1545,7 +1545,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
     };
     // NW = 8: waves 4..7 take one barrier more before the loop and waves 0..3 one more after it: the same number for
     // all, the second group one interval behind
-    if (NW == 8 && wave >= 4) __syncthreads();
+    // (the group test on a scalar: a barrier inside a vector-divergent branch could be executed with an empty EXEC mask)
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    if (NW == 8 && wave_s >= 4) __syncthreads();
     int k3 = 0;
     int64_t tt = tile0;
     for (; tt + 2 < tile1; tt += 2) {
@@ -1561,7 +1563,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
     } else {                                               // one tile left
       step(std::false_type{}, tt, k3, pqa, pqb, ra, sla, swa, rb, slb, swb);
     }
-    if (NW == 8 && wave < 4) __syncthreads();
+    if (NW == 8 && wave_s < 4) __syncthreads();
   }
 
   float* gout = gpart + (int64_t)split * mx * D;

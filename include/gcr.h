@@ -72,6 +72,24 @@ int32_t gcr_spmm_csr_f32(const int64_t* desc, int64_t n_parts,
                          int64_t n_rows, int64_t n_cols, void* stream);
 
 /*
+ * gcr_spmm_csr_f32 with a second addend in the combine:
+ *           acc_out[r] = (acc_in[r] + acc_in2_scale * acc_in2[r] + y[r]) * acc_scale
+ * (acc_in2 == NULL: exactly gcr_spmm_csr_f32).  The backward of the K-layer message pass with per-layer outputs
+ * (ncl.py:415-422 returns `all_emb`; ncl.py:319-322 reads emb_list[2 * hyper_layers]) is the Horner recurrence
+ * h_k = g_final + g_k / c + A^T h_{k+1}: the per-layer gradient g_k rides on the epilogue instead of a separate
+ * [n_rows, d] add pass per layer.
+ */
+int32_t gcr_spmm_csr_acc2_f32(const int64_t* desc, int64_t n_parts,
+                              const int32_t* long_row, const int32_t* long_slot0, int64_t n_long_rows,
+                              const int64_t* rowptr, const int32_t* col, const float* val,
+                              const uint32_t* keep_bits, float val_scale,
+                              const float* x, int32_t d,
+                              float* y, const float* acc_in, const float* acc_in2, float acc_in2_scale,
+                              float* acc_out, float acc_scale,
+                              uint32_t flags, float* inv_norm_out, float* partials,
+                              int64_t n_rows, int64_t n_cols, void* stream);
+
+/*
  * The same product with TWO outputs from one launch:
  *   y_raw  = val_scale * A[keep] x                     (fed to the next layer)
  *   y_norm = y_raw / max(||y_raw||_2, 1e-12) per row   (appended to the layer list)
@@ -298,7 +316,8 @@ int32_t gcr_normalize_bwd_f32(const float* x, const float* inv_norm, const float
 
 /* ---------------------------------------------------------------------------------------------
  * k-means E-step of NCL's prototype contrast (ncl.py:340-356: faiss.Kmeans(d, k).train(x) +
- * index.search(x, 1); faiss itself is an un-vendored dependency: semantics = plain Lloyd).
+ * index.search(x, 1); faiss itself is an un-vendored dependency, not installed: what is restated is its published
+ * Clustering::train loop — Lloyd iterations + split_clusters for empty clusters; PARITY WITH FAISS UNPINNED).
  * --------------------------------------------------------------------------------------------- */
 /* assign[i] = argmin_c ||x_i - centroids_c||^2 (ties -> smaller c) on the MFMA tile engine;
  * half_sqnorm[c] = 0.5 ||centroids_c||^2 (kept up to date by gcr_kmeans_update_f32);
@@ -315,6 +334,24 @@ int32_t gcr_kmeans_update_f32(const float* x, int64_t n, int32_t d, const int64_
 int32_t gcr_kmeans_update_sorted_f32(const float* x, int64_t n, int32_t d, const uint32_t* keys_sorted,
                                      const int32_t* perm, int64_t k, float* centroids, float* half_sqnorm,
                                      float* sums, float* counts, void* stream);
+
+/*
+ * One Lloyd update without host involvement (a fixed launch sequence: hipGraph-capturable):
+ *   1. centroids_c <- mean of the rows assigned to c (empty clusters keep their centroid) — from `assign` (one row
+ *      atomic per point) or, when (keys_sorted, perm) = gcr_sort_index(assign, n, k) is given, from the ordered points;
+ *   2. faiss Clustering.cpp `split_clusters` on the device: every empty cluster takes over a copy of the centroid of a
+ *      cluster cj accepted with probability (size_cj - 1) / (n - k) while walking cj = 0, 1, ...; the two copies are
+ *      perturbed by (1 +- 1/1024) alternating over the dimensions, the sizes split in half.  Trial q of the e-th empty
+ *      cluster uses word x of Philox-4x32-10(counter (q, e, iter, 'KMSP'), key seed); after 64 k misses the largest
+ *      cluster (>= 2 points) is split instead;
+ *   3. half_sqnorm refreshed.
+ * sums [k, d] / counts [k] must be ZERO on entry and are zero again on exit (no memsets between iterations).
+ * n_split (optional device int32) is incremented by the number of re-seeded clusters.
+ */
+int32_t gcr_kmeans_lloyd_update_f32(const float* x, int64_t n, int32_t d, const int64_t* assign,
+                                    const uint32_t* keys_sorted, const int32_t* perm, int64_t k,
+                                    float* centroids, float* half_sqnorm, float* sums, float* counts,
+                                    uint64_t seed, int32_t iter, int32_t* n_split, void* stream);
 
 
 /* ---------------------------------------------------------------------------------------------
@@ -423,6 +460,11 @@ int32_t gcr_edge_mask_exact_bits(int64_t nnz, int64_t n_keep, uint64_t seed, uin
 int32_t gcr_adam_step_f32(float* param, const float* grad, const float* grad2, const float* grad3, float* exp_avg,
                           float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
                           float weight_decay, int64_t step, float grad_scale, void* stream);
+/* The same step with the step count read from device memory (*step_dev >= 1, incremented by the caller on the same
+ * stream): a training step captured in a hipGraph replays with the current count instead of the captured one. */
+int32_t gcr_adam_step_dev_f32(float* param, const float* grad, const float* grad2, const float* grad3, float* exp_avg,
+                              float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
+                              float weight_decay, const int64_t* step_dev, float grad_scale, void* stream);
 
 /* out[r, c] = keep bit c ? x[r, c] : 0 — PyGCL's FeatureMasking / drop_feature (univariate/grace.py:261-278): whole
  * feature columns zeroed.  keep_bits: bit c of a little-endian uint32 bitmap (gcr_edge_mask_bits(d, pf, seed) draws

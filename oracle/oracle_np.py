@@ -537,9 +537,59 @@ def synthetic_interactions(num_users, num_items, num_edges, seed=20250919, zipf_
 # --------------------------------------------------------------------------
 
 
-def kmeans_lloyd(x, init_centroids, niter=20):
+STREAM_KMSPLIT = 0x4B4D5350  # 'KMSP'
+
+
+def kmeans_split_clusters(cent, counts, n_points, seed, it):
+    """faiss Clustering.cpp `split_clusters` (the rule ncl.py:352 gets from faiss.Kmeans.train; faiss itself is absent:
+    PARITY UNPINNED), with the draws of the HIP path: every empty cluster ci, ascending, walks cj = 0, 1, ..., k-1, 0, ...
+    and accepts cj when u < (counts[cj] - 1) / (n_points - k), u = (x >> 8) * 2^-24 of
+    Philox-4x32-10(ctr = (q lo, e, it, 'KMSP'), key = (seed lo + q hi, seed hi)) for trial q of the e-th empty cluster;
+    64 k misses -> the largest cluster (smallest id among ties) if it has >= 2 points.  centroid[ci] = centroid[cj] *
+    (1 +- 1/1024), centroid[cj] *= (1 -+ 1/1024), alternating over the dimensions; counts split in half.
+    Works in place on float64 / float32 `cent` and float `counts`; returns the number of splits."""
+    k, d = cent.shape
+    empties = np.nonzero(np.asarray(counts) == 0)[0]
+    denom = float(n_points - k)
+    k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    eps = 1.0 / 1024.0
+    sign = np.where(np.arange(d) % 2 == 0, 1.0, -1.0)
+    n_split = 0
+    for e, ci in enumerate(empties):
+        hit = -1
+        if denom > 0:
+            max_trials = 64 * k
+            for q0 in range(0, max_trials, 4096):
+                q = np.arange(q0, min(q0 + 4096, max_trials), dtype=np.uint64)
+                cj = (q % np.uint64(k)).astype(np.int64)
+                p = ((np.asarray(counts, dtype=np.float64)[cj] - 1.0) / denom).astype(np.float32)
+                r = philox4x32_10((q & _MASK32).astype(np.uint32), np.full(q.size, e, np.uint32), np.full(q.size, it, np.uint32),
+                                  np.full(q.size, STREAM_KMSPLIT, np.uint32),
+                                  np.uint32((k0 + int(q0 >> 32)) & 0xFFFFFFFF), np.uint32(k1))[0]
+                u = (r >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)
+                ok = np.nonzero(u < p)[0]
+                if ok.size:
+                    hit = int(cj[ok[0]])
+                    break
+        if hit < 0:
+            best = int(np.argmax(counts))
+            if counts[best] >= 2:
+                hit = best
+        if hit >= 0:
+            c0 = cent[hit].copy()
+            cent[ci] = c0 * (1.0 + eps * sign).astype(cent.dtype)
+            cent[hit] = c0 * (1.0 - eps * sign).astype(cent.dtype)
+            half = np.floor(counts[hit] * 0.5)
+            counts[ci] = half
+            counts[hit] -= half
+            n_split += 1
+    return n_split
+
+
+def kmeans_lloyd(x, init_centroids, niter=20, split_seed=None, n_split_out=None):
     """Assignment = argmin_c ||x - c||^2 (ties -> smaller c); update = mean of members, an empty
-    cluster keeps its centroid; final assignment against the final centroids (index.search(x, 1))."""
+    cluster keeps its centroid — or, with split_seed (the HIP path's behaviour), is re-seeded by
+    `kmeans_split_clusters`; final assignment against the final centroids (index.search(x, 1))."""
     x = np.asarray(x, dtype=F64)
     cent = np.asarray(init_centroids, dtype=F64).copy()
 
@@ -547,13 +597,18 @@ def kmeans_lloyd(x, init_centroids, niter=20):
         score = x @ c.T - 0.5 * (c * c).sum(1)[None, :]
         return np.argmax(score, axis=1)
 
-    for _ in range(niter):
+    total = 0
+    for it in range(niter):
         a = assign(cent)
         sums = np.zeros_like(cent)
         np.add.at(sums, a, x)
-        cnt = np.bincount(a, minlength=cent.shape[0])
+        cnt = np.bincount(a, minlength=cent.shape[0]).astype(F64)
         nz = cnt > 0
         cent[nz] = sums[nz] / cnt[nz, None]
+        if split_seed is not None:
+            total += kmeans_split_clusters(cent, cnt, x.shape[0], split_seed, it)
+    if n_split_out is not None:
+        n_split_out.append(total)
     return cent, assign(cent)
 
 

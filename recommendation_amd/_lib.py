@@ -24,6 +24,8 @@ SIGNATURES = {
     "gcr_spmm_plan_fill_host": (c_int32, [_P, c_int64, c_int32, _P, _P, _P]),
     "gcr_spmm_csr_f32": (c_int32, [_P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, c_float, _P, c_int32,
                                    _P, _P, _P, c_float, c_uint32, _P, _P, c_int64, c_int64, _P]),
+    "gcr_spmm_csr_acc2_f32": (c_int32, [_P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, c_float, _P, c_int32,
+                                        _P, _P, _P, c_float, _P, c_float, c_uint32, _P, _P, c_int64, c_int64, _P]),
     "gcr_spmm_csr_dual_f32": (c_int32, [_P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, c_float, _P, c_int32,
                                         _P, _P, _P, _P, c_int64, c_int64, _P]),
     "gcr_csr_validate": (c_int32, [_P, _P, c_int64, c_int64, c_int64, _P, _P]),
@@ -55,6 +57,8 @@ SIGNATURES = {
     "gcr_kmeans_assign_f32": (c_int32, [_P, c_int64, _P, _P, c_int64, c_int32, _P, _P, _P]),
     "gcr_kmeans_update_f32": (c_int32, [_P, c_int64, c_int32, _P, c_int64, _P, _P, _P, _P, _P]),
     "gcr_kmeans_update_sorted_f32": (c_int32, [_P, c_int64, c_int32, _P, _P, c_int64, _P, _P, _P, _P, _P]),
+    "gcr_kmeans_lloyd_update_f32": (c_int32, [_P, c_int64, c_int32, _P, _P, _P, c_int64, _P, _P, _P, _P, c_uint64, c_int32,
+                                              _P, _P]),
     "gcr_score_rows_f32": (c_int32, [_P, _P, c_int64, c_int64, _P, c_int64, c_int32, _P, _P]),
     "gcr_topk_masked_f32": (c_int32, [_P, c_int64, c_int64, _P, c_int64, _P, _P, c_int32, _P, _P, _P]),
     "gcr_rank_fused_supported": (c_int32, [c_int64, c_int32, c_int32]),
@@ -69,6 +73,8 @@ SIGNATURES = {
     "gcr_edge_mask_exact_bits": (c_int32, [c_int64, c_int64, c_uint64, _P, _P, _P]),
     "gcr_adam_step_f32": (c_int32, [_P, _P, _P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int64,
                                     c_float, _P]),
+    "gcr_adam_step_dev_f32": (c_int32, [_P, _P, _P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, _P,
+                                        c_float, _P]),
     "gcr_mask_columns_f32": (c_int32, [_P, c_int64, c_int32, _P, _P, _P]),
     "gcr_spgemm_expand_f32": (c_int32, [_P, _P, _P, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gcr_csr_lookup_f32": (c_int32, [_P, _P, c_int64, _P, _P, _P, _P, _P]),

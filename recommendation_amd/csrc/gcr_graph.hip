@@ -16,6 +16,7 @@
 #include <rocprim/device/device_reduce_by_key.hpp>
 
 #include "gcr_common.h"
+#include "gcr_philox.h"
 
 namespace {
 
@@ -139,21 +140,6 @@ __global__ void scale_values_kernel(const int64_t* __restrict__ rowptr, const in
     }
     val_out[e] = dinv_row[lo] * (val != nullptr ? val[e] : 1.0f) * (dinv_col != nullptr ? dinv_col[col[e]] : 1.0f);
   }
-}
-
-struct U4 {
-  uint32_t x, y, z, w;
-};
-__device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
-    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
-    c = U4{hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-  return c;
 }
 
 // 64-bit random key per edge (ties broken by the stable sort): ctr = (e, 1, 'EDGE')

@@ -2108,106 +2108,6 @@ __global__ __launch_bounds__(256, 2) void kmeans_assign_b3_kernel(
   }
 }
 
-// sums[c] += x_i (256-B float-atomic rows), counts[c] += 1, one wave per point
-__global__ __launch_bounds__(256) void kmeans_accumulate_kernel(const float* __restrict__ x, int64_t n, int d,
-                                                                const int64_t* __restrict__ assign, int64_t k,
-                                                                float* __restrict__ sums, float* __restrict__ counts) {
-  const int lane = threadIdx.x & 63;
-  for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += (int64_t)gridDim.x * 4) {
-    const int64_t c = assign[i];
-    if (c < 0 || c >= k) continue;
-    for (int col = lane; col < d; col += 64) atomicAdd(sums + c * d + col, x[i * d + col]);
-    if (lane == 0) atomicAdd(counts + c, 1.0f);
-  }
-}
-
-// The same sums from the points ORDERED by cluster (gcr_sort_index of `assign`): a wave walks 64 consecutive
-// entries, adds every run of equal cluster ids in registers and issues one row atomic per run and chunk
-// (1M x 64 points: 0.42 ms with one atomic row per point).
-__global__ __launch_bounds__(256) void kmeans_accumulate_sorted_kernel(const float* __restrict__ x, int64_t n, int d,
-                                                                       const uint32_t* __restrict__ keys,
-                                                                       const int32_t* __restrict__ perm, int64_t k,
-                                                                       float* __restrict__ sums,
-                                                                       float* __restrict__ counts) {
-  const int lane = threadIdx.x & 63;
-  const int64_t n_chunks = (n + 63) / 64;
-  for (int64_t chunk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); chunk < n_chunks; chunk += (int64_t)gridDim.x * 4) {
-    const int64_t c0 = chunk * 64;
-    const int cnt = (int)(n - c0 < 64 ? n - c0 : 64);
-    uint32_t my_key = 0xFFFFFFFFu;
-    int my_row = 0;
-    if (lane < cnt) {
-      my_key = keys[c0 + lane];
-      my_row = perm[c0 + lane];
-      if (my_key >= (uint32_t)k) my_key = 0xFFFFFFFFu;
-    }
-    uint32_t cur = 0xFFFFFFFFu;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    float run = 0.f;
-    auto flush = [&]() {
-      if (cur != 0xFFFFFFFFu) {
-        for (int v = 0; v < 4; ++v) {
-          const int c = lane + 64 * v;
-          if (c < d) atomicAdd(sums + (int64_t)cur * d + c, acc[v]);
-        }
-        if (lane == 0) atomicAdd(counts + cur, run);
-      }
-    };
-    constexpr int kGather = 8;
-    for (int e0 = 0; e0 < cnt; e0 += kGather) {
-      uint32_t key[kGather];
-      float row[kGather][4];
-#pragma unroll
-      for (int q = 0; q < kGather; ++q) {
-        const int e = e0 + q < cnt ? e0 + q : cnt - 1;
-        key[q] = e0 + q < cnt ? (uint32_t)__builtin_amdgcn_readlane((int)my_key, e) : 0xFFFFFFFFu;
-        const int64_t r = key[q] != 0xFFFFFFFFu ? (int64_t)__builtin_amdgcn_readlane(my_row, e) : 0;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const int c = lane + 64 * v;
-          row[q][v] = c < d ? x[r * d + c] : 0.f;
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < kGather; ++q) {
-        if (key[q] == 0xFFFFFFFFu) continue;
-        if (key[q] != cur) {
-          flush();
-          cur = key[q];
-          run = 0.f;
-#pragma unroll
-          for (int v = 0; v < 4; ++v) acc[v] = 0.f;
-        }
-        run += 1.f;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) acc[v] += row[q][v];
-      }
-    }
-    flush();
-  }
-}
-
-// centroid = sum / count (empty clusters keep their previous centroid); half_sq = 0.5 ||c||^2
-__global__ __launch_bounds__(256) void kmeans_finalize_kernel(const float* __restrict__ sums,
-                                                              const float* __restrict__ counts, int64_t k, int d,
-                                                              float* __restrict__ cent, float* __restrict__ half_sq) {
-  const int l16 = threadIdx.x & 15;
-  for (int64_t c = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); c < k; c += (int64_t)gridDim.x * 16) {
-    const float cnt = counts != nullptr ? counts[c] : 0.f;
-    float ss = 0.f;
-    for (int col = l16; col < d; col += 16) {
-      float v = cent[c * d + col];
-      if (cnt > 0.f) {
-        v = sums[c * d + col] / cnt;
-        cent[c * d + col] = v;
-      }
-      ss += v * v;
-    }
-    ss = group16_sum(ss);
-    if (l16 == 0) half_sq[c] = 0.5f * ss;
-  }
-}
-
 }  // namespace
 
 extern "C" int32_t gcr_kmeans_assign_f32(const float* x, int64_t n, const float* centroids, const float* half_sqnorm,
@@ -2234,45 +2134,6 @@ extern "C" int32_t gcr_kmeans_assign_f32(const float* x, int64_t n, const float*
   }
 #undef GCR_KM
 #undef GCR_KM3
-  return GCR_LAUNCH_STATUS();
-}
-
-extern "C" int32_t gcr_kmeans_update_f32(const float* x, int64_t n, int32_t d, const int64_t* assign, int64_t k,
-                                         float* centroids, float* half_sqnorm, float* sums, float* counts,
-                                         void* stream) {
-  GCR_CHECK_ARG(n >= 0 && k >= 1 && d >= 1);
-  GCR_CHECK_ARG(centroids && half_sqnorm);
-  hipStream_t s = (hipStream_t)stream;
-  if (n > 0) {
-    GCR_CHECK_ARG(x && assign && sums && counts);
-    hipError_t err = hipMemsetAsync(sums, 0, sizeof(float) * (size_t)(k * d), s);
-    if (err == hipSuccess) err = hipMemsetAsync(counts, 0, sizeof(float) * (size_t)k, s);
-    if (err != hipSuccess) return gcr_hip_status(err);
-    const int64_t want = (n + 3) / 4;
-    hipLaunchKernelGGL(kmeans_accumulate_kernel, dim3((unsigned)(want > 16384 ? 16384 : want)), dim3(256), 0, s, x, n,
-                       d, assign, k, sums, counts);
-  }
-  const int64_t wantk = (k + 15) / 16;
-  hipLaunchKernelGGL(kmeans_finalize_kernel, dim3((unsigned)(wantk > 4096 ? 4096 : wantk)), dim3(256), 0, s, sums,
-                     n > 0 ? counts : nullptr, k, d, centroids, half_sqnorm);
-  return GCR_LAUNCH_STATUS();
-}
-
-extern "C" int32_t gcr_kmeans_update_sorted_f32(const float* x, int64_t n, int32_t d, const uint32_t* keys_sorted,
-                                                const int32_t* perm, int64_t k, float* centroids, float* half_sqnorm,
-                                                float* sums, float* counts, void* stream) {
-  GCR_CHECK_ARG(n >= 1 && n < (1ll << 31) && k >= 1 && d >= 1 && d <= 256);
-  GCR_CHECK_ARG(x && keys_sorted && perm && centroids && half_sqnorm && sums && counts);
-  hipStream_t s = (hipStream_t)stream;
-  hipError_t err = hipMemsetAsync(sums, 0, sizeof(float) * (size_t)(k * d), s);
-  if (err == hipSuccess) err = hipMemsetAsync(counts, 0, sizeof(float) * (size_t)k, s);
-  if (err != hipSuccess) return gcr_hip_status(err);
-  const int64_t want = ((n + 63) / 64 + 3) / 4;
-  hipLaunchKernelGGL(kmeans_accumulate_sorted_kernel, dim3((unsigned)(want > 65536 ? 65536 : want)), dim3(256), 0, s, x, n,
-                     d, keys_sorted, perm, k, sums, counts);
-  const int64_t wantk = (k + 15) / 16;
-  hipLaunchKernelGGL(kmeans_finalize_kernel, dim3((unsigned)(wantk > 4096 ? 4096 : wantk)), dim3(256), 0, s, sums, counts,
-                     k, d, centroids, half_sqnorm);
   return GCR_LAUNCH_STATUS();
 }
 

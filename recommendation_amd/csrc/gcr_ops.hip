@@ -14,8 +14,14 @@ __global__ __launch_bounds__(256) void adam_step_kernel(float4* __restrict__ p, 
                                                         const float4* __restrict__ g2, const float4* __restrict__ g3,
                                                         float4* __restrict__ m, float4* __restrict__ v, int64_t n4,
                                                         int tail, float lr_over_bc1, float beta1, float beta2, float eps,
-                                                        float inv_sqrt_bc2, float weight_decay, float grad_scale) {
+                                                        float inv_sqrt_bc2, float weight_decay, float grad_scale,
+                                                        const int64_t* __restrict__ step_dev, float lr) {
   const float omb1 = 1.0f - beta1, omb2 = 1.0f - beta2;
+  if (step_dev != nullptr) {      // step count kept on the device (a captured graph replays with the CURRENT count)
+    const double st = (double)*step_dev;
+    lr_over_bc1 = (float)((double)lr / (1.0 - pow((double)beta1, st)));
+    inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)beta2, st)));
+  }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     float4 pp = p[i], gg = g1[i], mm = m[i], vv = v[i];
     if (g2 != nullptr) {
@@ -145,7 +151,24 @@ extern "C" int32_t gcr_adam_step_f32(float* param, const float* grad, const floa
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(adam_step_kernel, dim3(ops_grid(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, (float4*)param,
                      (const float4*)grad, (const float4*)grad2, (const float4*)grad3, (float4*)exp_avg, (float4*)exp_avg_sq,
-                     n / 4, (int)(n & 3), (float)((double)lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), weight_decay, grad_scale);
+                     n / 4, (int)(n & 3), (float)((double)lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), weight_decay, grad_scale,
+                     (const int64_t*)nullptr, lr);
+  return GCR_LAUNCH_STATUS();
+}
+
+extern "C" int32_t gcr_adam_step_dev_f32(float* param, const float* grad, const float* grad2, const float* grad3,
+                                         float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                                         float eps, float weight_decay, const int64_t* step_dev, float grad_scale,
+                                         void* stream) {
+  GCR_CHECK_ARG(n >= 0 && step_dev != nullptr);
+  GCR_CHECK_ARG(lr >= 0.f && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f);
+  if (n == 0) return GCR_OK;
+  GCR_CHECK_ARG(param && grad && exp_avg && exp_avg_sq);
+  GCR_CHECK_ARG((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)grad2 | (uintptr_t)grad3 | (uintptr_t)exp_avg |
+                  (uintptr_t)exp_avg_sq) & 15) == 0);
+  hipLaunchKernelGGL(adam_step_kernel, dim3(ops_grid(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, (float4*)param,
+                     (const float4*)grad, (const float4*)grad2, (const float4*)grad3, (float4*)exp_avg, (float4*)exp_avg_sq,
+                     n / 4, (int)(n & 3), 0.f, beta1, beta2, eps, 0.f, weight_decay, grad_scale, step_dev, lr);
   return GCR_LAUNCH_STATUS();
 }
 

@@ -9,27 +9,12 @@
 // with the same Philox-4x32-10 counters (oracle/oracle_np.py, oracle/oracle.c); what is shared
 // with the reference is the contract: uniform over items, never a training positive.
 #include "gcr_common.h"
+#include "gcr_philox.h"
 
 namespace {
 
 constexpr uint32_t kStreamNeg = 0x4E454753u;   // 'NEGS'
 constexpr uint32_t kStreamEdge = 0x45444745u;  // 'EDGE'
-
-struct U4 {
-  uint32_t x, y, z, w;
-};
-
-__device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
-    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
-    c = U4{hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-  return c;
-}
 
 __device__ __forceinline__ uint32_t pick(const U4& r, int w) { return w == 0 ? r.x : (w == 1 ? r.y : (w == 2 ? r.z : r.w)); }
 

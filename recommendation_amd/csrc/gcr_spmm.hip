@@ -35,6 +35,8 @@ struct Epilogue {
   uint32_t flags;
   float* inv_norm_out;
   float* y_raw;          // second output under ROW_L2NORM: the product before the row normalise (mhcn.py:440-442)
+  const float* acc_in2;  // second addend of the combine, with its own scale (the per-layer gradient of the Horner backward)
+  float acc_in2_scale;
 };
 
 template <int NV, bool D64>
@@ -67,7 +69,8 @@ __device__ __forceinline__ void store_row(const Epilogue& ep, int64_t row, int d
     if (D64 || c < d) {
       if (ep.y != nullptr) ep.y[base + c] = yv[v];
       if (ep.acc_out != nullptr) {
-        const float prev = ep.acc_in != nullptr ? ep.acc_in[base + c] : 0.f;
+        float prev = ep.acc_in != nullptr ? ep.acc_in[base + c] : 0.f;
+        if (ep.acc_in2 != nullptr) prev = fmaf(ep.acc_in2[base + c], ep.acc_in2_scale, prev);
         ep.acc_out[base + c] = (prev + yv[v]) * ep.acc_scale;
       }
     }
@@ -270,21 +273,23 @@ int32_t launch_spmm(const int64_t* desc, int64_t n_parts, const int32_t* long_ro
 
 }  // namespace
 
-extern "C" int32_t gcr_spmm_csr_f32(const int64_t* desc, int64_t n_parts, const int32_t* long_row,
-                                    const int32_t* long_slot0, int64_t n_long_rows, const int64_t* rowptr,
-                                    const int32_t* col, const float* val, const uint32_t* keep_bits,
-                                    float val_scale, const float* x, int32_t d, float* y, const float* acc_in,
-                                    float* acc_out, float acc_scale, uint32_t flags, float* inv_norm_out,
-                                    float* partials, int64_t n_rows, int64_t n_cols, void* stream) {
+extern "C" int32_t gcr_spmm_csr_acc2_f32(const int64_t* desc, int64_t n_parts, const int32_t* long_row,
+                                         const int32_t* long_slot0, int64_t n_long_rows, const int64_t* rowptr,
+                                         const int32_t* col, const float* val, const uint32_t* keep_bits,
+                                         float val_scale, const float* x, int32_t d, float* y, const float* acc_in,
+                                         const float* acc_in2, float acc_in2_scale, float* acc_out, float acc_scale,
+                                         uint32_t flags, float* inv_norm_out, float* partials, int64_t n_rows,
+                                         int64_t n_cols, void* stream) {
   GCR_CHECK_ARG(n_parts >= 0 && n_long_rows >= 0 && n_rows >= 0 && n_cols >= 0);
   GCR_CHECK_ARG(n_parts < (1ll << 31) - 4 && n_rows < (1ll << 31) && n_cols < (1ll << 31));
   GCR_CHECK_ARG(d >= 1 && d <= 256);
   if (n_rows == 0 || n_parts == 0) return GCR_OK;
   GCR_CHECK_ARG(desc != nullptr && rowptr != nullptr && x != nullptr);
   GCR_CHECK_ARG(y != nullptr || acc_out != nullptr);
+  GCR_CHECK_ARG(acc_in2 == nullptr || acc_out != nullptr);
   GCR_CHECK_ARG(n_long_rows == 0 || (long_row != nullptr && long_slot0 != nullptr && partials != nullptr));
   GCR_CHECK_ARG((flags & ~GCR_SPMM_ROW_L2NORM) == 0);
-  Epilogue ep{val_scale, y, acc_in, acc_out, acc_scale, flags, inv_norm_out, nullptr};
+  Epilogue ep{val_scale, y, acc_in, acc_out, acc_scale, flags, inv_norm_out, nullptr, acc_in2, acc_in2_scale};
   hipStream_t s = (hipStream_t)stream;
 #define GCR_GO(NV, D64) \
   return launch_spmm<NV, D64>(desc, n_parts, long_row, long_slot0, n_long_rows, rowptr, col, val, keep_bits, x, d, ep, partials, s)
@@ -294,6 +299,17 @@ extern "C" int32_t gcr_spmm_csr_f32(const int64_t* desc, int64_t n_parts, const 
   if (d <= 192) GCR_GO(3, false);
   GCR_GO(4, false);
 #undef GCR_GO
+}
+
+extern "C" int32_t gcr_spmm_csr_f32(const int64_t* desc, int64_t n_parts, const int32_t* long_row,
+                                    const int32_t* long_slot0, int64_t n_long_rows, const int64_t* rowptr,
+                                    const int32_t* col, const float* val, const uint32_t* keep_bits,
+                                    float val_scale, const float* x, int32_t d, float* y, const float* acc_in,
+                                    float* acc_out, float acc_scale, uint32_t flags, float* inv_norm_out,
+                                    float* partials, int64_t n_rows, int64_t n_cols, void* stream) {
+  return gcr_spmm_csr_acc2_f32(desc, n_parts, long_row, long_slot0, n_long_rows, rowptr, col, val, keep_bits, val_scale,
+                               x, d, y, acc_in, nullptr, 0.f, acc_out, acc_scale, flags, inv_norm_out, partials, n_rows,
+                               n_cols, stream);
 }
 
 extern "C" int32_t gcr_spmm_csr_dual_f32(const int64_t* desc, int64_t n_parts, const int32_t* long_row,
@@ -309,7 +325,7 @@ extern "C" int32_t gcr_spmm_csr_dual_f32(const int64_t* desc, int64_t n_parts, c
   GCR_CHECK_ARG(desc != nullptr && rowptr != nullptr && x != nullptr && y_raw != nullptr && y_norm != nullptr);
   GCR_CHECK_ARG(y_raw != y_norm);
   GCR_CHECK_ARG(n_long_rows == 0 || (long_row != nullptr && long_slot0 != nullptr && partials != nullptr));
-  Epilogue ep{val_scale, y_norm, nullptr, nullptr, 1.0f, GCR_SPMM_ROW_L2NORM, inv_norm_out, y_raw};
+  Epilogue ep{val_scale, y_norm, nullptr, nullptr, 1.0f, GCR_SPMM_ROW_L2NORM, inv_norm_out, y_raw, nullptr, 0.f};
   hipStream_t s = (hipStream_t)stream;
 #define GCR_GO(NV, D64) \
   return launch_spmm<NV, D64>(desc, n_parts, long_row, long_slot0, n_long_rows, rowptr, col, val, keep_bits, x, d, ep, partials, s)

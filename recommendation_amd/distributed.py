@@ -392,6 +392,7 @@ class _ShardedChannelLayer(torch.autograd.Function):
             for s in ch.streams:
                 cur.wait_stream(s)                       # join: the pooled gather buffers are free again, outputs ready
         ctx.save_for_backward(*saved)
+        ctx.set_materialize_grads(False)       # an unused output (the last layer's raw rows) arrives as None, not as zeros
         return tuple(outs)
 
     @staticmethod

@@ -73,9 +73,28 @@ class Interaction:
         return list(self.training_set_u[user]), []
 
 
+class _StackedTable(torch.autograd.Function):
+    """`torch.cat([user_emb, item_emb], 0)` (ncl.py:416) without the copy: the two parameters are the row blocks of ONE
+    [U + I, d] buffer, so the concatenation is that buffer itself; the backward hands each parameter its block of the
+    incoming gradient as a view (no split copy either)."""
+
+    @staticmethod
+    def forward(ctx, user_emb, item_emb, table):
+        ctx.n_u = user_emb.shape[0]
+        return table.view_as(table)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[: ctx.n_u], g[ctx.n_u:], None
+
+
 class LGCNEncoder(nn.Module):
     """ncl.py:397-422: `forward()` -> (user_emb [U, d], item_emb [I, d], all_emb list of K+1 [N, d]),
-    final = mean of the K+1 layer outputs; K SpMMs with the mean fused into the epilogue."""
+    final = mean of the K+1 layer outputs; K SpMMs with the mean fused into the epilogue.
+
+    `embedding_dict["user_emb"]` / `["item_emb"]` are the reference's two parameters (same names, shapes, separate
+    xavier_uniform_ initialisation); here they are views of one stacked [U + I, d] buffer (`self.table`), which is what
+    the propagation reads — the reference concatenates them in every forward (ncl.py:416), a 282 MB copy at cfg3."""
 
     def __init__(self, data, emb_size, n_layers):
         super().__init__()
@@ -84,13 +103,30 @@ class LGCNEncoder(nn.Module):
         self.layers = n_layers
         self.norm_adj = data.norm_adj
         init = nn.init.xavier_uniform_
+        n_u, n_i = data.user_num, data.item_num
+        self.table = torch.empty(n_u + n_i, emb_size, device=data.device)
+        init(self.table[:n_u])
+        init(self.table[n_u:])
         self.embedding_dict = nn.ParameterDict({
-            "user_emb": nn.Parameter(init(torch.empty(data.user_num, emb_size))),
-            "item_emb": nn.Parameter(init(torch.empty(data.item_num, emb_size))),
-        }).to(data.device)
+            "user_emb": nn.Parameter(self.table[:n_u]),
+            "item_emb": nn.Parameter(self.table[n_u:]),
+        })
+
+    def _apply(self, fn, *args, **kwargs):
+        # .to() / .cuda() / .float() re-create the parameters one by one: re-establish the stacked buffer afterwards
+        super()._apply(fn, *args, **kwargs)
+        u, i = self.embedding_dict["user_emb"], self.embedding_dict["item_emb"]
+        if self.table.device != u.device or self.table.dtype != u.dtype or u.data_ptr() != self.table.data_ptr():
+            self.table = torch.cat([u.data, i.data], 0)
+            u.data, i.data = self.table[: u.shape[0]], self.table[u.shape[0]:]
+        return self
+
+    def stacked(self):
+        """The [U + I, d] embedding table as an autograd alias of the two parameters."""
+        return _StackedTable.apply(self.embedding_dict["user_emb"], self.embedding_dict["item_emb"], self.table)
 
     def forward(self):
-        emb = torch.cat([self.embedding_dict["user_emb"], self.embedding_dict["item_emb"]], 0)
+        emb = self.stacked()
         final, all_emb = Fn.lightgcn_propagate(self.norm_adj, emb, self.layers, combine="mean", return_layers=True)
         user_all, item_all = Fn.split_rows(final, self.data.user_num)
         return user_all, item_all, all_emb
@@ -164,35 +200,122 @@ def load_data(train_path, test_path, device=None):
     return edge_index, (tu, ti), (su, si), num_users, num_items
 
 
+class _MultiStreamSpMM(torch.autograd.Function):
+    """The independent SpMMs of one layer as ONE autograd node: forward and backward fork onto the side streams and
+    join on the caller's stream themselves, so autograd sees a node that lives on the caller's stream (per-operator
+    nodes recorded under `torch.cuda.stream(s)` make the engine run each backward on its side stream and the
+    parameters' AccumulateGrad then synchronises across streams — the warning GPUTEST r02 showed — and it is the
+    form a hipGraph capture of the step needs)."""
+
+    @staticmethod
+    def forward(ctx, graphs, modes, streams, *xs):
+        dev = xs[0].device
+        cur = torch.cuda.current_stream(dev)
+        xs = [x.contiguous() for x in xs]
+        # outputs come from the caller's stream's pool; the join below orders every later reuse behind the side streams
+        bufs = []
+        for g, x, mode in zip(graphs, xs, modes):
+            d = x.shape[1]
+            y = torch.empty(g.n_rows, d, dtype=torch.float32, device=dev)
+            raw = torch.empty_like(y) if mode == "dual" else None
+            inv = torch.empty(g.n_rows, dtype=torch.float32, device=dev) if mode else None
+            bufs.append((y, raw, inv))
+        start = torch.cuda.Event()
+        start.record(cur)
+        for g, x, s, mode, (y, raw, inv) in zip(graphs, xs, streams, modes, bufs):
+            s.wait_event(start)
+            with torch.cuda.stream(s):
+                if mode == "dual":
+                    Fn.spmm_dual_into(g, x, raw, y, inv)
+                else:
+                    Fn.spmm_into(g, x, y=y, l2norm=bool(mode), inv_norm_out=inv)
+        for s in streams[: len(graphs)]:
+            cur.wait_stream(s)
+        ctx.graphs, ctx.modes, ctx.streams = graphs, modes, streams
+        ctx.layout = []
+        saved, outs = [], []
+        for mode, (y, raw, inv) in zip(modes, bufs):
+            if mode == "dual":
+                outs += [raw, y]
+                saved += [y, inv]
+            elif mode:
+                outs.append(y)
+                saved += [y, inv]
+            else:
+                outs.append(y)
+        ctx.save_for_backward(*saved)
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        graphs, modes, streams = ctx.graphs, ctx.modes, ctx.streams
+        saved = list(ctx.saved_tensors)
+        ref = next(g for g in gs if g is not None)
+        dev = ref.device
+        cur = torch.cuda.current_stream(dev)
+        start = torch.cuda.Event()
+        start.record(cur)
+        dxs, gi, si = [], 0, 0
+        used = []
+        for g, s, mode in zip(graphs, streams, modes):
+            if mode == "dual":
+                g_raw, g_y = gs[gi], gs[gi + 1]
+                gi += 2
+            else:
+                g_raw, g_y = (None, gs[gi]) if mode else (gs[gi], None)
+                gi += 1
+            y = inv = None
+            if mode:
+                y, inv = saved[si], saved[si + 1]
+                si += 2
+            if g_raw is None and g_y is None:
+                dxs.append(None)
+                continue
+            gt = g.t
+            dx = torch.empty(gt.n_rows, ref.shape[1], dtype=torch.float32, device=dev)
+            s.wait_event(start)
+            with torch.cuda.stream(s):
+                dz = None
+                if g_y is not None:       # through the row normalise: (g - y <y, g>) / max(||A x||, eps)
+                    dz = (g_y - y * (y * g_y).sum(1, keepdim=True)) * inv.unsqueeze(1)
+                if g_raw is not None:
+                    dz = g_raw if dz is None else dz + g_raw
+                dz = dz.contiguous()
+                Fn.spmm_into(gt, dz, y=dx)
+                dz.record_stream(s)
+            used.append(s)
+            dxs.append(dx)
+        for s in used:
+            cur.wait_stream(s)
+        return (None, None, None, *dxs)
+
+
 def multi_stream_spmm(graphs, xs, streams=None, l2norm=False):
     """BASELINE config 5 (univariate/mhcn.py:440-456): the per-layer SpMMs over independent operators
     (H_s, H_j, H_p, R^T, R) launched on separate HIP streams so that they fill the chip together and
     can hide each other's tails / a concurrent all-gather.  Returns the outputs in order; the caller's
-    current stream waits for all of them (event join).  Autograd-aware.
+    current stream waits for all of them (stream join) in the forward AND in the backward (one autograd node,
+    `_MultiStreamSpMM`).
 
     l2norm: False -> A x (`spmm`); True -> normalize(A x) only (SEPT-style, `spmm_l2norm`);
     "dual" -> the pair (A x, normalize(A x)) per operator (`spmm_l2norm_dual`) — what MHCN's layer loop
     needs: mhcn.py:440-442 feeds the RAW product to the next layer and appends the normalised copy to
     the layer list.  A per-operator sequence of those values is accepted too."""
-    cur = torch.cuda.current_stream()
+    graphs, xs = list(graphs), list(xs)
     if streams is None:
         streams = [torch.cuda.Stream() for _ in graphs]
     modes = list(l2norm) if isinstance(l2norm, (list, tuple)) else [l2norm] * len(graphs)
-    start = torch.cuda.Event()
-    start.record(cur)
-    outs = []
-    for g, x, s, mode in zip(graphs, xs, streams, modes):
-        s.wait_event(start)
-        with torch.cuda.stream(s):
-            if mode == "dual":
-                outs.append(Fn.spmm_l2norm_dual(g, x))
-            else:
-                outs.append(Fn.spmm_l2norm(g, x) if mode else Fn.spmm(g, x))
-            x.record_stream(s)
-    for s, o in zip(streams, outs):
-        done = torch.cuda.Event()
-        done.record(s)
-        cur.wait_event(done)
-        for t in (o if isinstance(o, tuple) else (o,)):
-            t.record_stream(cur)
+    for x in xs:
+        if not x.is_cuda:
+            raise RuntimeError("multi_stream_spmm operates on HIP device tensors only")
+    flat = _MultiStreamSpMM.apply(graphs, modes, list(streams), *xs)
+    outs, k = [], 0
+    for mode in modes:
+        if mode == "dual":
+            outs.append((flat[k], flat[k + 1]))
+            k += 2
+        else:
+            outs.append(flat[k])
+            k += 1
     return outs

@@ -25,21 +25,23 @@ def _check_dense(x, n_rows, name):
 
 
 def spmm_into(graph: CsrGraph, x, *, y=None, acc_in=None, acc_out=None, acc_scale=1.0, val_scale=1.0,
-              keep_bits=None, l2norm=False, inv_norm_out=None):
-    """Raw launch of gcr_spmm_csr_f32: y = epilogue(val_scale * A[keep] x); optional fused layer
-    combine acc_out = (acc_in + y) * acc_scale (lightgcn.py:26, ncl.py:421) and row L2
+              keep_bits=None, l2norm=False, inv_norm_out=None, acc_in2=None, acc_in2_scale=1.0):
+    """Raw launch of gcr_spmm_csr_acc2_f32: y = epilogue(val_scale * A[keep] x); optional fused layer
+    combine acc_out = (acc_in + acc_in2_scale * acc_in2 + y) * acc_scale (lightgcn.py:26, ncl.py:421) and row L2
     normalise (sept.py:224).  Outputs are caller-allocated; nothing is recorded for autograd."""
-    _lib.require_cuda(x, y, acc_in, acc_out, keep_bits, inv_norm_out)
+    _lib.require_cuda(x, y, acc_in, acc_out, keep_bits, inv_norm_out, acc_in2)
     x = x.contiguous()
     _check_dense(x, graph.n_cols, "x")
     d = x.shape[1]
-    for t, nm in ((y, "y"), (acc_in, "acc_in"), (acc_out, "acc_out")):
+    for t, nm in ((y, "y"), (acc_in, "acc_in"), (acc_out, "acc_out"), (acc_in2, "acc_in2")):
         if t is not None:
             _check_dense(t, graph.n_rows, nm)
             if t.shape[1] != d or not t.is_contiguous():
                 raise ValueError(f"{nm} must be contiguous [{graph.n_rows}, {d}]")
     if y is None and acc_out is None:
         raise ValueError("need y and/or acc_out")
+    if acc_in2 is not None and acc_out is None:
+        raise ValueError("acc_in2 needs acc_out")
     if keep_bits is not None and (keep_bits.dtype != torch.int32 or keep_bits.numel() * 32 < graph.nnz):
         raise ValueError("keep_bits must be an int32 bitmap with >= nnz bits")
     if inv_norm_out is not None and (inv_norm_out.dtype != torch.float32 or inv_norm_out.numel() != graph.n_rows):
@@ -50,13 +52,13 @@ def spmm_into(graph: CsrGraph, x, *, y=None, acc_in=None, acc_out=None, acc_scal
     if sink is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    rc = _lib.lib().gcr_spmm_csr_f32(
+    rc = _lib.lib().gcr_spmm_csr_acc2_f32(
         _lib.dptr(p.desc), p.n_parts, _lib.dptr(p.long_row), _lib.dptr(p.long_slot0), p.n_long,
         _lib.dptr(graph.rowptr), _lib.dptr(graph.col), _lib.dptr(graph.val), _lib.dptr(keep_bits), float(val_scale),
-        _lib.dptr(x), d, _lib.dptr(y), _lib.dptr(acc_in), _lib.dptr(acc_out), float(acc_scale),
-        SPMM_ROW_L2NORM if l2norm else 0, _lib.dptr(inv_norm_out), _lib.dptr(ws),
+        _lib.dptr(x), d, _lib.dptr(y), _lib.dptr(acc_in), _lib.dptr(acc_in2), float(acc_in2_scale), _lib.dptr(acc_out),
+        float(acc_scale), SPMM_ROW_L2NORM if l2norm else 0, _lib.dptr(inv_norm_out), _lib.dptr(ws),
         graph.n_rows, graph.n_cols, _lib.cur_stream(x.device))
-    _lib.check(rc, "gcr_spmm_csr_f32")
+    _lib.check(rc, "gcr_spmm_csr_acc2_f32")
     if sink is not None:
         ev1.record()
         sink.append((ev0, ev1))
@@ -161,14 +163,12 @@ class _Propagate(torch.autograd.Function):
         # rides on the last launch's epilogue instead of a pass over g_final
         gl = [x.contiguous() if x is not None else None for x in g_layers] if ctx.want_layers else [None] * K
         inv_c = 1.0 / c
-
-        def addend(k):
-            return g if gl[k] is None else torch.add(g, gl[k], alpha=inv_c)
-
-        h = addend(K - 1)
+        # the last layer's own gradient is part of the first launch's INPUT, so it is the one addend that needs a pass;
+        # every other g_k rides on an epilogue as the second addend (gcr_spmm_csr_acc2_f32)
+        h = g if gl[K - 1] is None else torch.add(g, gl[K - 1], alpha=inv_c)
         for k in range(K - 1, 0, -1):
             out = torch.empty_like(g)
-            spmm_into(gt, h, acc_in=addend(k - 1), acc_out=out)
+            spmm_into(gt, h, acc_in=g, acc_in2=gl[k - 1], acc_in2_scale=inv_c, acc_out=out)
             h = out
         dx0 = torch.empty_like(g)
         spmm_into(gt, h, acc_in=g, acc_out=dx0, acc_scale=c)
@@ -262,11 +262,15 @@ class _NormPropDual(torch.autograd.Function):
         spmm_dual_into(graph, x, z, n, inv)
         ctx.graph = graph
         ctx.save_for_backward(n, inv)
+        # an unused output (the raw rows of the last MHCN layer) arrives as None instead of a materialised [U, d] zero
+        ctx.set_materialize_grads(False)
         return z, n
 
     @staticmethod
     def backward(ctx, gz, gn):
         n, inv = ctx.saved_tensors
+        if gz is None and gn is None:
+            return None, None
         # dz = gz + (gn - n <n, gn>) / max(||z||, eps); rows clamped by eps have inv = 1e12 and n = 0
         dz = None
         if gn is not None:
@@ -363,6 +367,17 @@ def _sorted_order(idx, n_keys, cache=False):
     return keys, perm, idx
 
 
+def _halves_of_one_table(top, bot):
+    """True when `top` / `bot` are the two row blocks of ONE contiguous [rows, d] tensor (split_rows' outputs): decided
+    from the views themselves — same base, shapes adding up to it — not from address adjacency, which two unrelated
+    allocations can show by accident."""
+    base = top._base
+    return base is not None and base is bot._base and base.dim() == 2 and base.is_contiguous() \
+        and top.is_contiguous() and bot.is_contiguous() and top.shape[1] == base.shape[1] == bot.shape[1] \
+        and top.shape[0] + bot.shape[0] == base.shape[0] and top.data_ptr() == base.data_ptr() \
+        and bot.data_ptr() == base.data_ptr() + top.numel() * base.element_size()
+
+
 class _BprSums(torch.autograd.Function):
     """sums = [sum_b loss_b, sum|U[u]|^2, sum|I[i]|^2, sum|I[j]|^2] through gcr_bpr_fwd/bwd_f32."""
 
@@ -385,7 +400,7 @@ class _BprSums(torch.autograd.Function):
         ctx.n_neg = n_neg
         # the two tables are the halves of one stacked [N, d] table (split_rows): the backward then writes both
         # gradients into one buffer, which _SplitRows.backward hands on without a copy
-        ctx.stacked = user_tab.data_ptr() + user_tab.numel() * 4 == item_tab.data_ptr()
+        ctx.stacked = _halves_of_one_table(user_tab, item_tab)
         ctx.mark_non_differentiable(u_idx, i_idx, j_idx)
         return sums
 
@@ -545,14 +560,16 @@ def infonce_fwd_o_supported(d, engine_flag=0):
     return bool(_lib.lib().gcr_infonce_fwd_o_supported(int(d), int(engine_flag)))
 
 
-def infonce_fwd_o_raw(a, a_scale, b, b_scale, inv_tau, exclude_diagonal=False, engine_flag=None):
+def infonce_fwd_o_raw(a, a_scale, b, b_scale, inv_tau, exclude_diagonal=False, engine_flag=None, lse_out=None, o_out=None):
     """(lse [M], o [M, d]): lse[i] = log sum_j exp(s_ij), o[i] = sum_j softmax(s_i.)_j * (b_scale[j] b_j)
-    (no autograd)."""
+    (no autograd).  lse_out / o_out: caller-owned contiguous outputs (e.g. slices of one stacked buffer)."""
     L = _lib.lib()
     m, d = a.shape
     n = b.shape[0]
-    lse = torch.empty(m, dtype=torch.float32, device=a.device)
-    o = torch.empty(m, d, dtype=torch.float32, device=a.device)
+    lse = torch.empty(m, dtype=torch.float32, device=a.device) if lse_out is None else lse_out
+    o = torch.empty(m, d, dtype=torch.float32, device=a.device) if o_out is None else o_out
+    if lse.shape != (m,) or o.shape != (m, d) or lse.dtype != torch.float32 or o.dtype != torch.float32:
+        raise ValueError("lse_out [M] / o_out [M, d] must be float32")
     ws = torch.empty(max(int(L.gcr_infonce_fwd_o_workspace_bytes(m, n, d)), 8) // 4, dtype=torch.float32, device=a.device)
     _lib.check(L.gcr_infonce_fwd_o_f32(_lib.dptr(a), _lib.dptr(a_scale), m, _lib.dptr(b), _lib.dptr(b_scale), n, d,
                                        float(inv_tau), _lib.dptr(lse), _lib.dptr(o), _lib.dptr(ws),
@@ -562,20 +579,24 @@ def infonce_fwd_o_raw(a, a_scale, b, b_scale, inv_tau, exclude_diagonal=False, e
     return lse, o
 
 
-def pos_logit_raw(a, a_scale, b, b_scale, pos, scale):
+def pos_logit_raw(a, a_scale, b, b_scale, pos, scale, out=None):
     m, d = a.shape
-    out = torch.empty(m, dtype=torch.float32, device=a.device)
+    out = torch.empty(m, dtype=torch.float32, device=a.device) if out is None else out
     _lib.check(_lib.lib().gcr_pos_logit_f32(_lib.dptr(a), _lib.dptr(a_scale), _lib.dptr(b), _lib.dptr(b_scale),
                                             _lib.dptr(pos), m, b.shape[0], d, float(scale), _lib.dptr(out),
                                             _lib.cur_stream(a.device)), "gcr_pos_logit_f32")
     return out
 
 
-def _infonce_bwd_raw(x, x_scale, y, y_scale, inv_tau, lse_x, w_x, lse_y, w_y, exclude_diagonal=False, engine_flag=None):
-    """g = inv_tau * sum_j P_ij yhat_j (see gcr_infonce_bwd_f32): gradient w.r.t. the scaled rows of x."""
+def _infonce_bwd_raw(x, x_scale, y, y_scale, inv_tau, lse_x, w_x, lse_y, w_y, exclude_diagonal=False, engine_flag=None,
+                     out=None):
+    """g = inv_tau * sum_j P_ij yhat_j (see gcr_infonce_bwd_f32): gradient w.r.t. the scaled rows of x.
+    out: caller-owned contiguous [Mx, d] (e.g. one half of a stacked gradient table)."""
     L = _lib.lib()
     mx, d = x.shape
-    g = torch.empty_like(x)
+    g = torch.empty_like(x) if out is None else out
+    if g.shape != x.shape or g.dtype != torch.float32:
+        raise ValueError("out must be float32 with x's shape")
     nbytes = int(L.gcr_infonce_bwd_workspace_bytes(mx, y.shape[0], d))
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device) if nbytes else None
     _lib.check(L.gcr_infonce_bwd_ex_f32(_lib.dptr(x), _lib.dptr(x_scale), mx, _lib.dptr(y), _lib.dptr(y_scale), y.shape[0],
@@ -757,12 +778,27 @@ class _GatherRows(torch.autograd.Function):
         return gt, None
 
 
+# True: gather_rows checks its ids on the host (one min / max read-back per call) and raises IndexError like `table[idx]`
+# does; off by default because the read-back stalls the stream (and forbids hipGraph capture)
+CHECK_INDEX = False
+
+
 def gather_rows(table, idx):
-    """`table[idx]` for a float32 [N, d] table and int64 ids (`rec_user_emb[user_idx]`, `context[user]` ...; ncl.py:314-316,
+    """`table[idx]` for a float32 [N, d] table and int64 ids in [0, N) — NOT torch's full indexing contract: negative
+    ids do not wrap, and an id outside [0, N) yields a zero row and is skipped by the backward instead of raising (set
+    `functional.CHECK_INDEX = True` to get torch's IndexError, at the price of a host read-back).  The backward adds
+    duplicate ids with float atomics: their order, hence the last bits of such rows, can differ from run to run.
+
+    `table[idx]` for a float32 [N, d] table and int64 ids (`rec_user_emb[user_idx]`, `context[user]` ...; ncl.py:314-316,
     360-361,370-373) whose backward scatters the row gradients with float atomics (gcr_scatter_add_rows_f32) instead of
     the sort + segmented reduction of a generic index_put(accumulate=True) (which grows with the batch; at B = 2048
     the two cost the same within noise, profiles/r02_ncl_step_kernel_stats.csv)."""
     _lib.require_cuda(table)
     if table.dim() != 2 or table.dtype != torch.float32:
         raise ValueError("table must be float32 [N, d]")
-    return _GatherRows.apply(table, _as_index(idx, table.device).reshape(-1))
+    idx = _as_index(idx, table.device).reshape(-1)
+    if CHECK_INDEX and idx.numel() > 0:
+        lo, hi = int(idx.min()), int(idx.max())
+        if lo < 0 or hi >= table.shape[0]:
+            raise IndexError(f"gather_rows: index {lo if lo < 0 else hi} is out of bounds for a table of {table.shape[0]} rows")
+    return _GatherRows.apply(table, idx)

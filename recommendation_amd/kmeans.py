@@ -1,14 +1,26 @@
 """k-means E-step of NCL (ncl.py:340-356) on the GPU: `run_kmeans(x)` -> (centroids, assignment).
 
-The reference delegates to `faiss.Kmeans(d, k, gpu=False).train(x)` + `kmeans.index.search(x, 1)`;
-faiss is an un-vendored dependency that is not installed here, so parity with it is UNPINNED.  What
-is implemented is faiss' published `Clustering::train` with its defaults: if n > 256 k the
-centroids are trained on a random subsample of 256 k points (max_points_per_centroid), initial
-centroids = a random sample of k training points, niter = 20 Lloyd iterations with L2 nearest
-centroid, then EVERY point is assigned against the final centroids (the `index.search`).  Differences:
-the random draws are torch's / numpy's, not faiss' generator (an empty cluster is re-seeded from a big one with
-faiss' `split_clusters` rule).  The assignment runs on the MFMA tile engine
-(gcr_kmeans_assign_f32), the update is float-atomic row adds.
+The reference delegates to `faiss.Kmeans(d=emb_size, k=k, gpu=False).train(x)` + `kmeans.index.search(x, 1)`
+(ncl.py:352-355); faiss is an un-vendored dependency that is not installed here and the reference holds no fixture
+for it, so PARITY WITH FAISS IS UNPINNED.  What is implemented is faiss' published `Clustering::train`
+(faiss/Clustering.cpp) under the parameter list the reference's call leaves at its defaults — `struct
+ClusteringParameters` of faiss/Clustering.h as published for faiss 1.7 / 1.8 (restated from memory of the public
+source; not checkable offline, hence explicit arguments here rather than a claim):
+
+    niter = 25, nredo = 1, seed = 1234, spherical = false, int_centroids = false, update_index = false,
+    frozen_centroids = false, min_points_per_centroid = 39, max_points_per_centroid = 256
+
+  * n > k * max_points_per_centroid: train on a random subsample of k * 256 points (`subsample_training_set`, a
+    random permutation seeded `seed`); n < k * 39 only warns (the reference clamps k so that it does not happen);
+  * initial centroids = k training points from a random permutation seeded `seed + 1` (nredo = 1);
+  * niter times: nearest centroid under L2 for every training point (IndexFlatL2), centroid = mean of its points
+    (an empty cluster keeps its centroid), then `split_clusters`: every empty cluster takes a perturbed copy of a
+    cluster picked with probability (size - 1) / (n - k);
+  * every point is then assigned against the final centroids (`kmeans.index.search(x, 1)`).
+faiss seeds its generator identically in every call (seed = 1234), so the subsample and the initial picks are the SAME
+index vectors in every e_step; they are cached here per (n, count, seed).  The random streams themselves are torch's /
+Philox, not faiss' Mersenne twister.  Nothing in an e_step reads anything back to the host (hipGraph-capturable);
+the nearest-centroid search runs on the MFMA tile engine (gcr_kmeans_assign_f32).
 """
 from __future__ import annotations
 
@@ -17,8 +29,29 @@ import torch
 from . import _lib
 from . import functional as Fn
 
+# faiss/Clustering.h `ClusteringParameters` defaults (see the module docstring for provenance)
+FAISS_NITER = 25
+FAISS_SEED = 1234
+FAISS_MIN_POINTS_PER_CENTROID = 39          # ncl.py:350 clamps k with it: max_k = max(2, n // 39)
+FAISS_MAX_POINTS_PER_CENTROID = 256
 
 SORTED_UPDATE_MIN_POINTS = 1 << 16
+
+_PERM_CACHE = {}
+
+
+def _perm_prefix(n, count, seed, device):
+    """First `count` entries of a random permutation of range(n), fixed by `seed` (faiss: `rand_perm(perm, n, seed)`;
+    it re-seeds per call, so the vector is a constant of (n, seed): computed once, kept)."""
+    key = (int(n), int(count), int(seed), str(device))
+    hit = _PERM_CACHE.get(key)
+    if hit is None:
+        g = torch.Generator(device=device).manual_seed(int(seed))
+        hit = torch.randperm(int(n), device=device, generator=g)[: int(count)].contiguous()
+        if len(_PERM_CACHE) >= 16:
+            _PERM_CACHE.pop(next(iter(_PERM_CACHE)))
+        _PERM_CACHE[key] = hit
+    return hit
 
 
 def kmeans_assign(x, centroids, half_sq):
@@ -30,72 +63,49 @@ def kmeans_assign(x, centroids, half_sq):
     return assign
 
 
-def run_kmeans(x, k, niter=20, seed=1234, init_centroids=None, max_points_per_centroid=256):
+def run_kmeans(x, k, niter=FAISS_NITER, seed=FAISS_SEED, init_centroids=None,
+               max_points_per_centroid=FAISS_MAX_POINTS_PER_CENTROID, return_info=False):
     """ncl.py:347-356.  x: float32 [n, d] on the GPU.  Returns (centroids [k', d], assignment int64 [n])
-    with k' = min(k, max(2, n // 39)) exactly as ncl.py:350-351 clamps it."""
+    with k' = min(k, max(2, n // 39)) exactly as ncl.py:350-351 clamps it (and, with return_info, a dict holding the
+    device counter of re-seeded empty clusters).  No host synchronisation."""
     _lib.require_cuda(x)
     if x.dim() != 2 or x.dtype != torch.float32:
         raise ValueError("x must be float32 [n, d]")
     n, d_orig = x.shape
-    k = min(int(k), max(2, n // 39))
+    k = min(int(k), max(2, n // FAISS_MIN_POINTS_PER_CENTROID))
     xp = Fn._pad_dim(x.detach()).contiguous()
-    g = torch.Generator(device=x.device).manual_seed(int(seed))
     xt = xp                                            # training set
     if max_points_per_centroid and n > k * max_points_per_centroid:
-        xt = xp[torch.randperm(n, device=x.device, generator=g)[:k * max_points_per_centroid]]
+        xt = xp[_perm_prefix(n, k * max_points_per_centroid, seed, x.device)]
     n_train = xt.shape[0]
     if init_centroids is None:
-        cent = xt[torch.randperm(n_train, device=x.device, generator=g)[:k]].clone()
+        cent = xt[_perm_prefix(n_train, k, seed + 1, x.device)].clone()
     else:
         cent = Fn._pad_dim(init_centroids.detach().to(torch.float32)).contiguous().clone()
     k = cent.shape[0]
     d = xp.shape[1]
     L = _lib.lib()
-    half_sq = torch.empty(k, dtype=torch.float32, device=x.device)
-    sums = torch.empty(k, d, dtype=torch.float32, device=x.device)
-    counts = torch.empty(k, dtype=torch.float32, device=x.device)
-    stream = _lib.cur_stream(x.device)
-
-    def update(assign, n_rows):
-        if n_rows >= SORTED_UPDATE_MIN_POINTS:
+    dev = x.device
+    half_sq = torch.empty(k, dtype=torch.float32, device=dev)
+    sums = torch.zeros(k, d, dtype=torch.float32, device=dev)      # zero on entry / exit of every lloyd_update
+    counts = torch.zeros(k, dtype=torch.float32, device=dev)
+    n_split = torch.zeros(1, dtype=torch.int32, device=dev)
+    stream = _lib.cur_stream(dev)
+    # 0.5 |c|^2 of the initial centroids (n = 0: refresh only)
+    _lib.check(L.gcr_kmeans_update_f32(None, 0, d, None, k, _lib.dptr(cent), _lib.dptr(half_sq), None, None, stream),
+               "gcr_kmeans_update_f32")
+    for it in range(int(niter)):
+        assign = kmeans_assign(xt, cent, half_sq)
+        keys = perm = None
+        if n_train >= SORTED_UPDATE_MIN_POINTS:
             # points ordered by cluster: one row atomic per run instead of one per point
             keys, perm, _ = Fn._sorted_order(assign, k)
-            _lib.check(L.gcr_kmeans_update_sorted_f32(_lib.dptr(xt), n_rows, d, _lib.dptr(keys), _lib.dptr(perm), k,
-                                                      _lib.dptr(cent), _lib.dptr(half_sq), _lib.dptr(sums),
-                                                      _lib.dptr(counts), stream), "gcr_kmeans_update_sorted_f32")
-            return
-        _lib.check(L.gcr_kmeans_update_f32(_lib.dptr(xt), n_rows, d, _lib.dptr(assign), k, _lib.dptr(cent),
-                                           _lib.dptr(half_sq), _lib.dptr(sums), _lib.dptr(counts), stream),
-                   "gcr_kmeans_update_f32")
-
-    def split_empty(it):
-        """faiss `split_clusters` (Clustering.cpp): every empty cluster takes over a copy of a big cluster's centroid —
-        chosen by walking the clusters and accepting cluster j with probability (size_j - 1) / (n - k) — and the two
-        copies are pushed apart by the symmetric perturbation (1 +- 1/1024) alternating over the dimensions; the sizes
-        are split in half.  Rare (never at the bench sizes), so it runs on the host: one count read-back per iteration."""
-        if not bool((counts == 0).any()):
-            return
-        import numpy as np
-        cnt = counts.cpu().numpy().astype(np.float64)
-        rng = np.random.default_rng(int(seed) * 7919 + it)
-        eps = 1.0 / 1024.0
-        sign = torch.ones(d, device=x.device)
-        sign[1::2] = -1.0
-        for ci in np.nonzero(cnt == 0)[0]:
-            cj = 0
-            for _ in range(64 * k):                       # bounded walk (faiss loops until a draw succeeds)
-                if rng.random() < (cnt[cj] - 1.0) / max(n_train - k, 1):
-                    break
-                cj = (cj + 1) % k
-            cent[ci] = cent[cj] * (1.0 + eps * sign)
-            cent[cj] = cent[cj] * (1.0 - eps * sign)
-            cnt[ci] = cnt[cj] // 2
-            cnt[cj] -= cnt[ci]
-        update(None, 0)                                   # refresh 0.5 |c|^2
-
-    update(None, 0)                      # half_sq of the initial centroids
-    for it in range(niter):
-        update(kmeans_assign(xt, cent, half_sq), n_train)
-        split_empty(it)
+        _lib.check(L.gcr_kmeans_lloyd_update_f32(_lib.dptr(xt), n_train, d, _lib.dptr(assign), _lib.dptr(keys), _lib.dptr(perm),
+                                                 k, _lib.dptr(cent), _lib.dptr(half_sq), _lib.dptr(sums), _lib.dptr(counts),
+                                                 int(seed) & (2 ** 64 - 1), it, _lib.dptr(n_split), stream),
+                   "gcr_kmeans_lloyd_update_f32")
     assign = kmeans_assign(xp, cent, half_sq)       # kmeans.index.search(x, 1) against the final centroids
-    return cent[:, :d_orig].contiguous(), assign
+    cent = cent[:, :d_orig].contiguous()
+    if return_info:
+        return cent, assign, {"n_split": n_split, "n_train": n_train, "k": k}
+    return cent, assign

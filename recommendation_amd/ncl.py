@@ -19,7 +19,8 @@ from . import functional as Fn
 from . import losses as Ls
 from .encoders import Interaction, LGCNEncoder
 from .evaluate import ranking_evaluation, test as rank_test
-from .kmeans import run_kmeans
+from .kmeans import FAISS_NITER, FAISS_SEED, run_kmeans
+from .ncl_step import FusedNCLStep
 from .optim import FusedAdam
 from .sampler import next_batch_pairwise
 
@@ -34,8 +35,17 @@ _CONF_DEFAULTS = {"batch_size": ("batch.size", 2048), "emb_size": ("embedding.si
 
 
 class NCLModel:
-    def __init__(self, conf, train_set, test_set, device=None, seed=0):
+    def __init__(self, conf, train_set, test_set, device=None, seed=0, kmeans_niter=FAISS_NITER, kmeans_seed=FAISS_SEED,
+                 fused_step=True, graph_capture=False):
+        """kmeans_niter / kmeans_seed: the two parameters of `faiss.Kmeans(d, k, gpu=False)` that ncl.py:352 leaves at
+        faiss' defaults (ClusteringParameters: niter = 25, seed = 1234; see kmeans.py for provenance — faiss is absent,
+        parity with it unpinned), explicit here.  fused_step: run the loop body as the hand-derived launch sequence of
+        ncl_step.FusedNCLStep when the configuration allows it (same arithmetic as the autograd path);
+        graph_capture: replay that sequence from a hipGraph."""
         self.config, self.seed = conf, seed
+        self.kmeans_niter, self.kmeans_seed = int(kmeans_niter), int(kmeans_seed)
+        self.fused_step, self.graph_capture = bool(fused_step), bool(graph_capture)
+        self._fused = None
         self.model_name = conf.get("model", {}).get("name", "NCL")
         for attr, (key, default) in _CONF_DEFAULTS.items():
             setattr(self, attr, conf.get(key, default))
@@ -43,10 +53,21 @@ class NCLModel:
             setattr(self, attr, conf["NCL"][key])
         self.topN = list(map(int, self.ranking))
         self.max_N = max(self.topN)
-        self.data = Interaction(conf, train_set, test_set, device=device)
+        # `train_set` may be a prepared data object (user_num, item_num, norm_adj, device, ...) instead of the triple list:
+        # NCLModel.from_graph builds one around a device-resident operator (graphs too large for Python id maps)
+        self.data = train_set if hasattr(train_set, "norm_adj") else Interaction(conf, train_set, test_set, device=device)
         self.model = LGCNEncoder(self.data, self.emb_size, self.n_layers)
         self.user_centroids = self.user_2cluster = self.item_centroids = self.item_2cluster = None
         self.bestPerformance = []
+
+    @classmethod
+    def from_graph(cls, conf, norm_adj, user_num, item_num, **kw):
+        """NCLModel over an operator that already lives on the device (bench.py's 1M x 100K graph): everything the
+        training step reads from `Interaction` — sizes, the operator, the device — without the Python id maps."""
+        import types
+        data = types.SimpleNamespace(user_num=int(user_num), item_num=int(item_num), norm_adj=norm_adj, device=norm_adj.device,
+                                     test_set={}, training_set_u={}, user={}, item={})
+        return cls(conf, data, None, device=norm_adj.device, **kw)
 
     # ncl.py:340-356
     def e_step(self, user_emb=None, item_emb=None):
@@ -59,9 +80,12 @@ class NCLModel:
             user_emb, item_emb = user_emb.detach(), item_emb.detach()
             # ncl.py:350-351 clamps `self.k = min(self.k, max(2, n // 39))` and KEEPS it: the item k-means
             # inherits the users' clamp and, from the second e_step on, the users inherit the items'
-            self.user_centroids, self.user_2cluster = run_kmeans(user_emb.contiguous(), self.k, seed=self.seed)
+            # ncl.py:352 builds a fresh faiss.Kmeans for each table: both run with the same seed
+            self.user_centroids, self.user_2cluster = run_kmeans(user_emb.contiguous(), self.k, niter=self.kmeans_niter,
+                                                                 seed=self.kmeans_seed)
             self.k = int(self.user_centroids.shape[0])
-            self.item_centroids, self.item_2cluster = run_kmeans(item_emb.contiguous(), self.k, seed=self.seed + 1)
+            self.item_centroids, self.item_2cluster = run_kmeans(item_emb.contiguous(), self.k, niter=self.kmeans_niter,
+                                                                 seed=self.kmeans_seed)
             self.k = int(self.item_centroids.shape[0])
 
     # ncl.py:358-367
@@ -74,13 +98,26 @@ class NCLModel:
                                 self.user_2cluster, self.item_centroids, self.item_2cluster, self.ssl_temp,
                                 self.proto_reg, self.batch_size)
 
-    def train_step(self, batch, optimizer):
+    def train_step(self, batch, optimizer, check_negatives=True, fused=None):
         """One iteration of the loop body ncl.py:311-329.  A batch with an unfilled negative slot (-1, the
         sampler's 100-trial bail-out) is skipped like the reference does (ncl.py:113: it is never yielded);
-        returns None then."""
+        returns None then (check_negatives=False: the caller's sampler has already dropped such batches —
+        `next_batch_pairwise` does — and the step starts without a host read-back).
+        fused (default: self.fused_step): the hand-derived launch sequence of ncl_step.FusedNCLStep."""
         user_idx, pos_idx, neg_idx = batch
-        if bool((torch.as_tensor(neg_idx) < 0).any()):
+        if check_negatives and bool((torch.as_tensor(neg_idx) < 0).any()):
             return None
+        fused = self.fused_step if fused is None else fused
+        if fused and FusedNCLStep.supported(self):
+            if self._fused is None or self._fused.opt is not optimizer:
+                self._fused = FusedNCLStep(self, optimizer)
+                if self.graph_capture:
+                    self._fused.capture(len(user_idx))
+            dev = self.model.table.device
+            idx = [torch.as_tensor(t, device=dev, dtype=torch.int64).contiguous() for t in (user_idx, pos_idx, neg_idx)]
+            if self.graph_capture and self._fused.capturable_for(len(user_idx)):
+                return self._fused.replay(*idx)
+            return self._fused(*idx)
         rec_user_emb, rec_item_emb, emb_list = self.model()
         # ncl.py:314-317 gathers three [B, d] row blocks and feeds bpr_loss / l2_reg_loss; here the gathers, the BPR
         # terms and the three squared norms come out of ONE kernel (gcr_bpr_fwd_f32) and its backward scatters row
@@ -102,13 +139,14 @@ class NCLModel:
         return rec_loss, ssl_loss, proto_loss, total
 
     def train(self):
-        optimizer = FusedAdam(self.model.parameters(), lr=self.lRate)      # ncl.py:305 torch.optim.Adam: gcr_adam_step_f32
+        # ncl.py:305 torch.optim.Adam: gcr_adam_step_f32 (step count on the device when the step is replayed from a graph)
+        optimizer = FusedAdam(self.model.parameters(), lr=self.lRate, capturable=self.graph_capture)
         self.model.train()
         for epoch in range(self.max_epoch):
             self.e_step()
             batches = next_batch_pairwise(self.data, self.batch_size, seed=self.seed, epoch=epoch)
             for n, batch in enumerate(batches):
-                out = self.train_step(batch, optimizer)
+                out = self.train_step(batch, optimizer, check_negatives=False)
                 if out is not None and n % 100 == 99:
                     names = ("Rec_loss", "ssl_loss", "Proto_loss", "Total_loss")
                     print(f"Batch {n + 1}: " + ", ".join(f"{k}={float(v):.4f}" for k, v in zip(names, out)))

@@ -1,0 +1,250 @@
+"""One NCL training iteration (the loop body ncl.py:311-329) as a fixed, hand-derived launch sequence.
+
+`NCLModel.train_step` through autograd is the general path (any loss mix); this is the same arithmetic for the
+reference's fixed recipe — LightGCN propagation + BPR + structure contrast + per-batch e_step + prototype contrast +
+Adam — with the backward written out, so that no gradient ever takes a detour through a dense zero-filled [N, d]
+buffer or a separate add pass:
+
+  forward   y_k = A y_{k-1} (gcr_spmm_csr_acc2_f32, running mean fused), BPR sums (gcr_bpr_fwd_f32), structure contrast
+            as the flash-style forward (lse + softmax-weighted row sum, gcr_infonce_fwd_o_f32), e_step (kmeans.py, no host
+            read-back), prototype contrast (B x B)
+  backward  G0  = d loss / d x0 through the layer-0 table of the structure contrast: ONE [N, d] buffer written by the two
+                  table-side launches (users -> rows [0, U), items -> rows [U, N)), positives and F.normalize's backward
+                  in place, the prototype rows' gradients scattered on top                       (ncl.py:358-375)
+            Zg  = d loss / d final from BPR, scattered into the step's only zero-filled buffer      (ncl.py:314-317)
+            Horner recurrence of the K-layer pass on A^T:  h_K = Zg (+ g_ctx / c if the context layer is the last),
+                  h_k = Zg + A^T h_{k+1}, with the context rows' sparse gradient ADDED AFTER the launch that produces
+                  its layer's h (4096 row atomics instead of a dense addend), dx0 = c (Zg + G0 / c + A^T h_1): the last
+                  launch takes G0 as the epilogue's second addend                                   (ncl.py:415-422)
+            Adam (gcr_adam_step_f32 / _dev_f32) on the two parameter views of the stacked table      (ncl.py:305,327-329)
+
+Nothing in here synchronises with the host or depends on host-side values that change between steps, so the whole step
+can be captured in a hipGraph (`capture()`): batch indices live in static buffers, Adam's step count on the device.
+Checked against the autograd path by tests/test_ncl_step_gpu.py (same losses, same parameter update).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from . import functional as Fn
+
+
+class FusedNCLStep:
+    def __init__(self, owner, optimizer):
+        """owner: NCLModel (reads n_layers / hyper_layers / ssl_temp / ssl_reg / alpha / proto_reg / reg / batch_size and
+        calls owner.e_step); optimizer: FusedAdam over owner.model.parameters()."""
+        self.owner, self.opt = owner, optimizer
+        enc = owner.model
+        self.enc, self.graph = enc, enc.norm_adj
+        self.n_u, self.n_i = owner.data.user_num, owner.data.item_num
+        self._graph = None
+        self._static = None
+        # False: leave the per-batch e_step (ncl.py:324) out and contrast against the centroids the owner already holds —
+        # NOT the reference's loop body; bench.py uses it to report the e_step's share of the step
+        self.e_step_every_batch = True
+
+    @staticmethod
+    def supported(owner):
+        enc = owner.model
+        d, k = enc.latent_size, enc.layers
+        if not hasattr(enc, "table") or d not in Fn._MFMA_DIMS or k < 1 or owner.hyper_layers < 1:
+            return False
+        if not enc.table.is_cuda:
+            return False
+        eng = Fn._resolve_engine(unit_rows=True)
+        return Fn.infonce_fwd_o_supported(d, eng) and 1.0 / float(owner.ssl_temp) > 0
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _contrast_fwd(self, a, sa, b, sb, pos, inv_tau, eng, lse, o, pl):
+        Fn.infonce_fwd_o_raw(a, sa, b, sb, inv_tau, engine_flag=eng, lse_out=lse, o_out=o)
+        Fn.pos_logit_raw(a, sa, b, sb, pos, inv_tau, out=pl)
+
+    def __call__(self, user_idx, pos_idx, neg_idx):
+        """user_idx / pos_idx / neg_idx: int64 device tensors [B] (a batch of next_batch_pairwise).  Returns
+        (rec_loss, ssl_loss, proto_loss, total) as device scalars; the parameters are updated."""
+        o_ = self.owner
+        enc, graph, n_u, n_i = self.enc, self.graph, self.n_u, self.n_i
+        L = _lib.lib()
+        x0 = enc.table
+        dev = x0.device
+        n, d = x0.shape
+        K = enc.layers
+        c = 1.0 / (K + 1)
+        inv_c = float(K + 1)
+        ci = K if o_.hyper_layers * 2 >= K + 1 else o_.hyper_layers * 2          # ncl.py:319-322
+        stream = _lib.cur_stream(dev)
+        bsz = user_idx.numel()
+        inv_tau = 1.0 / float(o_.ssl_temp)
+        eng = Fn._resolve_engine(unit_rows=True)
+        gat = torch.cat([user_idx, pos_idx + n_u])                                # rows of the stacked table
+
+        # ---- forward: K-layer message pass, mean of the K + 1 layer outputs in the epilogue (ncl.py:415-422) ----
+        cur, acc, ctx_rows = x0, x0, None
+        for k in range(1, K + 1):
+            last = k == K
+            need_y = (not last) or ci == K
+            y = torch.empty_like(x0) if need_y else None
+            acc_out = torch.empty_like(x0) if k == 1 else acc
+            Fn.spmm_into(graph, cur, y=y, acc_in=acc, acc_out=acc_out, acc_scale=c if last else 1.0)
+            acc = acc_out
+            if need_y:
+                cur = y
+            if k == ci:
+                ctx_layer = y
+        final = acc
+        fu, fi = final[:n_u], final[n_u:]
+
+        # ---- BPR + the three squared norms of l2_reg_loss (ncl.py:314-317,116-123) ----
+        dldx = torch.empty(max(bsz, 1), dtype=torch.float32, device=dev)
+        sums = torch.zeros(5, dtype=torch.float32, device=dev)
+        ws = torch.empty(int(L.gcr_bpr_workspace_floats(bsz)), dtype=torch.float32, device=dev)
+        _lib.check(L.gcr_bpr_fwd_f32(_lib.dptr(fu), _lib.dptr(fi), d, _lib.dptr(user_idx), _lib.dptr(pos_idx), _lib.dptr(neg_idx),
+                                     bsz, 1, Fn.BPR_NCL, n_u, n_i, _lib.dptr(dldx), _lib.dptr(sums), _lib.dptr(ws), stream),
+                   "gcr_bpr_fwd_f32")
+        rec_loss = sums[0] / bsz
+        roots = sums[1:4].sqrt()
+        l2 = o_.reg * roots.sum() / bsz                                            # l2_reg_loss(reg, u, p, n)
+        # d total / d sums: total = sums[0] / B + reg (sqrt s1 + sqrt s2 + sqrt s3) / B / batch_size + ...
+        gs = torch.zeros(5, dtype=torch.float32, device=dev)
+        gs[0] = 1.0 / bsz
+        gs[1:4] = (0.5 * o_.reg / (bsz * o_.batch_size)) / roots
+
+        # ---- structure contrast (ncl.py:358-367): batch rows of the context layer against ALL layer-0 rows ----
+        rows_c = torch.empty(2 * bsz, d, dtype=torch.float32, device=dev)
+        _lib.check(L.gcr_gather_rows_f32(_lib.dptr(ctx_layer), _lib.dptr(gat), 2 * bsz, d, n, _lib.dptr(rows_c), stream),
+                   "gcr_gather_rows_f32")
+        sa = Fn.row_inv_norm(rows_c)
+        sb = Fn.row_inv_norm(x0)                                                   # F.normalize(iu) / F.normalize(ii)
+        lse = torch.empty(2 * bsz, dtype=torch.float32, device=dev)
+        pl = torch.empty(2 * bsz, dtype=torch.float32, device=dev)
+        o = torch.empty(2 * bsz, d, dtype=torch.float32, device=dev)
+        xu, xi, sbu, sbi = x0[:n_u], x0[n_u:], sb[:n_u], sb[n_u:]
+        self._contrast_fwd(rows_c[:bsz], sa[:bsz], xu, sbu, user_idx, inv_tau, eng, lse[:bsz], o[:bsz], pl[:bsz])
+        self._contrast_fwd(rows_c[bsz:], sa[bsz:], xi, sbi, pos_idx, inv_tau, eng, lse[bsz:], o[bsz:], pl[bsz:])
+        w = torch.empty(2 * bsz, dtype=torch.float32, device=dev)                  # d total / d lse  (= - d total / d pos)
+        w[:bsz] = o_.ssl_reg
+        w[bsz:] = o_.ssl_reg * o_.alpha
+        ssl_loss = ((lse - pl) * w).sum()
+
+        # ---- e_step (ncl.py:324, every batch): k-means of the CURRENT encoder outputs, no host read-back ----
+        if self.e_step_every_batch:
+            o_.e_step(fu, fi)
+
+        # ---- prototype contrast (ncl.py:369-375): InfoNCE(e0[idx], centroid of idx's cluster) * batch_size ----
+        rows_0 = torch.empty(2 * bsz, d, dtype=torch.float32, device=dev)
+        _lib.check(L.gcr_gather_rows_f32(_lib.dptr(x0), _lib.dptr(gat), 2 * bsz, d, n, _lib.dptr(rows_0), stream),
+                   "gcr_gather_rows_f32")
+        cents = torch.cat([o_.user_centroids[o_.user_2cluster[user_idx]], o_.item_centroids[o_.item_2cluster[pos_idx]]])
+        s0, sc = Fn.row_inv_norm(rows_0), Fn.row_inv_norm(cents)
+        lse_p = torch.empty(2 * bsz, dtype=torch.float32, device=dev)
+        pl_p = torch.empty(2 * bsz, dtype=torch.float32, device=dev)
+        o_p = torch.empty(2 * bsz, d, dtype=torch.float32, device=dev)
+        for lo in (0, bsz):
+            sl = slice(lo, lo + bsz)
+            self._contrast_fwd(rows_0[sl], s0[sl], cents[sl], sc[sl], None, inv_tau, eng, lse_p[sl], o_p[sl], pl_p[sl])
+        wp = o_.proto_reg * o_.batch_size / bsz                                    # mean over the batch, * batch_size
+        proto_loss = wp * (lse_p - pl_p).sum()
+        total = rec_loss + l2 / o_.batch_size + ssl_loss + proto_loss
+
+        # =================================== backward ===================================
+        # G0: gradient w.r.t. the layer-0 table through the structure contrast's candidate side
+        g0 = torch.empty_like(x0)
+        Fn._infonce_bwd_raw(xu, sbu, rows_c[:bsz], sa[:bsz], inv_tau, None, None, lse[:bsz], w[:bsz], engine_flag=eng, out=g0[:n_u])
+        Fn._infonce_bwd_raw(xi, sbi, rows_c[bsz:], sa[bsz:], inv_tau, None, None, lse[bsz:], w[bsz:], engine_flag=eng, out=g0[n_u:])
+        # anchor side: softmax part = w * inv_tau * o (the flash forward kept o), positives added, then F.normalize backward
+        ga = o * (w * inv_tau).unsqueeze(1)
+        neg_w = -w
+        for a_sl, tab, stab, pos, g_tab in ((slice(0, bsz), xu, sbu, user_idx, g0[:n_u]), (slice(bsz, 2 * bsz), xi, sbi, pos_idx, g0[n_u:])):
+            _lib.check(L.gcr_infonce_pos_bwd_f32(_lib.dptr(rows_c[a_sl]), _lib.dptr(sa[a_sl]), _lib.dptr(tab), _lib.dptr(stab),
+                                                 _lib.dptr(pos), _lib.dptr(neg_w[a_sl]), bsz, tab.shape[0], d, inv_tau,
+                                                 _lib.dptr(ga[a_sl]), _lib.dptr(g_tab), stream), "gcr_infonce_pos_bwd_f32")
+        _lib.check(L.gcr_normalize_bwd_f32(_lib.dptr(rows_c), _lib.dptr(sa), _lib.dptr(ga), 2 * bsz, d, _lib.dptr(ga), stream),
+                   "gcr_normalize_bwd_f32")
+        _lib.check(L.gcr_normalize_bwd_f32(_lib.dptr(x0), _lib.dptr(sb), _lib.dptr(g0), n, d, _lib.dptr(g0), stream),
+                   "gcr_normalize_bwd_f32")
+        # prototype rows: only the anchors get a gradient (the centroids are constants of the e_step)
+        gp = o_p * (wp * inv_tau)
+        neg_wp = torch.full((2 * bsz,), -wp, dtype=torch.float32, device=dev)
+        for lo in (0, bsz):
+            sl = slice(lo, lo + bsz)
+            _lib.check(L.gcr_infonce_pos_bwd_f32(_lib.dptr(rows_0[sl]), _lib.dptr(s0[sl]), _lib.dptr(cents[sl]), _lib.dptr(sc[sl]),
+                                                 None, _lib.dptr(neg_wp[sl]), bsz, bsz, d, inv_tau, _lib.dptr(gp[sl]), None,
+                                                 stream), "gcr_infonce_pos_bwd_f32")
+        _lib.check(L.gcr_normalize_bwd_f32(_lib.dptr(rows_0), _lib.dptr(s0), _lib.dptr(gp), 2 * bsz, d, _lib.dptr(gp), stream),
+                   "gcr_normalize_bwd_f32")
+        _lib.check(L.gcr_scatter_add_rows_f32(_lib.dptr(gp), _lib.dptr(gat), 2 * bsz, d, n, _lib.dptr(g0), stream),
+                   "gcr_scatter_add_rows_f32")
+
+        # Zg: d total / d final (BPR rows), the only zero-filled [N, d] buffer of the step
+        zg = torch.zeros_like(x0)
+        _lib.check(L.gcr_bpr_bwd_f32(_lib.dptr(fu), _lib.dptr(fi), d, _lib.dptr(user_idx), _lib.dptr(pos_idx), _lib.dptr(neg_idx),
+                                     bsz, 1, n_u, n_i, _lib.dptr(dldx), _lib.dptr(gs), _lib.dptr(zg[:n_u]), _lib.dptr(zg[n_u:]),
+                                     stream), "gcr_bpr_bwd_f32")
+        # Horner recurrence on A^T in h' = h / c:  h'_K = Zg + g_K / c,  h'_k = Zg + g_k / c + A^T h'_{k+1},  dx0 = c h'_0 + G0
+        gt = graph.t
+        ga_c = ga * inv_c
+
+        def add_ctx(buf):
+            _lib.check(L.gcr_scatter_add_rows_f32(_lib.dptr(ga_c), _lib.dptr(gat), 2 * bsz, d, n, _lib.dptr(buf), stream),
+                       "gcr_scatter_add_rows_f32")
+
+        h = zg
+        if ci == K:
+            h = zg.clone()
+            add_ctx(h)
+        for k in range(K - 1, 0, -1):
+            out = torch.empty_like(x0)
+            Fn.spmm_into(gt, h, acc_in=zg, acc_out=out)
+            if k == ci:
+                add_ctx(out)                       # the context layer's sparse gradient joins h_k after the launch
+            h = out
+        dx0 = torch.empty_like(x0)
+        Fn.spmm_into(gt, h, acc_in=zg, acc_in2=g0, acc_in2_scale=inv_c, acc_out=dx0, acc_scale=c)
+
+        # ---- Adam on the two parameter views of the stacked table (ncl.py:327-329) ----
+        pu, pi = enc.embedding_dict["user_emb"], enc.embedding_dict["item_emb"]
+        pu.grad, pi.grad = dx0[:n_u], dx0[n_u:]
+        self.opt.step()
+        return rec_loss, ssl_loss, proto_loss, total
+
+    # ------------------------------------------------------------------------------------------------------------
+    def capture(self, batch_size, warmup=2):
+        """Arms hipGraph replay (torch.cuda.CUDAGraph) of the step over static index buffers of `batch_size` entries:
+        `replay(user_idx, pos_idx, neg_idx)` copies a batch in; its first `warmup` calls run eagerly on a side stream
+        (allocator warm-up, cached k-means index vectors, Adam state), the next one captures, every call trains on
+        exactly one batch.  The optimizer must be capturable (device step count)."""
+        dev = self.enc.table.device
+        if not all(g.get("capturable") for g in self.opt.param_groups):
+            raise ValueError("capture() needs FusedAdam(capturable=True)")
+        z = torch.zeros(int(batch_size), dtype=torch.int64, device=dev)
+        self._static = [z.clone(), z.clone(), z.clone()]
+        self._graph, self._warm, self._warmup, self._out = None, 0, int(warmup), None
+        return self
+
+    def capturable_for(self, batch_size):
+        """A graph replays ONE batch size (the epoch's ragged last batch runs eagerly)."""
+        return self._static is not None and self._static[0].numel() == int(batch_size)
+
+    def replay(self, user_idx, pos_idx, neg_idx):
+        st = self._static
+        if st is None:
+            raise RuntimeError("call capture(batch_size) first")
+        dev = st[0].device
+        for dst, src in zip(st, (user_idx, pos_idx, neg_idx)):
+            dst.copy_(torch.as_tensor(src, device=dev), non_blocking=True)
+        if self._graph is None:
+            if self._warm < self._warmup:
+                s = torch.cuda.Stream(device=dev)
+                s.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(s):
+                    out = self(*st)
+                torch.cuda.current_stream(dev).wait_stream(s)
+                self._warm += 1
+                return out
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._out = self(*st)
+            self._graph = g               # capturing does not execute: the replay below trains on this batch
+        self._graph.replay()
+        return self._out

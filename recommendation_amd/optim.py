@@ -10,10 +10,12 @@ from . import _lib
 
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, capturable=False):
+        """capturable: keep the step count in device memory (gcr_adam_step_dev_f32), so that a step captured in a
+        hipGraph replays with the current bias corrections (torch.optim.Adam's flag of the same name)."""
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1 and 0 <= betas[1] < 1) or weight_decay < 0:
             raise ValueError("invalid Adam hyper-parameters")
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, capturable=bool(capturable)))
 
     @torch.no_grad()
     def step(self, closure=None, extra_grads=None):
@@ -43,6 +45,16 @@ class FusedAdam(torch.optim.Optimizer):
                     raise ValueError("at most two extra gradient pieces")
                 g = p.grad.contiguous()
                 ex = [e.contiguous() for e in extra] + [None, None]
+                if group.get("capturable"):
+                    if "step_dev" not in st:
+                        st["step_dev"] = torch.full((1,), st["step"] - 1, dtype=torch.int64, device=p.device)
+                    st["step_dev"].add_(1)
+                    _lib.check(L.gcr_adam_step_dev_f32(_lib.dptr(p), _lib.dptr(g), _lib.dptr(ex[0]), _lib.dptr(ex[1]),
+                                                       _lib.dptr(st["exp_avg"]), _lib.dptr(st["exp_avg_sq"]), p.numel(),
+                                                       float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                                       float(group["weight_decay"]), _lib.dptr(st["step_dev"]), 1.0,
+                                                       _lib.cur_stream(p.device)), "gcr_adam_step_dev_f32")
+                    continue
                 _lib.check(L.gcr_adam_step_f32(_lib.dptr(p), _lib.dptr(g), _lib.dptr(ex[0]), _lib.dptr(ex[1]),
                                                _lib.dptr(st["exp_avg"]), _lib.dptr(st["exp_avg_sq"]), p.numel(),
                                                float(group["lr"]), float(b1), float(b2), float(group["eps"]),

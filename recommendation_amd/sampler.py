@@ -14,7 +14,7 @@ from . import functional as Fn
 _MASK64 = 2 ** 64 - 1
 
 
-def next_batch_pairwise(data, batch_size, n_negs=1, *, seed=0, epoch=0, max_trials=101, drop_incomplete=True):
+def next_batch_pairwise(data, batch_size, n_negs=1, *, seed=0, epoch=0, max_trials=101, drop_incomplete=True, prefetch=32):
     """Yields (u_idx, i_idx, j_idx) int64 device tensors per batch of shuffled training pairs
     (j_idx has batch * n_negs entries, ssl4rec.py:43-47).  Negatives are uniform over items and
     never a training positive of the user; `max_trials` = 101 and `drop_incomplete` restate ncl.py's
@@ -26,14 +26,28 @@ def next_batch_pairwise(data, batch_size, n_negs=1, *, seed=0, epoch=0, max_tria
     g = torch.Generator(device=dev).manual_seed((int(seed) * 1_000_003 + int(epoch)) & (2 ** 63 - 1))
     perm = torch.randperm(n, device=dev, generator=g)
     base = (int(epoch) << 40) & _MASK64
-    for ptr in range(0, n, batch_size):
-        sel = perm[ptr:ptr + batch_size]
-        u_idx, i_idx = data.uid_dev[sel], data.iid_dev[sel]
-        j_idx = Fn.neg_sample(data.user_rowptr, data.user_items_sorted, u_idx, n_negs, data.item_num,
-                              seed, base + ptr * n_negs, max_trials)
-        if max_trials > 0 and drop_incomplete and bool((j_idx < 0).any()):
-            continue
-        yield u_idx, i_idx, j_idx
+    # negatives are drawn for `chunk` batches per launch (slot s of the epoch uses the same counter whatever the launch
+    # boundaries, so the draws equal the per-batch ones) and the incomplete-batch test is ONE read-back per chunk
+    # instead of one per batch — a per-batch read-back would drain the stream in front of every training step
+    chunk = max(1, int(prefetch)) * batch_size
+    for c0 in range(0, n, chunk):
+        sel_c = perm[c0:c0 + chunk]
+        u_c, i_c = data.uid_dev[sel_c], data.iid_dev[sel_c]
+        j_c = Fn.neg_sample(data.user_rowptr, data.user_items_sorted, u_c, n_negs, data.item_num,
+                            seed, base + c0 * n_negs, max_trials)
+        n_b = (sel_c.numel() + batch_size - 1) // batch_size
+        bad = None
+        if max_trials > 0 and drop_incomplete:
+            miss = (j_c < 0).view(-1, n_negs).any(1)
+            pad = n_b * batch_size - miss.numel()
+            if pad:
+                miss = torch.cat([miss, miss.new_zeros(pad)])
+            bad = miss.view(n_b, batch_size).any(1).tolist()
+        for b in range(n_b):
+            if bad is not None and bad[b]:
+                continue
+            lo, hi = b * batch_size, min((b + 1) * batch_size, sel_c.numel())
+            yield u_c[lo:hi], i_c[lo:hi], j_c[lo * n_negs:hi * n_negs]
 
 
 def randint_negatives(num_samples, num_items, n_neg=1, *, seed=0, step=0, device="cuda"):

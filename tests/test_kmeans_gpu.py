@@ -111,7 +111,59 @@ def test_empty_cluster_is_reseeded_from_a_big_one():
     centers = rng.standard_normal((3, d)) * 5
     x = (centers[rng.integers(0, 3, 3000)] + 0.3 * rng.standard_normal((3000, d))).astype(np.float32)
     init = np.concatenate([centers, np.full((1, d), 1e3)]).astype(np.float32)      # the 4th start is far from every point
-    cent, assign = run_kmeans(torch.from_numpy(x).cuda(), k, niter=10, init_centroids=torch.from_numpy(init).cuda())
+    cent, assign, info = run_kmeans(torch.from_numpy(x).cuda(), k, niter=10, init_centroids=torch.from_numpy(init).cuda(),
+                                    return_info=True)
     counts = np.bincount(assign.cpu().numpy(), minlength=k)
     assert (counts > 0).all(), counts
     assert float(cent.abs().max()) < 100.0                  # the dead centroid at 1e3 is gone
+    assert int(info["n_split"]) >= 1                        # counted on the device, never read during the iterations
+
+
+def test_split_step_matches_restatement_bit_for_bit():
+    """One Lloyd update with forced empty clusters against oracle_np.kmeans_split_clusters: same Philox trials, so the
+    SAME donor clusters are picked and the perturbed centroids agree to fp32 rounding; no empty cluster is left after
+    one more iteration (the re-seed must never be a no-op)."""
+    from recommendation_amd.kmeans import run_kmeans
+    rng = np.random.default_rng(7)
+    d, k, n = 64, 12, 6000
+    centers = rng.standard_normal((8, d)) * 5
+    lab = rng.integers(0, 8, n)
+    x = (centers[lab] + 0.3 * rng.standard_normal((n, d))).astype(np.float32)
+    far = 1e3 * (1 + np.arange(4))[:, None] * np.ones((4, d))
+    init = np.concatenate([centers, far]).astype(np.float32)                      # clusters 8..11 start dead
+    for seed in (1234, 99):
+        cent, assign, info = run_kmeans(torch.from_numpy(x).cuda(), k, niter=1, seed=seed,
+                                        init_centroids=torch.from_numpy(init).cuda(), max_points_per_centroid=0,
+                                        return_info=True)
+        ns = []
+        ref_c, ref_a = O.kmeans_lloyd(x, init, niter=1, split_seed=seed, n_split_out=ns)
+        assert int(info["n_split"]) == ns[0] == 4
+        np.testing.assert_allclose(cent.cpu().numpy(), ref_c, rtol=2e-6, atol=1e-6)
+        cent2, assign2 = run_kmeans(torch.from_numpy(x).cuda(), k, niter=2, seed=seed,
+                                    init_centroids=torch.from_numpy(init).cuda(), max_points_per_centroid=0)
+        assert (np.bincount(assign2.cpu().numpy(), minlength=k) > 0).all()
+
+
+def test_split_falls_back_to_the_largest_cluster():
+    """n == k: the acceptance probability (size - 1) / (n - k) is undefined, no walk can end, and the re-seed falls back
+    to the largest cluster (never a no-op, never a cluster with <= 1 point)."""
+    from recommendation_amd import _lib
+    k, d = 5, 64
+    cent = torch.arange(k * d, dtype=torch.float32, device="cuda").reshape(k, d) / 100 + 1
+    half = torch.empty(k, device="cuda")
+    sums = torch.zeros(k, d, device="cuda")
+    counts = torch.zeros(k, device="cuda")
+    x = cent[[0, 1, 2, 3, 3]].clone().contiguous()
+    assign = torch.tensor([0, 1, 2, 3, 3], device="cuda")
+    ns = torch.zeros(1, dtype=torch.int32, device="cuda")
+    L = _lib.lib()
+    _lib.check(L.gcr_kmeans_lloyd_update_f32(_lib.dptr(x), 5, d, _lib.dptr(assign), None, None, k, _lib.dptr(cent), _lib.dptr(half),
+                                             _lib.dptr(sums), _lib.dptr(counts), 1234, 0, _lib.dptr(ns), _lib.cur_stream()), "lloyd")
+    ref_c = (np.arange(k * d, dtype=np.float64).reshape(k, d) / 100 + 1).astype(np.float32).astype(np.float64)
+    cnt = np.array([1, 1, 1, 2, 0], dtype=np.float64)
+    assert O.kmeans_split_clusters(ref_c, cnt, 5, 1234, 0) == 1
+    assert cnt.tolist() == [1, 1, 1, 1, 1]
+    assert int(ns) == 1
+    np.testing.assert_allclose(cent.cpu().numpy(), ref_c, rtol=2e-6)
+    np.testing.assert_allclose(half.cpu().numpy(), 0.5 * (ref_c ** 2).sum(1), rtol=1e-5)
+    assert float(counts.abs().sum()) == 0.0 and float(sums.abs().sum()) == 0.0      # scratch left zeroed

@@ -85,6 +85,13 @@ class ShardedBipartiteGraph:
         self.items_per_rank, self.rank, self.world, self.group = items_per_rank, rank, world, group
         self.items_padded = items_per_rank * world
         self.buffers = _Buffers()
+        self._comm_stream = None
+
+    def comm_stream(self, device):
+        """The side stream the item-shard chain (all-gather -> reduce-scatter -> shard update) is issued from."""
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=device)
+        return self._comm_stream
 
     @classmethod
     def from_local_interactions(cls, local_uid, iid, n_local_users, num_items, user_deg, item_deg_global, rank, world,
@@ -174,6 +181,8 @@ def sharded_propagate_raw(g: ShardedBipartiteGraph, x_user, x_item_shard, n_laye
     z_u, z_i = x_user, x_item_shard
     multi = _multi(world)
     pooled = multi and spmm is _hip_spmm              # injected (test) SpMMs allocate their own outputs
+    if pooled and overlap and dev.type == "cuda":
+        return _propagate_two_streams(g, x_user, x_item_shard, n_layers, scale, kw_iu, kw_ui)
     z_item_full = g.buffers.get("z_item_full", g.items_padded, d, dev) if multi else None
     part_buf = g.buffers.get("part_i", g.items_padded, d, dev) if pooled else None
     y_buf = g.buffers.get("y_i", g.items_per_rank, d, dev) if multi else None
@@ -199,6 +208,48 @@ def sharded_propagate_raw(g: ShardedBipartiteGraph, x_user, x_item_shard, n_laye
             h_rs.wait()
         z_i = (x_item_shard + y_i) * s if s != 1.0 else x_item_shard + y_i
         z_u = z_u_next
+    return z_u, z_i
+
+
+def _propagate_two_streams(g, x_user, x_item_shard, n_layers, scale, kw_iu, kw_ui):
+    """The overlapped schedule on two HIP streams with double-buffered staging.
+
+    main stream:  P_i(k) = R_g^T z_u(k)  ->  [wait AG(k)]  z_u(k+1) = x_u + R_g Z_i(k)
+    side stream:  AG(k): Z_i(k) <- shards z_i(k)  ->  [wait P_i(k)]  RS(k): y_i <- sum_ranks P_i(k)  ->  z_i(k+1) = x_i + y_i
+
+    The item-shard chain AG -> RS -> update -> AG ... lives on the side stream, so the all-gather of layer k + 1 starts as
+    soon as the reduce-scatter of layer k has landed — it no longer queues behind the user-side SpMM of layer k, which is
+    what a single gathered buffer (and collectives issued from the compute stream) forced.  Two gathered tables and two
+    partial-sum buffers alternate by layer parity; reuse distances, each ordered by an event that is already in the
+    schedule: Z_i[p] is rewritten by AG(k + 2), issued behind RS(k + 1), which waited for P_i(k + 1), which follows the
+    user-side SpMM(k) that read it; P_i[p] is rewritten by the item-side SpMM(k + 2), issued behind main's wait for
+    AG(k + 1), which follows RS(k) that read it."""
+    dev, d = x_user.device, x_user.shape[1]
+    main = torch.cuda.current_stream(dev)
+    side = g.comm_stream(dev)
+    z_full = [g.buffers.get(f"z_item_full{p}", g.items_padded, d, dev) for p in (0, 1)]
+    part = [g.buffers.get(f"part_i{p}", g.items_padded, d, dev) for p in (0, 1)]
+    y_buf = g.buffers.get("y_i", g.items_per_rank, d, dev)
+    z_u, z_i = x_user, x_item_shard.contiguous()
+    side.wait_stream(main)                                  # the inputs (and the pooled buffers' last users) are done
+    for k in range(n_layers):
+        p = k & 1
+        s = scale if k == n_layers - 1 else 1.0
+        with torch.cuda.stream(side):
+            _all_gather(z_full[p], z_i, g.group, False)
+            ev_ag = torch.cuda.Event()
+            ev_ag.record(side)
+        _hip_spmm(g.r_iu, z_u, y_out=part[p], **kw_iu)                    # item side: local users only
+        ev_part = torch.cuda.Event()
+        ev_part.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(ev_part)
+            _reduce_scatter(y_buf, part[p], g.group, False)
+            z_i = (x_item_shard + y_buf) * s if s != 1.0 else x_item_shard + y_buf
+        main.wait_event(ev_ag)
+        _, z_u = _hip_spmm(g.r_ui, z_full[p], acc_in=x_user, acc_scale=s, want_y=False, **kw_ui)
+    main.wait_stream(side)
+    z_i.record_stream(main)                                 # allocated under the side stream, handed to the caller's
     return z_u, z_i
 
 

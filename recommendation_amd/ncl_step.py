@@ -106,9 +106,10 @@ class FusedNCLStep:
         roots = sums[1:4].sqrt()
         l2 = o_.reg * roots.sum() / bsz                                            # l2_reg_loss(reg, u, p, n)
         # d total / d sums: total = sums[0] / B + reg (sqrt s1 + sqrt s2 + sqrt s3) / B / batch_size + ...
+        # (`t[i] = python_scalar` on a device tensor is a host-to-device copy, which a stream capture refuses: fill_ views)
         gs = torch.zeros(5, dtype=torch.float32, device=dev)
-        gs[0] = 1.0 / bsz
-        gs[1:4] = (0.5 * o_.reg / (bsz * o_.batch_size)) / roots
+        gs[0:1].fill_(1.0 / bsz)
+        gs[1:4].copy_((0.5 * o_.reg / (bsz * o_.batch_size)) / roots)
 
         # ---- structure contrast (ncl.py:358-367): batch rows of the context layer against ALL layer-0 rows ----
         rows_c = torch.empty(2 * bsz, d, dtype=torch.float32, device=dev)
@@ -123,8 +124,8 @@ class FusedNCLStep:
         self._contrast_fwd(rows_c[:bsz], sa[:bsz], xu, sbu, user_idx, inv_tau, eng, lse[:bsz], o[:bsz], pl[:bsz])
         self._contrast_fwd(rows_c[bsz:], sa[bsz:], xi, sbi, pos_idx, inv_tau, eng, lse[bsz:], o[bsz:], pl[bsz:])
         w = torch.empty(2 * bsz, dtype=torch.float32, device=dev)                  # d total / d lse  (= - d total / d pos)
-        w[:bsz] = o_.ssl_reg
-        w[bsz:] = o_.ssl_reg * o_.alpha
+        w[:bsz].fill_(float(o_.ssl_reg))
+        w[bsz:].fill_(float(o_.ssl_reg * o_.alpha))
         ssl_loss = ((lse - pl) * w).sum()
 
         # ---- e_step (ncl.py:324, every batch): k-means of the CURRENT encoder outputs, no host read-back ----

@@ -54,10 +54,19 @@ def test_fused_step_equals_autograd_step(n_layers, hyper_layers):
     batches = next_batch_pairwise(fused.data, 512, seed=1)
     for step in range(2):
         batch = next(batches)
+        if step:
+            # Adam's normalised update amplifies round-off where a gradient is tiny, so the two tables drift apart by
+            # fractions of lr per step: re-align the state, the second step then checks a state with non-zero moments
+            with torch.no_grad():
+                fused.model.table.copy_(auto.model.table)
+                for key in ("user_emb", "item_emb"):
+                    sf, sa = of.state[fused.model.embedding_dict[key]], oa.state[auto.model.embedding_dict[key]]
+                    sf["exp_avg"].copy_(sa["exp_avg"])
+                    sf["exp_avg_sq"].copy_(sa["exp_avg_sq"])
         lf = fused.train_step(batch, of, check_negatives=False, fused=True)
         la = auto.train_step(batch, oa, check_negatives=False, fused=False)
         for name, x, y in zip(("rec", "ssl", "proto", "total"), lf, la):
-            assert float(x) == pytest.approx(float(y), rel=2e-5, abs=1e-7), (step, name)
+            assert float(x.detach()) == pytest.approx(float(y.detach()), rel=2e-5, abs=1e-7), (step, name)
         for key in ("user_emb", "item_emb"):
             gf, ga = fused.model.embedding_dict[key].grad, auto.model.embedding_dict[key].grad
             scale = float(ga.abs().max())
@@ -65,7 +74,7 @@ def test_fused_step_equals_autograd_step(n_layers, hyper_layers):
         # Adam divides by sqrt(v): elements whose gradient is at round-off level may move differently; the tables must
         # agree wherever the gradient is resolved
         mask = auto.model.embedding_dict["user_emb"].grad.abs() > 1e-3 * float(auto.model.embedding_dict["user_emb"].grad.abs().max())
-        du = (fused.model.embedding_dict["user_emb"] - auto.model.embedding_dict["user_emb"]).abs()
+        du = (fused.model.embedding_dict["user_emb"].detach() - auto.model.embedding_dict["user_emb"].detach()).abs()
         assert float(du[mask].max()) <= 0.005 * 0.02
         # the e_step ran inside both (same seeds, same inputs up to round-off): same partition
         assert float((fused.user_2cluster == auto.user_2cluster).float().mean()) > 0.99
@@ -94,7 +103,7 @@ def test_graph_replay_equals_eager_sequence():
     for batch in batches:
         lg = graphed.train_step(batch, og, check_negatives=False)
         le = eager.train_step(batch, oe, check_negatives=False, fused=True)
-        assert float(lg[3]) == pytest.approx(float(le[3]), rel=1e-3)
+        assert float(lg[3].detach()) == pytest.approx(float(le[3].detach()), rel=1e-3)
     assert graphed._fused._graph is not None                       # the graph path really ran
     assert int(og.state[graphed.model.embedding_dict["user_emb"]]["step_dev"]) == 6
     diff = (graphed.model.table - eager.model.table).abs()

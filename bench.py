@@ -411,6 +411,7 @@ def main():
                 "workload": "cfg4 on 1 GPU: 10000000 users x 1000000 items / 100000000 interactions (nnz=%d), 3-layer "
                             "d=64 forward" % r4["nnz"],
                 "edges_per_s": r4["edges_per_s"], "ms_per_step": r4["ms_per_step"], "graph_build_s": r4["graph_build_s"],
+                "spmm_parts": r4["graph"].plan.n_parts, "spmm_split_rows": r4["graph"].plan.n_long,
                 **r4["roofline"]}
             del r4
         except Exception as e:      # noqa: BLE001

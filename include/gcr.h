@@ -324,6 +324,14 @@ int32_t gcr_normalize_bwd_f32(const float* x, const float* inv_norm, const float
  * best_score (optional) = <x_i, c> - 0.5 ||c||^2 of the winner.  d in {32, 64, 128, 256}. */
 int32_t gcr_kmeans_assign_f32(const float* x, int64_t n, const float* centroids, const float* half_sqnorm,
                               int64_t k, int32_t d, int64_t* assign, float* best_score, void* stream);
+/* The search fused with the first half of the Lloyd update: besides assign[i] (optional, may be NULL) every row x_i is
+ * added to sums[copy, assign[i], :] and counts[copy, assign[i]] += 1 (float-atomic 256-B rows; copy = workgroup %
+ * n_copies; sums [n_copies, k, d] / counts [n_copies, k] zeroed by the caller or by the previous
+ * gcr_kmeans_lloyd_update_f32) — one launch instead of search + accumulate.  d in {32, 64, 128}; GCR_EUNSUPPORTED
+ * otherwise (use gcr_kmeans_assign_f32 + the `assign` form of gcr_kmeans_lloyd_update_f32). */
+int32_t gcr_kmeans_assign_accumulate_f32(const float* x, int64_t n, const float* centroids, const float* half_sqnorm,
+                                         int64_t k, int32_t d, int64_t* assign, float* sums, float* counts,
+                                         int32_t n_copies, void* stream);
 /* centroids_c <- mean of the rows assigned to c (empty clusters keep their centroid), and
  * half_sqnorm refreshed.  n == 0 only refreshes half_sqnorm (initialisation).
  * sums [k, d] / counts [k] are fp32 scratch. */
@@ -338,19 +346,23 @@ int32_t gcr_kmeans_update_sorted_f32(const float* x, int64_t n, int32_t d, const
 /*
  * One Lloyd update without host involvement (a fixed launch sequence: hipGraph-capturable):
  *   1. centroids_c <- mean of the rows assigned to c (empty clusters keep their centroid) — from `assign` (one row
- *      atomic per point) or, when (keys_sorted, perm) = gcr_sort_index(assign, n, k) is given, from the ordered points;
+ *      atomic per point), or, when (keys_sorted, perm) = gcr_sort_index(assign, n, k) is given, from the ordered points,
+ *      or — assign == keys_sorted == NULL — from sums / counts as gcr_kmeans_assign_accumulate_f32 left them;
  *   2. faiss Clustering.cpp `split_clusters` on the device: every empty cluster takes over a copy of the centroid of a
  *      cluster cj accepted with probability (size_cj - 1) / (n - k) while walking cj = 0, 1, ...; the two copies are
  *      perturbed by (1 +- 1/1024) alternating over the dimensions, the sizes split in half.  Trial q of the e-th empty
  *      cluster uses word x of Philox-4x32-10(counter (q, e, iter, 'KMSP'), key seed); after 64 k misses the largest
  *      cluster (>= 2 points) is split instead;
  *   3. half_sqnorm refreshed.
- * sums [k, d] / counts [k] must be ZERO on entry and are zero again on exit (no memsets between iterations).
- * n_split (optional device int32) is incremented by the number of re-seeded clusters.
+ * sums [n_copies, k, d] / counts [n_copies, k] must be ZERO on entry and are zero again on exit (no memsets between
+ * iterations).  n_copies (1 .. 64; used by the `assign` form only): workgroup b adds into private copy b % n_copies and
+ * the copies are summed in a fixed order — with a few hundred clusters and ~256 points each, one copy would serialise
+ * the memory-side row atomics on a few hundred rows.
+ * n_split (optional device int32) is incremented by the number of re-seeded clusters.  d in {32, 64, 128, 256}.
  */
 int32_t gcr_kmeans_lloyd_update_f32(const float* x, int64_t n, int32_t d, const int64_t* assign,
                                     const uint32_t* keys_sorted, const int32_t* perm, int64_t k,
-                                    float* centroids, float* half_sqnorm, float* sums, float* counts,
+                                    float* centroids, float* half_sqnorm, float* sums, float* counts, int32_t n_copies,
                                     uint64_t seed, int32_t iter, int32_t* n_split, void* stream);
 
 

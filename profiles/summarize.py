@@ -54,7 +54,43 @@ def stats(pattern, out, top=12):
     print("wrote", out)
 
 
-stats("kt/*/*_kernel_stats.csv", f"{tag}_cfg2_kernel_stats.csv", top=16)
+def stats_by_grid(pattern, bench_json, out):
+    """The SpMM rows of bench.py's kernel trace, one row per (kernel, grid size): the bench line carries a cfg2 leg and a
+    cfg4 companion leg that launch the SAME kernel template, which `--stats` pools into one row (r02: 204 calls with a
+    2x spread).  The grid size (256 threads x ceil(partitions / 4) workgroups) tells the workloads apart; the bench JSON
+    names each leg's partition count, and its live HIP-event average is written beside the trace's for comparison."""
+    path = one(pattern)
+    if not path:
+        return
+    legs = {}
+    try:
+        line = json.loads(open(os.path.join(src, bench_json)).read().strip().splitlines()[-1])
+        legs[256 * ((line["extra"]["spmm_parts"] + 3) // 4)] = ("cfg2", line["roofline"]["avg_launch_ms"])
+        c4 = line["roofline"].get("cfg4_graph")
+        if c4 and "spmm_parts" in c4:
+            legs[256 * ((c4["spmm_parts"] + 3) // 4)] = ("cfg4", c4["avg_launch_ms"])
+    except (OSError, ValueError, KeyError, IndexError):
+        pass
+    groups = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if "spmm_" not in r["Kernel_Name"]:
+            continue
+        grid = int(r.get("Grid_Size") or r.get("Grid_Size_X") or 0)
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+        groups[(name, grid)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    with open(os.path.join(here, out), "w") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "grid_threads", "workload", "calls", "avg_ns", "min_ns", "max_ns", "bench_hip_event_avg_launch_ms",
+                    "note"])
+        for (name, grid), v in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
+            wl, ev = legs.get(grid, ("", ""))
+            note = "bench avg_launch_ms spans spmm_parts + spmm_long_rows of one gcr_spmm_csr_f32 launch" if wl and "parts" in name else ""
+            w.writerow([name, grid, wl, len(v), round(sum(v) / len(v), 1), min(v), max(v), ev, note])
+    print("wrote", out)
+
+
+stats("kt/*/*_kernel_stats.csv", f"{tag}_bench_kernel_stats.csv", top=16)
+stats_by_grid("kt/*/*_kernel_trace.csv", "bench_kt.json", f"{tag}_spmm_by_workload_kernel_stats.csv")
 stats("kt_cfg4/*/*_kernel_stats.csv", f"{tag}_cfg4_kernel_stats.csv")
 stats("kt_nce/*/*_kernel_stats.csv", f"{tag}_infonce_kernel_stats.csv", top=10)
 stats("kt_ncl/*/*_kernel_stats.csv", f"{tag}_ncl_step_kernel_stats.csv", top=16)      # profiles/ncl_step_probe.py

@@ -55,10 +55,11 @@ SIGNATURES = {
     "gcr_infonce_pos_bwd_f32": (c_int32, [_P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int32, c_float, _P, _P, _P]),
     "gcr_normalize_bwd_f32": (c_int32, [_P, _P, _P, c_int64, c_int32, _P, _P]),
     "gcr_kmeans_assign_f32": (c_int32, [_P, c_int64, _P, _P, c_int64, c_int32, _P, _P, _P]),
+    "gcr_kmeans_assign_accumulate_f32": (c_int32, [_P, c_int64, _P, _P, c_int64, c_int32, _P, _P, _P, c_int32, _P]),
     "gcr_kmeans_update_f32": (c_int32, [_P, c_int64, c_int32, _P, c_int64, _P, _P, _P, _P, _P]),
     "gcr_kmeans_update_sorted_f32": (c_int32, [_P, c_int64, c_int32, _P, _P, c_int64, _P, _P, _P, _P, _P]),
-    "gcr_kmeans_lloyd_update_f32": (c_int32, [_P, c_int64, c_int32, _P, _P, _P, c_int64, _P, _P, _P, _P, c_uint64, c_int32,
-                                              _P, _P]),
+    "gcr_kmeans_lloyd_update_f32": (c_int32, [_P, c_int64, c_int32, _P, _P, _P, c_int64, _P, _P, _P, _P, c_int32, c_uint64,
+                                              c_int32, _P, _P]),
     "gcr_score_rows_f32": (c_int32, [_P, _P, c_int64, c_int64, _P, c_int64, c_int32, _P, _P]),
     "gcr_topk_masked_f32": (c_int32, [_P, c_int64, c_int64, _P, c_int64, _P, _P, c_int32, _P, _P, _P]),
     "gcr_rank_fused_supported": (c_int32, [c_int64, c_int32, c_int32]),

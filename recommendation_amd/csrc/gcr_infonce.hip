@@ -1960,7 +1960,8 @@ __global__ __launch_bounds__(256, (D <= 64 ? 3 : 2)) void kmeans_assign_kernel(
 template <int D>
 __global__ __launch_bounds__(256, 2) void kmeans_assign_b3_kernel(
     const float* __restrict__ x, int64_t n, const float* __restrict__ cent, const float* __restrict__ half_sq,
-    int64_t k, int64_t* __restrict__ assign, float* __restrict__ best_out) {
+    int64_t k, int64_t* __restrict__ assign, float* __restrict__ best_out, float* __restrict__ acc_sums = nullptr,
+    float* __restrict__ acc_counts = nullptr, int n_copies = 1) {
   using S = ShapeB3<D>;
   constexpr int NS = 6 * S::KC * S::NT, NU = 16 * S::NT + S::NLD;
   constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
@@ -2102,8 +2103,41 @@ __global__ __launch_bounds__(256, 2) void kmeans_assign_b3_kernel(
     const int j = other ? j_o : jl;
     const int64_t row = i0 + 32 * t + i32;
     if (h == 0 && row < n) {
-      assign[row] = j;
+      if (assign != nullptr) assign[row] = j;
       if (best_out != nullptr) best_out[row] = v;
+    }
+    btile[t] = j;                                         // kept for the fused centroid update below
+  }
+  // Lloyd update fused into the search (gcr_kmeans_assign_accumulate_f32): every point's row is added to its cluster's
+  // sum straight away — 256-B float-atomic rows into private copy blockIdx % n_copies — instead of a second kernel that
+  // re-reads the assignment.  The rows are re-read from L2 (the registers hold them as bf16 planes); 8 loads in flight.
+  if (acc_sums != nullptr) {
+    float* __restrict__ sb = acc_sums + (int64_t)(blockIdx.x % n_copies) * k * D;
+    float* __restrict__ cb = acc_counts + (int64_t)(blockIdx.x % n_copies) * k;
+    constexpr int NVX = (D + 63) / 64;
+#pragma unroll
+    for (int t = 0; t < S::NT; ++t) {
+      for (int p0 = 0; p0 < 32; p0 += 8) {
+        float xv[8][NVX];
+        int cj[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int64_t row = i0 + 32 * t + p0 + q;
+          cj[q] = __builtin_amdgcn_readlane(btile[t], p0 + q);
+          if (row >= n || cj[q] < 0 || cj[q] >= k) cj[q] = -1;
+          const float* xp = x + (row < n ? row : 0) * D;
+#pragma unroll
+          for (int c = 0; c < NVX; ++c) xv[q][c] = (lane + 64 * c < D) ? xp[lane + 64 * c] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          if (cj[q] < 0) continue;                        // wave-uniform
+#pragma unroll
+          for (int c = 0; c < NVX; ++c)
+            if (lane + 64 * c < D) atomicAdd(sb + (int64_t)cj[q] * D + lane + 64 * c, xv[q][c]);
+          if (lane == 0) atomicAdd(cb + cj[q], 1.0f);
+        }
+      }
     }
   }
 }
@@ -2134,6 +2168,27 @@ extern "C" int32_t gcr_kmeans_assign_f32(const float* x, int64_t n, const float*
   }
 #undef GCR_KM
 #undef GCR_KM3
+  return GCR_LAUNCH_STATUS();
+}
+
+extern "C" int32_t gcr_kmeans_assign_accumulate_f32(const float* x, int64_t n, const float* centroids,
+                                                    const float* half_sqnorm, int64_t k, int32_t d, int64_t* assign,
+                                                    float* sums, float* counts, int32_t n_copies, void* stream) {
+  GCR_CHECK_ARG(n >= 0 && k >= 1 && k < (1ll << 31) && n_copies >= 1 && n_copies <= 64);
+  if (!dim_supported(d) || !use_b3(d)) return GCR_EUNSUPPORTED;      // split-operand engine only (d <= 128)
+  if (n == 0) return GCR_OK;
+  GCR_CHECK_ARG(x && centroids && half_sqnorm && sums && counts);
+  hipStream_t s = (hipStream_t)stream;
+#define GCR_KMA(DD)                                                                                            \
+  hipLaunchKernelGGL((kmeans_assign_b3_kernel<DD>), dim3((unsigned)((n + ShapeB3<DD>::ANCHORS_PER_BLOCK - 1) / \
+                                                                    ShapeB3<DD>::ANCHORS_PER_BLOCK)),          \
+                     dim3(256), 0, s, x, n, centroids, half_sqnorm, k, assign, (float*)nullptr, sums, counts, (int)n_copies)
+  switch (d) {
+    case 32: GCR_KMA(32); break;
+    case 64: GCR_KMA(64); break;
+    default: GCR_KMA(128); break;
+  }
+#undef GCR_KMA
   return GCR_LAUNCH_STATUS();
 }
 

@@ -21,11 +21,16 @@ __device__ __forceinline__ float group16_sum(float v) {
   return v;
 }
 
-// sums[c] += x_i (256-B float-atomic rows), counts[c] += 1, one wave per point
+// sums[c] += x_i (256-B float-atomic rows), counts[c] += 1, one wave per point.  n_copies > 1: block b adds into private
+// copy b % n_copies of (sums, counts) — with a few hundred clusters every point of a 77K-point training set would
+// otherwise hit one of ~300 rows (the memory-side atomic unit serialises adds to one row); the finalize kernel sums the copies.
 __global__ __launch_bounds__(256) void kmeans_accumulate_kernel(const float* __restrict__ x, int64_t n, int d,
                                                                 const int64_t* __restrict__ assign, int64_t k,
-                                                                float* __restrict__ sums, float* __restrict__ counts) {
+                                                                float* __restrict__ sums, float* __restrict__ counts,
+                                                                int n_copies = 1) {
   const int lane = threadIdx.x & 63;
+  sums += (int64_t)(blockIdx.x % n_copies) * k * d;
+  counts += (int64_t)(blockIdx.x % n_copies) * k;
   for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += (int64_t)gridDim.x * 4) {
     const int64_t c = assign[i];
     if (c < 0 || c >= k) continue;
@@ -124,24 +129,55 @@ __global__ __launch_bounds__(256) void kmeans_finalize_kernel(const float* __res
 
 // centroid = sum / count (empty clusters keep their previous centroid); half_sq = 0.5 ||c||^2; the sums are CLEARED on the
 // way out (the next iteration's accumulate adds into zeros: no memset launches between iterations)
-__global__ __launch_bounds__(256) void kmeans_finalize_clear_kernel(float* __restrict__ sums, const float* __restrict__ counts,
+__global__ __launch_bounds__(256) void kmeans_finalize_clear_kernel(float* __restrict__ sums, float* __restrict__ counts,
                                                                     int64_t k, int d, float* __restrict__ cent,
-                                                                    float* __restrict__ half_sq) {
-  const int l16 = threadIdx.x & 15;
-  for (int64_t c = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); c < k; c += (int64_t)gridDim.x * 16) {
-    const float cnt = counts[c];
-    float ss = 0.f;
-    for (int col = l16; col < d; col += 16) {
-      float v = cent[c * d + col];
-      if (cnt > 0.f) {
-        v = sums[c * d + col] / cnt;
-        cent[c * d + col] = v;
-      }
-      sums[c * d + col] = 0.f;
-      ss += v * v;
+                                                                    float* __restrict__ half_sq, int n_copies) {
+  // one thread per centroid ELEMENT (a thread per row or a 16-lane group per row leaves a k = 300 update on 19
+  // workgroups, each walking the copies serially: 18-22 us); d divides 256 (32 / 64 / 128 / 256), so a row never
+  // straddles workgroups.  The copies are read with independent loads first and cleared afterwards.
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + tid;
+  const int64_t c = idx / d;
+  const int col = (int)(idx % d);
+  const bool valid = c < k;
+  const int64_t kd = k * (int64_t)d;
+  float cnt = 0.f, sum = 0.f, v = 0.f;
+  if (valid) {
+    for (int g = 0; g < n_copies; ++g) cnt += counts[(int64_t)g * k + c];      // copies in a fixed order
+    const float* p = sums + c * d + col;
+    int g = 0;
+    for (; g + 4 <= n_copies; g += 4) {
+      const float a0 = p[(int64_t)g * kd], a1 = p[(int64_t)(g + 1) * kd], a2 = p[(int64_t)(g + 2) * kd],
+                  a3 = p[(int64_t)(g + 3) * kd];
+      sum += a0;
+      sum += a1;
+      sum += a2;
+      sum += a3;
     }
-    ss = group16_sum(ss);
-    if (l16 == 0) half_sq[c] = 0.5f * ss;
+    for (; g < n_copies; ++g) sum += p[(int64_t)g * kd];
+    v = cent[c * d + col];
+    if (cnt > 0.f) {
+      v = sum / cnt;
+      cent[c * d + col] = v;
+    }
+    for (g = 0; g < n_copies; ++g) sums[(int64_t)g * kd + c * d + col] = 0.f;
+  }
+  float ss = v * v;
+  if (d <= 64) {
+    for (int off = d >> 1; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);     // butterfly inside the row's d lanes
+  } else {
+    ss = gcr_wave_sum(ss);
+    if (lane == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    const int w0 = (tid >> 6) / (d >> 6) * (d >> 6);                                 // first wave of this row
+    ss = 0.f;
+    for (int w = 0; w < (d >> 6); ++w) ss += red[w0 + w];
+  }
+  if (valid && col == 0) {
+    half_sq[c] = 0.5f * ss;
+    counts[c] = cnt;                                       // the total, for the split step (which clears it)
+    for (int g = 1; g < n_copies; ++g) counts[(int64_t)g * k + c] = 0.f;
   }
 }
 
@@ -262,7 +298,7 @@ extern "C" int32_t gcr_kmeans_update_f32(const float* x, int64_t n, int32_t d, c
     if (err != hipSuccess) return gcr_hip_status(err);
     const int64_t want = (n + 3) / 4;
     hipLaunchKernelGGL(kmeans_accumulate_kernel, dim3((unsigned)(want > 16384 ? 16384 : want)), dim3(256), 0, s, x, n,
-                       d, assign, k, sums, counts);
+                       d, assign, k, sums, counts, 1);
   }
   const int64_t wantk = (k + 15) / 16;
   hipLaunchKernelGGL(kmeans_finalize_kernel, dim3((unsigned)(wantk > 4096 ? 4096 : wantk)), dim3(256), 0, s, sums,
@@ -292,24 +328,27 @@ extern "C" int32_t gcr_kmeans_update_sorted_f32(const float* x, int64_t n, int32
 extern "C" int32_t gcr_kmeans_lloyd_update_f32(const float* x, int64_t n, int32_t d, const int64_t* assign,
                                                const uint32_t* keys_sorted, const int32_t* perm, int64_t k,
                                                float* centroids, float* half_sqnorm, float* sums, float* counts,
-                                               uint64_t seed, int32_t iter, int32_t* n_split, void* stream) {
+                                               int32_t n_copies, uint64_t seed, int32_t iter, int32_t* n_split,
+                                               void* stream) {
   GCR_CHECK_ARG(n >= 1 && n < (1ll << 31) && k >= 1 && k < (1ll << 31) && d >= 1 && d <= 256 && iter >= 0);
+  GCR_CHECK_ARG(n_copies >= 1 && n_copies <= 64);
   GCR_CHECK_ARG(x && centroids && half_sqnorm && sums && counts);
   GCR_CHECK_ARG((keys_sorted != nullptr) == (perm != nullptr));
-  GCR_CHECK_ARG(assign != nullptr || keys_sorted != nullptr);
   hipStream_t s = (hipStream_t)stream;
-  if (keys_sorted != nullptr) {
+  if (keys_sorted == nullptr && assign == nullptr) {
+    // sums / counts already hold this iteration's accumulation (gcr_kmeans_assign_accumulate_f32)
+  } else if (keys_sorted != nullptr) {
     const int64_t want = ((n + 63) / 64 + 3) / 4;
     hipLaunchKernelGGL(kmeans_accumulate_sorted_kernel, dim3((unsigned)(want > 65536 ? 65536 : want)), dim3(256), 0, s, x,
                        n, d, keys_sorted, perm, k, sums, counts);
   } else {
     const int64_t want = (n + 3) / 4;
     hipLaunchKernelGGL(kmeans_accumulate_kernel, dim3((unsigned)(want > 16384 ? 16384 : want)), dim3(256), 0, s, x, n, d,
-                       assign, k, sums, counts);
+                       assign, k, sums, counts, (int)n_copies);
   }
-  const int64_t wantk = (k + 15) / 16;
-  hipLaunchKernelGGL(kmeans_finalize_clear_kernel, dim3((unsigned)(wantk > 4096 ? 4096 : wantk)), dim3(256), 0, s, sums,
-                     counts, k, d, centroids, half_sqnorm);
+  GCR_CHECK_ARG(256 % d == 0 && k * (int64_t)d < (1ll << 39));       // rows must not straddle workgroups (d in 32..256)
+  hipLaunchKernelGGL(kmeans_finalize_clear_kernel, dim3((unsigned)((k * (int64_t)d + 255) / 256)), dim3(256), 0, s, sums,
+                     counts, k, d, centroids, half_sqnorm, keys_sorted != nullptr ? 1 : (int)n_copies);
   hipLaunchKernelGGL(kmeans_split_kernel, dim3(1), dim3(kSplitThreads), 0, s, counts, k, d, centroids, half_sqnorm, n, seed,
                      (uint32_t)iter, n_split);
   return GCR_LAUNCH_STATUS();

@@ -35,7 +35,10 @@ FAISS_SEED = 1234
 FAISS_MIN_POINTS_PER_CENTROID = 39          # ncl.py:350 clamps k with it: max_k = max(2, n // 39)
 FAISS_MAX_POINTS_PER_CENTROID = 256
 
-SORTED_UPDATE_MIN_POINTS = 1 << 16
+# centroid update: one float-atomic row per point into `copies` private (sums, counts) pairs (gcr_kmeans_lloyd_update_f32),
+# or — for training sets at least this large — from the points ordered by cluster (one atomic per run; needs a sort)
+SORTED_UPDATE_MIN_POINTS = 1 << 20
+MAX_ATOMIC_COPIES = 16
 
 _PERM_CACHE = {}
 
@@ -63,11 +66,21 @@ def kmeans_assign(x, centroids, half_sq):
     return assign
 
 
+def assign_to_centroids(x, centroids):
+    """`kmeans.index.search(x, 1)` (ncl.py:355): the nearest centroid (L2) of every row of x, int64 [n]."""
+    _lib.require_cuda(x, centroids)
+    xp = Fn._pad_dim(x.detach()).contiguous()
+    cp = Fn._pad_dim(centroids.detach().to(torch.float32)).contiguous()
+    return kmeans_assign(xp, cp, 0.5 * (cp * cp).sum(1))
+
+
 def run_kmeans(x, k, niter=FAISS_NITER, seed=FAISS_SEED, init_centroids=None,
-               max_points_per_centroid=FAISS_MAX_POINTS_PER_CENTROID, return_info=False):
+               max_points_per_centroid=FAISS_MAX_POINTS_PER_CENTROID, return_info=False, assign_points=True):
     """ncl.py:347-356.  x: float32 [n, d] on the GPU.  Returns (centroids [k', d], assignment int64 [n])
     with k' = min(k, max(2, n // 39)) exactly as ncl.py:350-351 clamps it (and, with return_info, a dict holding the
-    device counter of re-seeded empty clusters).  No host synchronisation."""
+    device counter of re-seeded empty clusters).  assign_points=False skips the final search over all n points and
+    returns None for the assignment (`assign_to_centroids` gives it later, for all rows or for a batch's rows only).
+    No host synchronisation."""
     _lib.require_cuda(x)
     if x.dim() != 2 or x.dtype != torch.float32:
         raise ValueError("x must be float32 [n, d]")
@@ -87,24 +100,34 @@ def run_kmeans(x, k, niter=FAISS_NITER, seed=FAISS_SEED, init_centroids=None,
     L = _lib.lib()
     dev = x.device
     half_sq = torch.empty(k, dtype=torch.float32, device=dev)
-    sums = torch.zeros(k, d, dtype=torch.float32, device=dev)      # zero on entry / exit of every lloyd_update
-    counts = torch.zeros(k, dtype=torch.float32, device=dev)
+    use_sorted = n_train >= SORTED_UPDATE_MIN_POINTS
+    # ~256 points per centroid (faiss' cap) on a few hundred rows: spread the row atomics over private copies
+    copies = 1 if use_sorted else max(1, min(MAX_ATOMIC_COPIES, n_train // (16 * k)))
+    sums = torch.zeros(copies, k, d, dtype=torch.float32, device=dev)      # zero on entry / exit of every lloyd_update
+    counts = torch.zeros(copies, k, dtype=torch.float32, device=dev)
     n_split = torch.zeros(1, dtype=torch.int32, device=dev)
     stream = _lib.cur_stream(dev)
     # 0.5 |c|^2 of the initial centroids (n = 0: refresh only)
     _lib.check(L.gcr_kmeans_update_f32(None, 0, d, None, k, _lib.dptr(cent), _lib.dptr(half_sq), None, None, stream),
                "gcr_kmeans_update_f32")
+    fused = not use_sorted and bool(L.gcr_infonce_engine(d))       # search + accumulate in one launch (d <= 128)
     for it in range(int(niter)):
-        assign = kmeans_assign(xt, cent, half_sq)
-        keys = perm = None
-        if n_train >= SORTED_UPDATE_MIN_POINTS:
-            # points ordered by cluster: one row atomic per run instead of one per point
-            keys, perm, _ = Fn._sorted_order(assign, k)
+        keys = perm = assign = None
+        if fused:
+            _lib.check(L.gcr_kmeans_assign_accumulate_f32(_lib.dptr(xt), n_train, _lib.dptr(cent), _lib.dptr(half_sq), k, d, None,
+                                                          _lib.dptr(sums), _lib.dptr(counts), copies, stream),
+                       "gcr_kmeans_assign_accumulate_f32")
+        else:
+            assign = kmeans_assign(xt, cent, half_sq)
+            if use_sorted:
+                # points ordered by cluster: one row atomic per run instead of one per point
+                keys, perm, _ = Fn._sorted_order(assign, k)
         _lib.check(L.gcr_kmeans_lloyd_update_f32(_lib.dptr(xt), n_train, d, _lib.dptr(assign), _lib.dptr(keys), _lib.dptr(perm),
                                                  k, _lib.dptr(cent), _lib.dptr(half_sq), _lib.dptr(sums), _lib.dptr(counts),
-                                                 int(seed) & (2 ** 64 - 1), it, _lib.dptr(n_split), stream),
+                                                 copies, int(seed) & (2 ** 64 - 1), it, _lib.dptr(n_split), stream),
                    "gcr_kmeans_lloyd_update_f32")
-    assign = kmeans_assign(xp, cent, half_sq)       # kmeans.index.search(x, 1) against the final centroids
+    # kmeans.index.search(x, 1) against the final centroids
+    assign = kmeans_assign(xp, cent, half_sq) if assign_points else None
     cent = cent[:, :d_orig].contiguous()
     if return_info:
         return cent, assign, {"n_split": n_split, "n_train": n_train, "k": k}

@@ -19,7 +19,7 @@ from . import functional as Fn
 from . import losses as Ls
 from .encoders import Interaction, LGCNEncoder
 from .evaluate import ranking_evaluation, test as rank_test
-from .kmeans import FAISS_NITER, FAISS_SEED, run_kmeans
+from .kmeans import FAISS_NITER, FAISS_SEED, assign_to_centroids, run_kmeans
 from .ncl_step import FusedNCLStep
 from .optim import FusedAdam
 from .sampler import next_batch_pairwise
@@ -57,7 +57,8 @@ class NCLModel:
         # NCLModel.from_graph builds one around a device-resident operator (graphs too large for Python id maps)
         self.data = train_set if hasattr(train_set, "norm_adj") else Interaction(conf, train_set, test_set, device=device)
         self.model = LGCNEncoder(self.data, self.emb_size, self.n_layers)
-        self.user_centroids = self.user_2cluster = self.item_centroids = self.item_2cluster = None
+        self.user_centroids = self.item_centroids = None
+        self._user_2cluster = self._item_2cluster = self._e_inputs = None
         self.bestPerformance = []
 
     @classmethod
@@ -70,10 +71,13 @@ class NCLModel:
         return cls(conf, data, None, device=norm_adj.device, **kw)
 
     # ncl.py:340-356
-    def e_step(self, user_emb=None, item_emb=None):
+    def e_step(self, user_emb=None, item_emb=None, assign_all=True):
         """`user_emb` / `item_emb`: the encoder outputs when the caller has just computed them with the
         current parameters (the training step has: the reference runs the same forward a second time,
-        ncl.py:341, with identical results)."""
+        ncl.py:341, with identical results).
+        assign_all=False: train the centroids only; `user_2cluster` / `item_2cluster` — `kmeans.index.search(x, 1)` over
+        ALL rows, of which ncl.py:371-372 reads the batch's 2 x B entries — are then computed when (and if) somebody
+        reads the attribute, from the same embeddings and centroids (the hand-derived step assigns just its batch rows)."""
         with torch.no_grad():
             if user_emb is None or item_emb is None:
                 user_emb, item_emb, _ = self.model()
@@ -81,12 +85,33 @@ class NCLModel:
             # ncl.py:350-351 clamps `self.k = min(self.k, max(2, n // 39))` and KEEPS it: the item k-means
             # inherits the users' clamp and, from the second e_step on, the users inherit the items'
             # ncl.py:352 builds a fresh faiss.Kmeans for each table: both run with the same seed
-            self.user_centroids, self.user_2cluster = run_kmeans(user_emb.contiguous(), self.k, niter=self.kmeans_niter,
-                                                                 seed=self.kmeans_seed)
+            self.user_centroids, self._user_2cluster = run_kmeans(user_emb.contiguous(), self.k, niter=self.kmeans_niter,
+                                                                  seed=self.kmeans_seed, assign_points=assign_all)
             self.k = int(self.user_centroids.shape[0])
-            self.item_centroids, self.item_2cluster = run_kmeans(item_emb.contiguous(), self.k, niter=self.kmeans_niter,
-                                                                 seed=self.kmeans_seed)
+            self.item_centroids, self._item_2cluster = run_kmeans(item_emb.contiguous(), self.k, niter=self.kmeans_niter,
+                                                                  seed=self.kmeans_seed, assign_points=assign_all)
             self.k = int(self.item_centroids.shape[0])
+            self._e_inputs = None if assign_all else (user_emb, item_emb)
+
+    @property
+    def user_2cluster(self):
+        if self._user_2cluster is None and self._e_inputs is not None:
+            self._user_2cluster = assign_to_centroids(self._e_inputs[0], self.user_centroids)
+        return self._user_2cluster
+
+    @user_2cluster.setter
+    def user_2cluster(self, value):
+        self._user_2cluster = value
+
+    @property
+    def item_2cluster(self):
+        if self._item_2cluster is None and self._e_inputs is not None:
+            self._item_2cluster = assign_to_centroids(self._e_inputs[1], self.item_centroids)
+        return self._item_2cluster
+
+    @item_2cluster.setter
+    def item_2cluster(self, value):
+        self._item_2cluster = value
 
     # ncl.py:358-367
     def ssl_layer_loss(self, context, initial, user, item):

@@ -130,13 +130,19 @@ class FusedNCLStep:
 
         # ---- e_step (ncl.py:324, every batch): k-means of the CURRENT encoder outputs, no host read-back ----
         if self.e_step_every_batch:
-            o_.e_step(fu, fi)
+            o_.e_step(fu, fi, assign_all=False)      # centroids now; the full assignment vectors on demand
 
         # ---- prototype contrast (ncl.py:369-375): InfoNCE(e0[idx], centroid of idx's cluster) * batch_size ----
         rows_0 = torch.empty(2 * bsz, d, dtype=torch.float32, device=dev)
         _lib.check(L.gcr_gather_rows_f32(_lib.dptr(x0), _lib.dptr(gat), 2 * bsz, d, n, _lib.dptr(rows_0), stream),
                    "gcr_gather_rows_f32")
-        cents = torch.cat([o_.user_centroids[o_.user_2cluster[user_idx]], o_.item_centroids[o_.item_2cluster[pos_idx]]])
+        # kmeans.index.search(x, 1) for the batch's rows only (ncl.py:371-372 read user_2cluster[user_idx] / item_2cluster[item_idx])
+        from .kmeans import assign_to_centroids
+        rows_f = torch.empty(2 * bsz, d, dtype=torch.float32, device=dev)
+        _lib.check(L.gcr_gather_rows_f32(_lib.dptr(final), _lib.dptr(gat), 2 * bsz, d, n, _lib.dptr(rows_f), stream),
+                   "gcr_gather_rows_f32")
+        cents = torch.cat([o_.user_centroids[assign_to_centroids(rows_f[:bsz], o_.user_centroids)],
+                           o_.item_centroids[assign_to_centroids(rows_f[bsz:], o_.item_centroids)]])
         s0, sc = Fn.row_inv_norm(rows_0), Fn.row_inv_norm(cents)
         lse_p = torch.empty(2 * bsz, dtype=torch.float32, device=dev)
         pl_p = torch.empty(2 * bsz, dtype=torch.float32, device=dev)

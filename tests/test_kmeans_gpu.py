@@ -158,7 +158,7 @@ def test_split_falls_back_to_the_largest_cluster():
     ns = torch.zeros(1, dtype=torch.int32, device="cuda")
     L = _lib.lib()
     _lib.check(L.gcr_kmeans_lloyd_update_f32(_lib.dptr(x), 5, d, _lib.dptr(assign), None, None, k, _lib.dptr(cent), _lib.dptr(half),
-                                             _lib.dptr(sums), _lib.dptr(counts), 1234, 0, _lib.dptr(ns), _lib.cur_stream()), "lloyd")
+                                             _lib.dptr(sums), _lib.dptr(counts), 1, 1234, 0, _lib.dptr(ns), _lib.cur_stream()), "lloyd")
     ref_c = (np.arange(k * d, dtype=np.float64).reshape(k, d) / 100 + 1).astype(np.float32).astype(np.float64)
     cnt = np.array([1, 1, 1, 2, 0], dtype=np.float64)
     assert O.kmeans_split_clusters(ref_c, cnt, 5, 1234, 0) == 1

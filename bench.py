@@ -77,6 +77,115 @@ def synth_interactions_device(n_users, n_items, n_edges, seed, device, perm_seed
     return keys // n_items, keys % n_items
 
 
+COMMUNITY = dict(n_comm=128, p_in=0.85)     # cfg2c: the cfg2 sizes with planted taste communities (8K users x 780 items each)
+
+
+def synth_community_interactions_device(n_users, n_items, n_edges, seed, device, n_comm=128, p_in=0.85):
+    """A bipartite graph with the structure real interaction data has and the uniform generator lacks: `n_comm` taste
+    communities (equal blocks of users and of items); a user draws an item of its own community with probability p_in
+    and any item otherwise, items by the same capped Zipf(1) popularity law as the uniform generator (popular and
+    unpopular items in every community).  The ids are then SHUFFLED (random permutations of users and of items), as ids
+    of a real data set carry no locality — recovering it is the renumbering's job (recommendation_amd/reorder.py).
+    Returns (users, items, hidden_user_community [U], hidden_item_community [I]) in the shuffled ids; unique pairs,
+    every user >= 1 interaction."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    p = 1.0 / torch.arange(1, n_items + 1, device=device, dtype=torch.float64)
+    p /= p.sum()
+    cap = 0.005
+    for _ in range(50):
+        over = p > cap
+        if not bool(over.any()):
+            break
+        excess = (p[over] - cap).sum()
+        p[over] = cap
+        p[~over] += excess * p[~over] / p[~over].sum()
+    p = p[torch.randperm(n_items, generator=g, device=device)]           # hidden item id -> popularity (ranks scattered)
+    cdf = torch.cumsum(p, 0)
+    cdf[-1] = 1.0
+    # community c owns hidden users [c U / C, (c + 1) U / C) and hidden items [ceil(c I / C), ceil((c + 1) I / C))
+    bounds = (torch.arange(n_comm + 1, device=device, dtype=torch.int64) * n_items + n_comm - 1) // n_comm
+    cdf0 = torch.cat([cdf.new_zeros(1), cdf])
+    seg_lo, seg_hi = cdf0[bounds[:-1]], cdf0[bounds[1:]]                  # popularity mass interval of every community
+
+    def draw(users_h):
+        n = users_h.numel()
+        r = torch.rand(n, generator=g, device=device, dtype=torch.float64)
+        inside = torch.rand(n, generator=g, device=device) < p_in
+        c = users_h * n_comm // n_users
+        target = torch.where(inside, seg_lo[c] + r * (seg_hi[c] - seg_lo[c]), r)
+        return torch.searchsorted(cdf, target, right=True).clamp_(max=n_items - 1)
+
+    uh = torch.arange(n_users, device=device, dtype=torch.int64)
+    keys = uh * n_items + draw(uh)
+    need = n_edges - n_users
+    while need > 0:
+        n = int(need * 1.15) + 16
+        u = torch.randint(0, n_users, (n,), generator=g, device=device)
+        k = torch.unique(u * n_items + draw(u))
+        k = k[~torch.isin(k, keys)]
+        if k.numel() > need:
+            k = k[torch.randperm(k.numel(), generator=g, device=device)[:need]]
+        keys = torch.cat([keys, k])
+        need = n_edges - keys.numel()
+    keys = keys[torch.randperm(keys.numel(), generator=g, device=device)]
+    uh, ih = keys // n_items, keys % n_items
+    pu = torch.randperm(n_users, generator=g, device=device)             # hidden -> public id
+    pi = torch.randperm(n_items, generator=g, device=device)
+    cu = torch.empty(n_users, dtype=torch.int64, device=device)
+    ci = torch.empty(n_items, dtype=torch.int64, device=device)
+    cu[pu] = torch.arange(n_users, device=device, dtype=torch.int64) * n_comm // n_users
+    ci[pi] = torch.searchsorted(bounds, torch.arange(n_items, device=device, dtype=torch.int64), right=True) - 1
+    return pu[uh], pi[ih], cu, ci
+
+
+def community_leg(ra, Fn, dev, name, d=64, reps=10):
+    """Secondary workload: the same K-layer forward on a graph WITH community structure, ids shuffled
+    as they arrive (`before`) and after recommendation_amd/reorder.py's spectral renumbering + XCD-grouped plan (`after`).
+    The uniform headline graph cannot benefit from any numbering; this one shows what the carried permutation buys."""
+    from recommendation_amd import reorder as R
+    wl = WORKLOADS[name]
+    n_u, n_i, n_e, k_layers = wl["users"], wl["items"], wl["edges"], wl["layers"]
+    n_comm = max(2, n_u // 8192)
+    users, items, _, _ = synth_community_interactions_device(n_u, n_i, n_e, SEED, dev, n_comm, COMMUNITY["p_in"])
+    n = n_u + n_i
+    x0 = torch.empty(n, d, device=dev)
+    torch.nn.init.xavier_uniform_(x0, generator=torch.Generator(device=dev).manual_seed(0))
+
+    def layer_ms(graph):
+        with torch.no_grad():
+            return _event_ms(lambda: Fn.lightgcn_propagate(graph, x0, k_layers, combine="sum"), reps) / k_layers
+
+    g0 = ra.CsrGraph.bipartite_sym_norm(users, items, n_u, n_i, dev)
+    t_before = layer_ms(g0)
+    nnz = g0.nnz
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pu, pi, group = R.locality_permutation(users, items, n_u, n_i, dev, graph=g0)
+    torch.cuda.synchronize()
+    t_reorder = time.perf_counter() - t0
+    del g0
+    g1 = ra.CsrGraph.bipartite_sym_norm(pu[users], pi[items], n_u, n_i, dev, row_group=group)
+    t_after = layer_ms(g1)
+    bytes_alg = nnz * (8 + 4 * d) + n * (4 * d + 4)
+    out = {"workload": f"{name} sizes with {n_comm} planted communities (p_in = {COMMUNITY['p_in']}), ids shuffled: {n_u} users x "
+                       f"{n_i} items / {n_e} interactions (nnz={nnz}), {k_layers}-layer d={d} forward",
+           "ms_per_layer_before": round(t_before, 4), "ms_per_layer_after": round(t_after, 4),
+           "speedup": round(t_before / t_after, 3), "reorder_s": round(t_reorder, 2),
+           "edges_per_s_before": nnz / t_before * 1e3, "edges_per_s_after": nnz / t_after * 1e3,
+           "frac_alg_before": round(bytes_alg / t_before / 1e6 / HBM_PEAK_GBS, 4),
+           "frac_alg_after": round(bytes_alg / t_after / 1e6 / HBM_PEAK_GBS, 4),
+           "traffic_before": None, "traffic_after": None,
+           "note": "after = spectral co-clustering renumbering (reorder.py: subspace iteration on the SpMM kernel + the e_step's "
+                   "k-means) + work plan walked community by community on one XCD; frac_alg is the no-reuse byte model (cache hits "
+                   "make it exceed 1)"}
+    for tag in ("before", "after"):
+        pmc = _committed_pmc(f"{name}c_{tag}", spmm_source_digest())
+        if pmc:
+            out[f"traffic_{tag}"] = pmc["bytes_per_launch"]
+            out["traffic_source"] = pmc["source"]
+    return out
+
+
 def sym_norm_csr_device(users, items, n_users, n_items):
     """D^-1/2 (R + R^T) D^-1/2 as CSR, built with torch ops on the device (bench plumbing; the
     pairs are unique so no duplicate merge is needed; rows sorted by (row, col) like selfcf.py:297)."""
@@ -416,6 +525,16 @@ def main():
             del r4
         except Exception as e:      # noqa: BLE001
             roofline["cfg4_graph_error"] = repr(e)
+
+    # secondary workload: graphs with community structure, before / after the locality renumbering
+    if not args.no_extra and d == 64 and name in ("cfg2", "cfg4"):
+        extra["community_graph"] = {}
+        for wl_name in ("cfg2",) if args.no_cfg4 else ("cfg2", "cfg4"):
+            try:
+                extra["community_graph"][wl_name] = community_leg(ra, Fn, dev, wl_name, d)
+            except Exception as e:      # noqa: BLE001
+                extra["community_graph"][wl_name] = {"error": repr(e)[:200]}
+            torch.cuda.empty_cache()
 
     line = {
         "metric": "edges propagated/sec (LightGCN d=%d, %d-layer fwd message pass)" % (d, k_layers),

@@ -509,6 +509,22 @@ int32_t gcr_scatter_add_rows_f32(const float* src, const int64_t* idx, int64_t n
                                  void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Raw id -> dense id maps of graph ingest, on the device.
+ *   order 0  dense id = rank of the key among the DISTINCT keys in ascending unsigned order
+ *            replaces  self.user = {u: idx for idx, u in enumerate(sorted(users))}   ncl.py:60-61, directau.py:116-117,
+ *                      univariate/sept.py:122-123
+ *   order 1  dense id = order of first appearance
+ *            replaces  if user not in self.user: self.user[user] = len(self.user)    selfcf.py:281-288, ssl4rec.py:69-75
+ * keys [n]: one 64-bit key per record whose unsigned order is the raw ids' order (the host packs id strings big-endian,
+ * 8 bytes per word; wider ids are folded word by word through order 0).  Outputs: dense [n] (id of every record),
+ * first_pos [n] (entry j < *n_unique: position of the first record carrying dense id j — the host reads the raw id there),
+ * n_unique (device int64).  Stable LSD radix sort (rocPRIM) + head flags + scan; no host involvement.
+ * --------------------------------------------------------------------------------------------- */
+int64_t gcr_dense_ids_workspace_bytes(int64_t n);
+int32_t gcr_dense_ids_u64(const uint64_t* keys, int64_t n, int32_t order, int64_t* dense, int64_t* first_pos,
+                          int64_t* n_unique, void* workspace, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Memory-system probes (measurement aids for the roofline block of bench.py; SURVEY.md §8d asks for
  * a device-copy bandwidth measured on the box next to the vendor peak).  16 B per lane.
  * --------------------------------------------------------------------------------------------- */

@@ -104,7 +104,7 @@ except (OSError, ValueError):
     traffic = {}
 sha, dirty = git_state()
 
-for wl in ("cfg2", "cfg4"):
+for wl in ("cfg2", "cfg4", "cfg2c_before", "cfg2c_after", "cfg4c_before", "cfg4c_after"):
     fetch, write = one(f"pmc_fetch_{wl}/*/*_counter_collection.csv"), one(f"pmc_write_{wl}/*/*_counter_collection.csv")
     info_path = os.path.join(root, "gpurun_out", f"pmc_probe_{wl}.json")
     if not (fetch and write and os.path.exists(info_path)):
@@ -126,7 +126,11 @@ for wl in ("cfg2", "cfg4"):
     w_parts = [float(r[5]) for r in rows if r[0] == "write" and r[2] == "spmm_parts"]
     f_long = [float(r[5]) for r in rows if r[0] == "fetch" and r[2] == "spmm_long_rows"]
     w_long = [float(r[5]) for r in rows if r[0] == "write" and r[2] == "spmm_long_rows"]
-    cal_f, lay_f, lay_w = f_parts[:3], f_parts[3:], w_parts[3:]
+    # dispatch order: 3 calibration launches, [the renumbering's own subspace-iteration launches], then the measured
+    # 2 forward passes x K layers — always the LAST 2 K dispatches
+    n_meas = 2 * int(info.get("layers", 3))
+    cal_f, lay_f, lay_w = f_parts[:3], f_parts[-n_meas:], w_parts[-n_meas:]
+    f_long, w_long = f_long[-n_meas:], w_long[-n_meas:]
     nc = info["cal_rows"]
     expected_read_kb = (nc * 256 + nc * 8 + nc * 8 + info["cal_parts"] * 32) / 1024
     cal_ratio = (sum(cal_f) / len(cal_f)) / expected_read_kb

@@ -81,6 +81,8 @@ SIGNATURES = {
     "gcr_csr_lookup_f32": (c_int32, [_P, _P, c_int64, _P, _P, _P, _P, _P]),
     "gcr_gather_rows_f32": (c_int32, [_P, _P, c_int64, c_int32, c_int64, _P, _P]),
     "gcr_scatter_add_rows_f32": (c_int32, [_P, _P, c_int64, c_int32, c_int64, _P, _P]),
+    "gcr_dense_ids_workspace_bytes": (c_int64, [c_int64]),
+    "gcr_dense_ids_u64": (c_int32, [_P, c_int64, c_int32, _P, _P, _P, _P, _P]),
     "gcr_probe_copy_f32": (c_int32, [_P, _P, c_int64, _P]),
     "gcr_probe_read_f32": (c_int32, [_P, c_int64, _P, _P]),
     "gcr_probe_gather_rows_f32": (c_int32, [_P, c_int64, _P, c_int64, _P, _P]),

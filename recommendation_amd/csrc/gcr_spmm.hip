@@ -39,7 +39,9 @@ struct Epilogue {
   float acc_in2_scale;
 };
 
-template <int NV, bool D64>
+// ACC2: the second-addend form is its own instantiation — read unconditionally, its pointer and scale cost the hot
+// instantiation 9 SGPRs (96 -> 105), which is one wave per SIMD of occupancy and 4 % of the cfg2 layer time
+template <int NV, bool D64, bool ACC2>
 __device__ __forceinline__ void store_row(const Epilogue& ep, int64_t row, int d, int lane, float (&acc)[NV]) {
   float yv[NV];
 #pragma unroll
@@ -70,14 +72,14 @@ __device__ __forceinline__ void store_row(const Epilogue& ep, int64_t row, int d
       if (ep.y != nullptr) ep.y[base + c] = yv[v];
       if (ep.acc_out != nullptr) {
         float prev = ep.acc_in != nullptr ? ep.acc_in[base + c] : 0.f;
-        if (ep.acc_in2 != nullptr) prev = fmaf(ep.acc_in2[base + c], ep.acc_in2_scale, prev);
+        if (ACC2) prev = fmaf(ep.acc_in2[base + c], ep.acc_in2_scale, prev);
         ep.acc_out[base + c] = (prev + yv[v]) * ep.acc_scale;
       }
     }
   }
 }
 
-template <int NV, bool D64, bool HAS_VAL, bool MASKED, int UNR>
+template <int NV, bool D64, bool HAS_VAL, bool MASKED, int UNR, bool ACC2>
 __global__ __launch_bounds__(256) void spmm_parts(const int64_t* __restrict__ desc, int64_t n_parts,
                                                   const int64_t* __restrict__ rowptr,
                                                   const int32_t* __restrict__ col,
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(256) void spmm_parts(const int64_t* __restrict__ de
   }
 
   auto flush = [&]() {
-    store_row<NV, D64>(ep, (int64_t)row0 + cur, d, lane, acc);
+    store_row<NV, D64, ACC2>(ep, (int64_t)row0 + cur, d, lane, acc);
 #pragma unroll
     for (int v = 0; v < NV; ++v) acc[v] = 0.f;
     ++cur;
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(256) void spmm_parts(const int64_t* __restrict__ de
 // the four wave sums are combined through LDS in wave order, then the common epilogue.  The order
 // of additions is fixed by the plan, so the result stays bitwise reproducible.  (One wave per row
 // took 24 us per cfg2 layer — hub rows have ~100 chunks — i.e. 3 % of the layer.)
-template <int NV, bool D64>
+template <int NV, bool D64, bool ACC2>
 __global__ __launch_bounds__(256) void spmm_long_rows(const int32_t* __restrict__ long_row,
                                                       const int32_t* __restrict__ long_slot0, int64_t n_long,
                                                       const float* __restrict__ partials, int d, Epilogue ep) {
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(256) void spmm_long_rows(const int32_t* __restrict_
     for (int w = 0; w < 3; ++w)
 #pragma unroll
       for (int v = 0; v < NV; ++v) acc[v] += red[w][v * 64 + lane];
-    store_row<NV, D64>(ep, (int64_t)long_row[i], d, lane, acc);
+    store_row<NV, D64, ACC2>(ep, (int64_t)long_row[i], d, lane, acc);
   }
 }
 
@@ -242,15 +244,15 @@ __global__ void csr_validate_kernel(const int64_t* __restrict__ rowptr, const in
   if (bad) atomicAdd(n_errors, bad);
 }
 
-template <int NV, bool D64>
-int32_t launch_spmm(const int64_t* desc, int64_t n_parts, const int32_t* long_row, const int32_t* long_slot0,
+template <int NV, bool D64, bool ACC2>
+int32_t launch_spmm_a(const int64_t* desc, int64_t n_parts, const int32_t* long_row, const int32_t* long_slot0,
                     int64_t n_long, const int64_t* rowptr, const int32_t* col, const float* val,
                     const uint32_t* keep_bits, const float* x, int d, const Epilogue& ep, float* partials,
                     hipStream_t stream) {
   const unsigned blocks = (unsigned)((n_parts + 3) / 4);
   if (blocks > 0) {
 #define GCR_SPMM_LAUNCH(HV, MK)                                                                             \
-  hipLaunchKernelGGL((spmm_parts<NV, D64, HV, MK, unroll_for<NV>()>), dim3(blocks), dim3(256), 0, stream, desc, n_parts, \
+  hipLaunchKernelGGL((spmm_parts<NV, D64, HV, MK, unroll_for<NV>(), ACC2>), dim3(blocks), dim3(256), 0, stream, desc, n_parts, \
                      rowptr, col, val, keep_bits, x, d, ep, partials)
     if (val != nullptr) {
       if (keep_bits != nullptr) GCR_SPMM_LAUNCH(true, true);
@@ -264,11 +266,23 @@ int32_t launch_spmm(const int64_t* desc, int64_t n_parts, const int32_t* long_ro
     if (st != GCR_OK) return st;
   }
   if (n_long > 0) {
-    hipLaunchKernelGGL((spmm_long_rows<NV, D64>), dim3((unsigned)n_long), dim3(256), 0, stream,
+    hipLaunchKernelGGL((spmm_long_rows<NV, D64, ACC2>), dim3((unsigned)n_long), dim3(256), 0, stream,
                        long_row, long_slot0, n_long, partials, d, ep);
     return GCR_LAUNCH_STATUS();
   }
   return GCR_OK;
+}
+
+template <int NV, bool D64>
+int32_t launch_spmm(const int64_t* desc, int64_t n_parts, const int32_t* long_row, const int32_t* long_slot0,
+                    int64_t n_long, const int64_t* rowptr, const int32_t* col, const float* val,
+                    const uint32_t* keep_bits, const float* x, int d, const Epilogue& ep, float* partials,
+                    hipStream_t stream) {
+  if (ep.acc_in2 != nullptr)
+    return launch_spmm_a<NV, D64, true>(desc, n_parts, long_row, long_slot0, n_long, rowptr, col, val, keep_bits, x, d, ep,
+                                        partials, stream);
+  return launch_spmm_a<NV, D64, false>(desc, n_parts, long_row, long_slot0, n_long, rowptr, col, val, keep_bits, x, d, ep,
+                                       partials, stream);
 }
 
 }  // namespace

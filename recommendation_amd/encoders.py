@@ -21,50 +21,147 @@ def _device(device=None):
     return torch.device(device) if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
 
 
-class Interaction:
+def encode_raw_ids(values):
+    """Raw ids (a column of the `user item rating` records) -> uint64 keys [n, W] whose lexicographic unsigned order is
+    the order Python's `sorted()` gives the ids (ncl.py:60-61): integers by value, strings by code point (= by UTF-8
+    byte, packed big-endian eight bytes per word, NUL-padded: a prefix sorts first).  None: ids of another type (the
+    caller then keeps the host dict path)."""
+    arr = np.asarray(values)
+    if arr.dtype.kind in "iu":
+        return (arr.astype(np.int64).view(np.uint64) ^ np.uint64(1 << 63)).reshape(-1, 1)
+    if arr.dtype.kind == "U":
+        arr = np.char.encode(arr, "utf-8")
+    if arr.dtype.kind != "S":
+        return None
+    n, w = arr.size, max(arr.dtype.itemsize, 1)
+    words = (w + 7) // 8
+    buf = np.zeros((n, words * 8), dtype=np.uint8)
+    buf[:, :w] = np.frombuffer(arr.tobytes(), dtype=np.uint8).reshape(n, w)
+    return buf.view(">u8").astype(np.uint64)
+
+
+def dense_ids_device(keys, device, order="sorted"):
+    """(dense int64 [n] on the device, first_pos int64 [m] on the host) of the records' uint64 keys [n, W]:
+    gcr_dense_ids_u64; ids wider than one word are folded word by word through their sorted ranks."""
+    from . import _lib
+    L = _lib.lib()
+    n, words = keys.shape
+    dev = torch.device(device)
+    ws = torch.empty(int(L.gcr_dense_ids_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+    n_unique = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def call(k, mode):
+        dense = torch.empty(n, dtype=torch.int64, device=dev)
+        first = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+        _lib.check(L.gcr_dense_ids_u64(_lib.dptr(k), n, mode, _lib.dptr(dense), _lib.dptr(first), _lib.dptr(n_unique),
+                                       _lib.dptr(ws), _lib.cur_stream(dev)), "gcr_dense_ids_u64")
+        return dense, first
+
+    mode = {"sorted": 0, "first_seen": 1}[order]
+    rank = None
+    for w in range(words):
+        kw = torch.from_numpy(np.ascontiguousarray(keys[:, w]).view(np.int64)).to(dev)
+        if words == 1:
+            rank = kw
+            break
+        rw, _ = call(kw, 0)
+        rank = rw if rank is None else call(rank * n + rw, 0)[0]
+    dense, first = call(rank, mode)
+    return dense, first[: int(n_unique.item())].cpu().numpy()
+
+
+class _LazyMaps:
+    """The Python-side views of the id maps (`user`, `item`, `id2user`, `id2item`, `training_data`, `training_set_u`:
+    ncl.py:50-72), built from the device result only when something reads them — the training step never does."""
+
+    def __getattr__(self, name):
+        if name == "user":
+            val = {u: k for k, u in enumerate(self._users_raw)}
+        elif name == "item":
+            val = {i: k for k, i in enumerate(self._items_raw)}
+        elif name == "id2user":
+            val = dict(enumerate(self._users_raw))
+        elif name == "id2item":
+            val = dict(enumerate(self._items_raw))
+        elif name == "training_data":
+            val = [(t[0], t[1]) for t in self.train]
+        elif name == "training_set_u":
+            val = {u: set() for u in self._users_raw}
+            for t in self.train:
+                val[t[0]].add(t[1])
+        else:
+            raise AttributeError(name)
+        setattr(self, name, val)
+        return val
+
+
+class Interaction(_LazyMaps):
     """ncl.py:46-88.  `train`/`test` are lists of (user, item, rating) with hashable raw ids.
-    Dense ids follow sorted raw-id order (ncl.py:60-61).  Besides the reference's attributes
-    (`user`, `item`, `id2user`, `id2item`, `user_num`, `item_num`, `training_data`,
+    Dense ids follow sorted raw-id order (ncl.py:60-61) or first appearance (selfcf.py:281-288).  Besides the reference's
+    attributes (`user`, `item`, `id2user`, `id2item`, `user_num`, `item_num`, `training_data`,
     `training_set_u`, `test_set`) it carries the device-resident operator `norm_adj` (a CsrGraph:
     the raw 0/1 adjacency with duplicates kept, exactly what the reference calls norm_adj, Q1) and
-    the sorted per-user training rows the device sampler rejects against."""
+    the sorted per-user training rows the device sampler rejects against.
 
-    def __init__(self, conf, train, test, device=None, normalised=False, id_order="sorted"):
+    On a GPU device the id maps are built there (gcr_dense_ids_u64: radix sort + head flags + scan over the encoded id
+    columns) — the Python dicts of the reference become lazily built views.
+    reorder="spectral": the dense ids are additionally re-numbered for gather locality (reorder.py); `perm_user` /
+    `perm_item` hold reference id -> id used here, and every id this object hands out is the re-numbered one."""
+
+    def __init__(self, conf, train, test, device=None, normalised=False, id_order="sorted", reorder=None,
+                 rows_per_cluster=None):
         self.train, self.test = train, test
         self.device = _device(device)
-        if id_order == "sorted":          # ncl.py:60-61, directau.py:116-117, sept.py:122-123
-            users = sorted({t[0] for t in train})
-            items = sorted({t[1] for t in train})
-        elif id_order == "first_seen":    # selfcf.py:279-288, ssl4rec.py:69-75 (dict insertion order)
-            users = list(dict.fromkeys(t[0] for t in train))
-            items = list(dict.fromkeys(t[1] for t in train))
-        else:
+        if id_order not in ("sorted", "first_seen"):
             raise ValueError("id_order must be 'sorted' or 'first_seen'")
-        self.user = {u: k for k, u in enumerate(users)}
-        self.item = {i: k for k, i in enumerate(items)}
-        self.id2user = {k: u for u, k in self.user.items()}
-        self.id2item = {k: i for i, k in self.item.items()}
-        self.user_num, self.item_num = len(users), len(items)
-        self.training_data = [(t[0], t[1]) for t in train]
-        self.training_set_u = {u: set() for u in self.user}
-        for t in train:
-            self.training_set_u[t[0]].add(t[1])
+        cols = list(zip(*train)) if len(train) else [(), ()]
+        ku = encode_raw_ids(cols[0]) if self.device.type == "cuda" and len(train) else None
+        ki = encode_raw_ids(cols[1]) if ku is not None else None
+        if ku is not None and ki is not None:
+            uid, first_u = dense_ids_device(ku, self.device, id_order)
+            iid, first_i = dense_ids_device(ki, self.device, id_order)
+            self._users_raw = [cols[0][p] for p in first_u]
+            self._items_raw = [cols[1][p] for p in first_i]
+        else:
+            if id_order == "sorted":          # ncl.py:60-61, directau.py:116-117, sept.py:122-123
+                self._users_raw = sorted({t[0] for t in train})
+                self._items_raw = sorted({t[1] for t in train})
+            else:                             # selfcf.py:279-288, ssl4rec.py:69-75 (dict insertion order)
+                self._users_raw = list(dict.fromkeys(t[0] for t in train))
+                self._items_raw = list(dict.fromkeys(t[1] for t in train))
+            user, item = self.user, self.item
+            uid = torch.from_numpy(np.fromiter((user[t[0]] for t in train), dtype=np.int64, count=len(train))).to(self.device)
+            iid = torch.from_numpy(np.fromiter((item[t[1]] for t in train), dtype=np.int64, count=len(train))).to(self.device)
+        self.user_num, self.item_num = len(self._users_raw), len(self._items_raw)
+        self.perm_user = self.perm_item = None
+        row_group = None
+        if reorder is not None:
+            if reorder != "spectral" or self.device.type != "cuda":
+                raise ValueError("reorder must be None or 'spectral' (GPU device)")
+            from .reorder import DEFAULT_ROWS_PER_CLUSTER, locality_permutation
+            pu, pi, row_group = locality_permutation(uid, iid, self.user_num, self.item_num, self.device,
+                                                     rows_per_cluster or DEFAULT_ROWS_PER_CLUSTER)
+            uid, iid = pu[uid], pi[iid]
+            self.perm_user, self.perm_item = pu.cpu().numpy(), pi.cpu().numpy()
+            self._users_raw = [u for _, u in sorted(zip(self.perm_user.tolist(), self._users_raw))]
+            self._items_raw = [i for _, i in sorted(zip(self.perm_item.tolist(), self._items_raw))]
         self.test_set = {}
         for t in test:
             self.test_set.setdefault(t[0], {})[t[1]] = 1
-        self.uid = np.fromiter((self.user[t[0]] for t in train), dtype=np.int64, count=len(train))
-        self.iid = np.fromiter((self.item[t[1]] for t in train), dtype=np.int64, count=len(train))
+        self.uid_dev, self.iid_dev = uid.contiguous(), iid.contiguous()
+        self.uid, self.iid = self.uid_dev.cpu().numpy(), self.iid_dev.cpu().numpy()
         build = CsrGraph.bipartite_sym_norm if normalised else CsrGraph.bipartite_raw
-        self.norm_adj = build(self.uid, self.iid, self.user_num, self.item_num, self.device)
+        self.norm_adj = build(self.uid_dev if self.device.type == "cuda" else self.uid,
+                              self.iid_dev if self.device.type == "cuda" else self.iid,
+                              self.user_num, self.item_num, self.device, row_group=row_group)
         # sorted, de-duplicated positives per user for the rejection sampler
-        keys = np.unique(self.uid * max(self.item_num, 1) + self.iid)
-        pu, pi = keys // max(self.item_num, 1), keys % max(self.item_num, 1)
-        rowptr = np.zeros(self.user_num + 1, dtype=np.int64)
-        np.cumsum(np.bincount(pu, minlength=self.user_num), out=rowptr[1:])
-        self.user_rowptr = torch.from_numpy(rowptr).to(self.device)
-        self.user_items_sorted = torch.from_numpy(pi.astype(np.int32)).to(self.device)
-        self.uid_dev = torch.from_numpy(self.uid).to(self.device)
-        self.iid_dev = torch.from_numpy(self.iid).to(self.device)
+        ni = max(self.item_num, 1)
+        keys = torch.unique(self.uid_dev * ni + self.iid_dev)
+        pu_, pi_ = keys // ni, keys % ni
+        rowptr = torch.zeros(self.user_num + 1, dtype=torch.int64, device=self.device)
+        rowptr[1:] = torch.cumsum(torch.bincount(pu_, minlength=self.user_num), 0)
+        self.user_rowptr = rowptr
+        self.user_items_sorted = pi_.to(torch.int32).contiguous()
 
     def get_user_id(self, user):
         return self.user[user]

@@ -32,7 +32,11 @@ def _np_i64(a):
 class SpmmPlan:
     """Host-built partition list for gcr_spmm_csr_f32 (include/gcr.h)."""
 
-    def __init__(self, rowptr_host: np.ndarray, device, nnz_per_part=DEFAULT_NNZ_PER_PART):
+    def __init__(self, rowptr_host: np.ndarray, device, nnz_per_part=DEFAULT_NNZ_PER_PART, row_group=None):
+        """row_group (optional int array [n_rows]): a locality group per row (reorder.locality_permutation's labels on the
+        re-numbered operator).  The partitions are then laid out so that each group runs on ONE XCD, group after group
+        (reorder.xcd_grouped_order), and its rows stay in that XCD's L2 between the gathers that share them; without it
+        the partitions keep row order and consecutive workgroups alternate over the XCDs."""
         L = _lib.lib()
         rowptr_host = np.ascontiguousarray(rowptr_host, dtype=np.int64)
         n_rows = rowptr_host.size - 1
@@ -47,6 +51,16 @@ class SpmmPlan:
         _lib.check(L.gcr_spmm_plan_fill_host(rowptr_host.ctypes.data, n_rows, nnz_per_part, desc.ctypes.data,
                                              long_row.ctypes.data, long_slot0.ctypes.data), "gcr_spmm_plan_fill_host")
         self.nnz_per_part = nnz_per_part
+        self.grouped = row_group is not None and self.n_parts > 0
+        if self.grouped:
+            from .reorder import xcd_grouped_order
+            rg = np.asarray(row_group.detach().cpu().numpy() if isinstance(row_group, torch.Tensor) else row_group)
+            if rg.shape != (n_rows,):
+                raise ValueError("row_group must have one entry per row")
+            order = xcd_grouped_order(desc[: self.n_parts], rg)
+            pad = np.array([0, 0, 0, -1], dtype=np.int64)                 # an empty whole-row partition: writes nothing
+            desc = np.where((order >= 0)[:, None], desc[np.maximum(order, 0)], pad[None, :])
+            self.n_parts = int(order.size)
         self.desc_host = desc[: self.n_parts]
         self.desc = torch.from_numpy(desc).to(device)
         self.long_row = torch.from_numpy(long_row).to(device)
@@ -57,7 +71,7 @@ class CsrGraph:
     """A sparse operator A [n_rows, n_cols] resident on one GPU, ready for `functional.spmm`."""
 
     def __init__(self, rowptr, col, val, n_rows, n_cols, device, symmetric=False,
-                 nnz_per_part=DEFAULT_NNZ_PER_PART, validate=True, transpose=None):
+                 nnz_per_part=DEFAULT_NNZ_PER_PART, validate=True, transpose=None, row_group=None):
         rowptr_host = _np_i64(rowptr)
         if rowptr_host.size != n_rows + 1:
             raise ValueError("rowptr must have n_rows + 1 entries")
@@ -71,7 +85,7 @@ class CsrGraph:
         self.val = None if val is None else torch.as_tensor(val).to(device=self.device, dtype=torch.float32).contiguous()
         if self.col.numel() != self.nnz or (self.val is not None and self.val.numel() != self.nnz):
             raise ValueError("col / val length must equal rowptr[-1]")
-        self.plan = SpmmPlan(rowptr_host, self.device, nnz_per_part)
+        self.plan = SpmmPlan(rowptr_host, self.device, nnz_per_part, row_group=row_group)
         self._t = self if symmetric else transpose
         self._workspaces = {}
         if validate and self.device.type == "cuda":

@@ -16,6 +16,14 @@ if [ "$WHAT" = "hbm" ] || [ "$WHAT" = "all" ]; then
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write_$wl" -- python3 "$R/profiles/pmc_probe.py" --workload $wl > "$OUT/pmc_write_$wl.log" 2>&1
     echo "pmc write $wl done"
   done
+  for wl in cfg2c cfg4c; do
+    for ro in before after; do
+      flag=""; [ "$ro" = "after" ] && flag="--reorder"
+      rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch_${wl}_$ro" -- python3 "$R/profiles/pmc_probe.py" --workload $wl $flag > "$OUT/pmc_fetch_${wl}_$ro.log" 2>&1
+      rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write_${wl}_$ro" -- python3 "$R/profiles/pmc_probe.py" --workload $wl $flag > "$OUT/pmc_write_${wl}_$ro.log" 2>&1
+      echo "pmc $wl $ro done"
+    done
+  done
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- python3 "$R/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-extra > "$OUT/bench_kt.json" 2> "$OUT/bench_kt.err"
   echo "kernel trace bench done"
 fi

@@ -1,0 +1,138 @@
+"""SURVEY §8f.3 remainder: raw id -> dense id maps on the device (gcr_dense_ids_u64) and the locality-aware renumbering
+carried as a permutation (recommendation_amd/reorder.py).  Integer work: bit-exact with the reference's own maps and
+adjacency (tests/golden/graph_build.npz, written by directau.Interaction / selfcf.Interaction) — after un-permuting, for the
+re-numbered operator."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle_np as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _triples(g):
+    return [[u, i, 1.0] for u, i in zip(g["train_user"].tolist(), g["train_item"].tolist())]
+
+
+def test_device_id_maps_match_reference_maps(golden):
+    from recommendation_amd.encoders import Interaction
+    g = golden("graph_build.npz")
+    train = _triples(g)
+    # ncl.py:55-66: sorted raw-id order; the raw (0/1, duplicates kept) adjacency of ncl.py:74-85
+    d = Interaction({}, train, train[:10], device="cuda")
+    assert [d.id2user[k] for k in range(d.user_num)] == g["sorted_user_ids"].tolist()
+    assert [d.id2item[k] for k in range(d.item_num)] == g["sorted_item_ids"].tolist()
+    assert d.user == {u: k for k, u in enumerate(g["sorted_user_ids"].tolist())}
+    rp, c, _, _ = O.coo_to_csr_stable(g["coo_row"], g["coo_col"], g["coo_data"], d.user_num + d.item_num)
+    assert np.array_equal(d.norm_adj.rowptr.cpu().numpy(), rp) and np.array_equal(d.norm_adj.col.cpu().numpy(), c)
+    # selfcf.py:279-306: first-appearance order; normalised adjacency
+    d = Interaction({}, train, train[:10], device="cuda", normalised=True, id_order="first_seen")
+    assert [d.id2user[k] for k in range(d.user_num)] == g["seen_user_ids"].tolist()
+    assert [d.id2item[k] for k in range(d.item_num)] == g["seen_item_ids"].tolist()
+    assert np.array_equal(d.norm_adj.rowptr.cpu().numpy(), g["norm_indptr"])
+    assert np.array_equal(d.norm_adj.col.cpu().numpy().astype(np.int64), g["norm_indices"])
+    np.testing.assert_allclose(d.norm_adj.val.cpu().numpy(), g["norm_data"], rtol=3e-7)
+    # the lazily built Python views agree with the reference's containers
+    assert d.training_set_u[train[0][0]] == {t[1] for t in train if t[0] == train[0][0]}
+    assert d.training_data[:3] == [(t[0], t[1]) for t in train[:3]]
+
+
+@pytest.mark.parametrize("kind", ["int", "short_str", "long_str", "unicode"])
+@pytest.mark.parametrize("order", ["sorted", "first_seen"])
+def test_dense_ids_equal_python_maps(kind, order):
+    """gcr_dense_ids_u64 against the reference's two constructions in plain Python, on ids that exercise the encoding:
+    integers incl. negatives, strings where lexicographic != numeric order ('10' < '9'), ids wider than one 8-byte key
+    word (folded word by word) with long common prefixes, and non-ASCII code points."""
+    from recommendation_amd.encoders import dense_ids_device, encode_raw_ids
+    rng = np.random.default_rng(3)
+    n = 5000
+    base = rng.integers(0, 700, n)
+    if kind == "int":
+        raw = (base - 350).tolist()
+    elif kind == "short_str":
+        raw = [str(v) for v in base]
+    elif kind == "long_str":
+        raw = ["customer-id-%05d-x" % v if v % 3 else "customer-id-%d" % v for v in base]
+    else:
+        raw = ["é%d" % v if v % 2 else "z%dü" % v for v in base]
+    keys = encode_raw_ids(raw)
+    dense, first = dense_ids_device(keys, "cuda", order)
+    if order == "sorted":
+        ref_list = sorted(set(raw))
+    else:
+        ref_list = list(dict.fromkeys(raw))
+    ref = {r: k for k, r in enumerate(ref_list)}
+    assert dense.cpu().tolist() == [ref[r] for r in raw]
+    assert [raw[p] for p in first] == ref_list
+
+
+def test_renumbering_is_a_permutation_of_the_reference_graph(golden):
+    """reorder='spectral': ids are re-numbered for locality, `perm_user` / `perm_item` carry reference id -> new id.
+    Un-permuting the operator must give the reference's neighbour lists bit for bit, and every id the object hands out
+    must be consistent with its own operator."""
+    from recommendation_amd.encoders import Interaction
+    g = golden("graph_build.npz")
+    train = _triples(g)
+    ref = Interaction({}, train, train[:10], device="cuda", normalised=True)
+    d = Interaction({}, train, train[:10], device="cuda", normalised=True, reorder="spectral", rows_per_cluster=8)
+    pu, pi = d.perm_user, d.perm_item
+    assert sorted(pu.tolist()) == list(range(ref.user_num)) and sorted(pi.tolist()) == list(range(ref.item_num))
+    for raw, k in ref.user.items():
+        assert d.user[raw] == pu[k]
+    for raw, k in ref.item.items():
+        assert d.item[raw] == pi[k]
+    n_u, n = ref.user_num, ref.user_num + ref.item_num
+    perm = np.concatenate([pu, n_u + pi])                       # reference node id -> new node id
+    inv = np.argsort(perm)
+    rp, col = d.norm_adj.rowptr.cpu().numpy(), d.norm_adj.col.cpu().numpy()
+    rrp, rcol, rval = ref.norm_adj.rowptr.cpu().numpy(), ref.norm_adj.col.cpu().numpy(), ref.norm_adj.val.cpu().numpy()
+    val = d.norm_adj.val.cpu().numpy()
+    for r in range(n):
+        new = perm[r]
+        got = inv[col[rp[new]:rp[new + 1]]]
+        order = np.argsort(got)
+        assert np.array_equal(got[order], rcol[rrp[r]:rrp[r + 1]])              # neighbour sets: bit-exact
+        np.testing.assert_allclose(val[rp[new]:rp[new + 1]][order], rval[rrp[r]:rrp[r + 1]], rtol=3e-7)
+    # propagation commutes with the renumbering (values: fp32, summation order inside a row differs)
+    from recommendation_amd import functional as Fn
+    x = torch.randn(n, 64, device="cuda", generator=torch.Generator(device="cuda").manual_seed(0))
+    xp = torch.empty_like(x)
+    xp[torch.from_numpy(perm).cuda()] = x
+    y_ref = Fn.lightgcn_propagate(ref.norm_adj, x, 3, "mean")
+    y_new = Fn.lightgcn_propagate(d.norm_adj, xp, 3, "mean")
+    torch.testing.assert_close(y_new[torch.from_numpy(perm).cuda()], y_ref, rtol=1e-5, atol=1e-6)
+    assert d.norm_adj.plan.grouped
+
+
+def test_grouped_plan_covers_every_partition_once():
+    """reorder.xcd_grouped_order: every partition exactly once, pads only, each group's partitions on one XCD (positions
+    whose workgroup index is congruent mod 8), groups contiguous within their XCD's sequence; and the SpMM over a
+    grouped plan equals the plain plan's result bit for bit (same partitions, another order)."""
+    import recommendation_amd as ra
+    from recommendation_amd import functional as Fn
+    from recommendation_amd.reorder import xcd_grouped_order
+    n_u, n_i = 6000, 900
+    u, i = O.synthetic_interactions(n_u, n_i, 90000, seed=5)
+    rng = np.random.default_rng(0)
+    group = np.concatenate([np.sort(rng.integers(0, 37, n_u)), np.sort(rng.integers(0, 37, n_i))])
+    plain = ra.CsrGraph.bipartite_sym_norm(u, i, n_u, n_i, "cuda")
+    grouped = ra.CsrGraph.bipartite_sym_norm(u, i, n_u, n_i, "cuda", row_group=group)
+    desc = plain.plan.desc_host
+    order = xcd_grouped_order(desc, group)
+    real = order[order >= 0]
+    assert sorted(real.tolist()) == list(range(desc.shape[0]))
+    pos = np.flatnonzero(order >= 0)
+    xcd = (pos // 4) % 8
+    pg = group[(desc[real, 2] & 0xFFFFFFFF)]
+    for gid in np.unique(pg):
+        assert np.unique(xcd[pg == gid]).size == 1
+    for x in range(8):
+        seq = pg[xcd == x]
+        change = np.flatnonzero(np.diff(seq) != 0).size + 1
+        assert change == np.unique(seq).size                     # each group contiguous in its XCD's sequence
+    xin = torch.randn(n_u + n_i, 64, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    a, b = torch.empty_like(xin), torch.empty_like(xin)
+    Fn.spmm_into(plain, xin, y=a)
+    Fn.spmm_into(grouped, xin, y=b)
+    assert torch.equal(a, b)

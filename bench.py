@@ -684,30 +684,62 @@ def main_sharded(args, rank, world, dev, ra):
     if name == "cfg5":
         return main_cfg5(args, rank, world, dev, ra)
     k_layers, d = WORKLOADS[name]["layers"], args.dim
-    users, items, n_u, n_u_total, n_i, n_e_total = local_interactions(name, args.scaling, rank, world, dev, gdist)
-    graph = build_sharded_bipartite(ra, gdist, dist, dev, rank, world, n_u, n_i, users, items)
-    nnz_local = graph.r_ui.nnz + graph.r_iu.nnz
-    gen = torch.Generator(device=dev).manual_seed(rank)
-    bound = (6.0 / (n_u_total + n_i + d)) ** 0.5                  # xavier_uniform of the global table
-    x_u = (torch.rand(n_u, d, device=dev, generator=gen) * 2 - 1) * bound
-    x_i = (torch.rand(graph.items_per_rank, d, device=dev, generator=gen) * 2 - 1) * bound
-    torch.cuda.synchronize()
 
-    def step():
-        with torch.no_grad():
-            return gdist.sharded_propagate_raw(graph, x_u, x_i, k_layers, 1.0)
+    def propagation_leg(wl_name, scaling, steps, warmup):
+        """One sharded K-layer forward leg: (rank-local state, whole-job numbers)."""
+        users, items, n_u, n_u_total, n_i, n_e_total = local_interactions(wl_name, scaling, rank, world, dev, gdist)
+        graph = build_sharded_bipartite(ra, gdist, dist, dev, rank, world, n_u, n_i, users, items)
+        nnz_local = graph.r_ui.nnz + graph.r_iu.nnz
+        gen = torch.Generator(device=dev).manual_seed(rank)
+        bound = (6.0 / (n_u_total + n_i + d)) ** 0.5                  # xavier_uniform of the global table
+        x_u = (torch.rand(n_u, d, device=dev, generator=gen) * 2 - 1) * bound
+        x_i = (torch.rand(graph.items_per_rank, d, device=dev, generator=gen) * 2 - 1) * bound
+        torch.cuda.synchronize()
 
-    elapsed = _timed_ranks(dist, dev, step, args.warmup, args.steps)
-    nnz_all = torch.tensor([nnz_local], device=dev, dtype=torch.int64)
-    dist.all_reduce(nnz_all)
-    nnz_all = int(nnz_all.item())
+        def step():
+            with torch.no_grad():
+                return gdist.sharded_propagate_raw(graph, x_u, x_i, WORKLOADS[wl_name]["layers"], 1.0)
+
+        elapsed = _timed_ranks(dist, dev, step, warmup, steps)
+        nnz_all = torch.tensor([nnz_local], device=dev, dtype=torch.int64)
+        dist.all_reduce(nnz_all)
+        return dict(users=users, items=items, graph=graph, n_u=n_u, n_u_total=n_u_total, n_i=n_i, n_e_total=n_e_total,
+                    nnz_all=int(nnz_all.item()), elapsed=elapsed, steps=steps)
+
+    leg = propagation_leg(name, args.scaling, args.steps, args.warmup)
+    users, items, graph = leg["users"], leg["items"], leg["graph"]
+    n_u, n_u_total, n_i, n_e_total, nnz_all, elapsed = (leg[k] for k in ("n_u", "n_u_total", "n_i", "n_e_total", "nnz_all",
+                                                                         "elapsed"))
     gcl = None
     if not args.no_extra:
         try:
             full = (graph, users, items, k_layers) if args.gcl_full else None
             gcl = gcl_step_leg(ra, gdist, dist, dev, rank, world, d, full)
+            del full
         except Exception as e:      # noqa: BLE001  (secondary: never costs the headline line)
             gcl = {"error": repr(e)[:300]}
+    # BASELINE configs[3] itself: the FIXED 10M x 1M / 100M-interaction graph split over the N ranks (strong scaling), next
+    # to the weak-scaling headline whose N = 1 point is the single-GPU bench line
+    cfg4_strong = None
+    items_padded = graph.items_padded
+    if not (name == "cfg4" and args.scaling == "strong") and not args.no_cfg4 and d == 64:
+        try:
+            del users, items, graph
+            leg.clear()
+            torch.cuda.empty_cache()
+            s4 = propagation_leg("cfg4", "strong", max(3, args.steps // 4), 2)
+            k4 = WORKLOADS["cfg4"]["layers"]
+            t4 = s4["elapsed"] / s4["steps"]
+            b4 = s4["nnz_all"] * (8 + 4 * d) + (s4["n_u_total"] + s4["n_i"]) * (4 * d + 4)
+            cfg4_strong = {
+                "workload": f"cfg4 x{world} (strong): LightGCN {k4}-layer d={d}, {s4['n_u_total']} users (row-sharded, "
+                            f"{s4['n_u']}/GPU) x {s4['n_i']} items / {s4['n_e_total']} interactions (nnz={s4['nnz_all']})",
+                "scaling": "strong", "edges_per_s": s4["nnz_all"] * k4 / t4, "ms_per_step": 1e3 * t4, "steps": s4["steps"],
+                "frac_alg": round(b4 * k4 / t4 / 1e9 / (HBM_PEAK_GBS * world), 4),
+                "note": "1-GPU point of this curve: roofline.cfg4_graph of the N = 1 bench line"}
+            del s4
+        except Exception as e:      # noqa: BLE001  (secondary: never costs the headline line)
+            cfg4_strong = {"error": repr(e)[:300]}
     if rank == 0:
         n_nodes = n_u_total + n_i
         bytes_alg = nnz_all * (8 + 4 * d) + n_nodes * (4 * d + 4)
@@ -728,9 +760,9 @@ def main_sharded(args, rank, world, dev, ra):
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                          "frac": round(achieved / (HBM_PEAK_GBS * world), 4), "traffic": None,
                          "frac_alg": round(achieved / (HBM_PEAK_GBS * world), 4),
-                         "collective_bytes_per_rank_per_layer": 2 * graph.items_padded * d * 4 * (world - 1) // world},
+                         "collective_bytes_per_rank_per_layer": 2 * items_padded * d * 4 * (world - 1) // world},
             "cpu_baseline": None, "dist_backend": dist.get_backend(), "dist_world": dist.get_world_size(),
-            "gcl_step": gcl,
+            "gcl_step": gcl, "cfg4_strong": cfg4_strong,
         }
         print(json.dumps(line))
     dist.destroy_process_group()

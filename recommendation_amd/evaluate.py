@@ -88,12 +88,14 @@ def test(data, user_emb, item_emb, max_n):
             for k, u in enumerate(users)}
 
 
-def ranking_metrics(top_items, test_rowptr, test_items_sorted, cutoffs):
+def ranking_metrics(top_items, test_rowptr, test_items_sorted, cutoffs, n_test_total=None):
     """Hit ratio / precision / recall / NDCG at every cut-off from the ranked lists, the per-user work on the
     device (gcr_rank_metrics).  top_items int64 [Q, K] on the GPU (-1 = padding); (test_rowptr, test_items_sorted)
     the CSR of each QUERY row's test items (ascending inside a row).  Users without a test item do not take part
     (the reference only evaluates users of its test set).  Returns {n: {"Hit Ratio", "Precision", "Recall", "NDCG"}}
-    rounded to 5 decimals like the reference's report (ncl.py:133-177)."""
+    rounded to 5 decimals like the reference's report (ncl.py:133-177).
+    n_test_total: the Hit Ratio's denominator when it is not the query rows' own test items — `Metric.hit_ratio`
+    (ncl.py:143-145) divides by the test items of ALL users of `origin`, ranked or not."""
     L = _lib.lib()
     dev = top_items.device
     q, k = top_items.shape
@@ -115,15 +117,19 @@ def ranking_metrics(top_items, test_rowptr, test_items_sorted, cutoffs):
     for c, n in enumerate(cut.tolist()):
         h = hits_h[:, c]
         ndcg = np.divide(dcg_h[:, c], idcg_h[:, c], out=np.zeros_like(h), where=idcg_h[:, c] > 0)
-        out[n] = {"Hit Ratio": round(float(h.sum() / n_test.sum()), 5), "Precision": round(float(h.sum() / (len(h) * n)), 5),
+        hr_den = float(n_test_total) if n_test_total is not None else float(n_test.sum())
+        out[n] = {"Hit Ratio": round(float(h.sum() / hr_den), 5), "Precision": round(float(h.sum() / (len(h) * n)), 5),
                   "Recall": round(float(np.mean(h / n_test)), 5), "NDCG": round(float(ndcg.sum() / len(h)), 5)}
     return out
 
 
-def ranking_evaluation(origin, res, N):
+def ranking_evaluation(origin, res, N, device=None):
     """The reference's report interface (ncl.py:165-177): origin {user: {item: 1}}, res {user: [(item, score), ...]}
     -> the list of "Top n" / "Hit Ratio:..." lines for every cut-off in N.  The dictionaries are packed into
-    index tensors (host plumbing) and the per-user hit / DCG sums run on the device (`ranking_metrics`)."""
+    index tensors (host plumbing) and the per-user hit / DCG sums run on the device (`ranking_metrics`; `device`:
+    the GPU to use, default the current one).  As in the reference, hits / precision / recall / NDCG run over the users
+    present in BOTH dictionaries while the Hit Ratio divides by the test items of every user of `origin`
+    (ncl.py:136-145) — a test user that was never ranked (absent from training) lowers it."""
     users = [u for u in origin if u in res]
     names = {}
     for u in users:
@@ -141,8 +147,9 @@ def ranking_evaluation(origin, res, N):
         t = sorted(names[it] for it in origin[u])
         test_items += t
         rowptr[r + 1] = rowptr[r] + len(t)
-    dev = torch.device("cuda")
-    m = ranking_metrics(torch.from_numpy(top).to(dev), torch.from_numpy(rowptr), np.asarray(test_items, dtype=np.int32), N)
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    m = ranking_metrics(torch.from_numpy(top).to(dev), torch.from_numpy(rowptr), np.asarray(test_items, dtype=np.int32), N,
+                        n_test_total=sum(len(origin[u]) for u in origin))
     lines = []
     for n in N:
         lines.append(f"Top {n}\n")

@@ -28,6 +28,12 @@ def test_ranking_evaluation_strings_match_reference():
     res = {u: [tuple(p) for p in lst] for u, lst in g["res"].items()}
     assert ranking_evaluation(g["origin"], res, g["N"]) == g["lines"]
     assert ranking_evaluation(g["origin"], res, [10, 70]) == O.ranking_report(g["origin"], res, [10, 70])   # cut-off > list
+    # a test user that was never ranked (absent from training, evaluate.test() drops it): hits / precision / recall /
+    # NDCG ignore it, the Hit Ratio's denominator still counts its test items (Metric.hit_ratio, ncl.py:143-145)
+    partial = {u: lst for k, (u, lst) in enumerate(res.items()) if k % 3}
+    got = ranking_evaluation(g["origin"], partial, g["N"], device="cuda:0")
+    assert got == O.ranking_report(g["origin"], partial, g["N"])
+    assert got != ranking_evaluation({u: g["origin"][u] for u in partial}, partial, g["N"])
 
 
 def _ref_topk(ue, ie, uids, pos, k):

@@ -27,7 +27,7 @@ root = os.path.dirname(here)
 
 def one(pattern):
     hits = glob.glob(os.path.join(src, pattern)) or glob.glob(os.path.join(src, pattern.replace("/*/", "/")))
-    return hits[0] if hits else None
+    return max(hits, key=os.path.getmtime) if hits else None          # several runs merged into one tree: the newest
 
 
 def git_state():

@@ -78,6 +78,10 @@ int32_t gcr_spmm_csr_f32(const int64_t* desc, int64_t n_parts,
  * (ncl.py:415-422 returns `all_emb`; ncl.py:319-322 reads emb_list[2 * hyper_layers]) is the Horner recurrence
  * h_k = g_final + g_k / c + A^T h_{k+1}: the per-layer gradient g_k rides on the epilogue instead of a separate
  * [n_rows, d] add pass per layer.
+ * col_active_bits (optional, excludes keep_bits): a little-endian uint32 bitmap over the COLUMNS, bit c clear = row c of x
+ * is known to be zero; non-zeros with a clear column are skipped before their gather.  The first launch of a backward
+ * pass whose incoming gradient touches a few thousand rows (the batch rows of ncl.py:314-317) then moves the CSR and its
+ * output but gathers almost nothing.  gcr_bitmap_set builds the bitmap from an index list.
  */
 int32_t gcr_spmm_csr_acc2_f32(const int64_t* desc, int64_t n_parts,
                               const int32_t* long_row, const int32_t* long_slot0, int64_t n_long_rows,
@@ -87,7 +91,9 @@ int32_t gcr_spmm_csr_acc2_f32(const int64_t* desc, int64_t n_parts,
                               float* y, const float* acc_in, const float* acc_in2, float acc_in2_scale,
                               float* acc_out, float acc_scale,
                               uint32_t flags, float* inv_norm_out, float* partials,
-                              int64_t n_rows, int64_t n_cols, void* stream);
+                              int64_t n_rows, int64_t n_cols, const uint32_t* col_active_bits, void* stream);
+/* bits[idx[i] >> 5] |= 1 << (idx[i] & 31) for every idx[i] in [0, n_bits) (atomic OR; the caller zeroes `bits`). */
+int32_t gcr_bitmap_set(const int64_t* idx, int64_t n, int64_t n_bits, uint32_t* bits, void* stream);
 
 /*
  * The same product with TWO outputs from one launch:

@@ -25,7 +25,8 @@ SIGNATURES = {
     "gcr_spmm_csr_f32": (c_int32, [_P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, c_float, _P, c_int32,
                                    _P, _P, _P, c_float, c_uint32, _P, _P, c_int64, c_int64, _P]),
     "gcr_spmm_csr_acc2_f32": (c_int32, [_P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, c_float, _P, c_int32,
-                                        _P, _P, _P, c_float, _P, c_float, c_uint32, _P, _P, c_int64, c_int64, _P]),
+                                        _P, _P, _P, c_float, _P, c_float, c_uint32, _P, _P, c_int64, c_int64, _P, _P]),
+    "gcr_bitmap_set": (c_int32, [_P, c_int64, c_int64, _P, _P]),
     "gcr_spmm_csr_dual_f32": (c_int32, [_P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, c_float, _P, c_int32,
                                         _P, _P, _P, _P, c_int64, c_int64, _P]),
     "gcr_csr_validate": (c_int32, [_P, _P, c_int64, c_int64, c_int64, _P, _P]),

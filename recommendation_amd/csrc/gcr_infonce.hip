@@ -2117,11 +2117,14 @@ __global__ __launch_bounds__(256, 2) void kmeans_assign_b3_kernel(
     constexpr int NVX = (D + 63) / 64;
 #pragma unroll
     for (int t = 0; t < S::NT; ++t) {
-      for (int p0 = 0; p0 < 32; p0 += 8) {
-        float xv[8][NVX];
-        int cj[8];
+      // all rows of the tile in flight at once (d <= 64: 32 loads; a batch of 8 per round trip left the wave waiting on
+      // eight dependent L2 round trips per tile: ~20 of the iteration's 53 us), then the row atomics
+      constexpr int PB = NVX == 1 ? 32 : 8;
+      for (int p0 = 0; p0 < 32; p0 += PB) {
+        float xv[PB][NVX];
+        int cj[PB];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < PB; ++q) {
           const int64_t row = i0 + 32 * t + p0 + q;
           cj[q] = __builtin_amdgcn_readlane(btile[t], p0 + q);
           if (row >= n || cj[q] < 0 || cj[q] >= k) cj[q] = -1;
@@ -2130,7 +2133,7 @@ __global__ __launch_bounds__(256, 2) void kmeans_assign_b3_kernel(
           for (int c = 0; c < NVX; ++c) xv[q][c] = (lane + 64 * c < D) ? xp[lane + 64 * c] : 0.f;
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < PB; ++q) {
           if (cj[q] < 0) continue;                        // wave-uniform
 #pragma unroll
           for (int c = 0; c < NVX; ++c)

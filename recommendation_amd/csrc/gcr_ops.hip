@@ -172,6 +172,21 @@ extern "C" int32_t gcr_adam_step_dev_f32(float* param, const float* grad, const 
   return GCR_LAUNCH_STATUS();
 }
 
+__global__ void bitmap_set_kernel(const int64_t* __restrict__ idx, int64_t n, int64_t n_bits, uint32_t* __restrict__ bits) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = idx[i];
+    if (b >= 0 && b < n_bits) atomicOr(bits + (b >> 5), 1u << (b & 31));
+  }
+}
+
+extern "C" int32_t gcr_bitmap_set(const int64_t* idx, int64_t n, int64_t n_bits, uint32_t* bits, void* stream) {
+  GCR_CHECK_ARG(n >= 0 && n_bits >= 0);
+  if (n == 0) return GCR_OK;
+  GCR_CHECK_ARG(idx && bits);
+  hipLaunchKernelGGL(bitmap_set_kernel, dim3(ops_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, idx, n, n_bits, bits);
+  return GCR_LAUNCH_STATUS();
+}
+
 extern "C" int32_t gcr_mask_columns_f32(const float* x, int64_t n, int32_t d, const uint32_t* keep_bits, float* out,
                                         void* stream) {
   GCR_CHECK_ARG(n >= 0 && d >= 1);

@@ -37,6 +37,7 @@ struct Epilogue {
   float* y_raw;          // second output under ROW_L2NORM: the product before the row normalise (mhcn.py:440-442)
   const float* acc_in2;  // second addend of the combine, with its own scale (the per-layer gradient of the Horner backward)
   float acc_in2_scale;
+  const uint32_t* col_bits;   // host-side dispatch only (COLMASK instantiation): never read through the struct on the device
 };
 
 // ACC2: the second-addend form is its own instantiation — read unconditionally, its pointer and scale cost the hot
@@ -79,7 +80,11 @@ __device__ __forceinline__ void store_row(const Epilogue& ep, int64_t row, int d
   }
 }
 
-template <int NV, bool D64, bool HAS_VAL, bool MASKED, int UNR, bool ACC2>
+// COLMASK: `keep_bits` is a bitmap over the COLUMNS (bit c set = row c of x may be non-zero) instead of over the stored
+// non-zeros: non-zeros whose column is clear are skipped before their 256-B gather — the first launch of a backward pass
+// whose incoming gradient has a few thousand non-zero rows of a million (the NCL step: DESIGN 4.5) reads the CSR and
+// writes its output, but gathers almost nothing.
+template <int NV, bool D64, bool HAS_VAL, bool MASKED, int UNR, bool ACC2, bool COLMASK = false>
 __global__ __launch_bounds__(256) void spmm_parts(const int64_t* __restrict__ desc, int64_t n_parts,
                                                   const int64_t* __restrict__ rowptr,
                                                   const int32_t* __restrict__ col,
@@ -130,9 +135,10 @@ __global__ __launch_bounds__(256) void spmm_parts(const int64_t* __restrict__ de
       const int64_t e = nnz0 + b + lane;
       cv = col[e];
       vv = HAS_VAL ? val[e] : 1.0f;
-      if (MASKED) keep = (keep_bits[e >> 5] >> (e & 31)) & 1u;
+      if (MASKED && !COLMASK) keep = (keep_bits[e >> 5] >> (e & 31)) & 1u;
+      if (COLMASK) keep = (keep_bits[cv >> 5] >> (cv & 31)) & 1u;
     }
-    unsigned long long todo = MASKED ? __ballot(keep) : (m == 64 ? ~0ull : ((1ull << m) - 1ull));
+    unsigned long long todo = (MASKED || COLMASK) ? __ballot(keep) : (m == 64 ? ~0ull : ((1ull << m) - 1ull));
     int cnt = __builtin_popcountll(todo);
 
     while (cnt >= UNR) {
@@ -254,7 +260,14 @@ int32_t launch_spmm_a(const int64_t* desc, int64_t n_parts, const int32_t* long_
 #define GCR_SPMM_LAUNCH(HV, MK)                                                                             \
   hipLaunchKernelGGL((spmm_parts<NV, D64, HV, MK, unroll_for<NV>(), ACC2>), dim3(blocks), dim3(256), 0, stream, desc, n_parts, \
                      rowptr, col, val, keep_bits, x, d, ep, partials)
-    if (val != nullptr) {
+    if (ep.col_bits != nullptr) {
+      if (val != nullptr)
+        hipLaunchKernelGGL((spmm_parts<NV, D64, true, false, unroll_for<NV>(), ACC2, true>), dim3(blocks), dim3(256), 0,
+                           stream, desc, n_parts, rowptr, col, val, ep.col_bits, x, d, ep, partials);
+      else
+        hipLaunchKernelGGL((spmm_parts<NV, D64, false, false, unroll_for<NV>(), ACC2, true>), dim3(blocks), dim3(256), 0,
+                           stream, desc, n_parts, rowptr, col, val, ep.col_bits, x, d, ep, partials);
+    } else if (val != nullptr) {
       if (keep_bits != nullptr) GCR_SPMM_LAUNCH(true, true);
       else GCR_SPMM_LAUNCH(true, false);
     } else {
@@ -293,7 +306,7 @@ extern "C" int32_t gcr_spmm_csr_acc2_f32(const int64_t* desc, int64_t n_parts, c
                                          float val_scale, const float* x, int32_t d, float* y, const float* acc_in,
                                          const float* acc_in2, float acc_in2_scale, float* acc_out, float acc_scale,
                                          uint32_t flags, float* inv_norm_out, float* partials, int64_t n_rows,
-                                         int64_t n_cols, void* stream) {
+                                         int64_t n_cols, const uint32_t* col_active_bits, void* stream) {
   GCR_CHECK_ARG(n_parts >= 0 && n_long_rows >= 0 && n_rows >= 0 && n_cols >= 0);
   GCR_CHECK_ARG(n_parts < (1ll << 31) - 4 && n_rows < (1ll << 31) && n_cols < (1ll << 31));
   GCR_CHECK_ARG(d >= 1 && d <= 256);
@@ -301,9 +314,10 @@ extern "C" int32_t gcr_spmm_csr_acc2_f32(const int64_t* desc, int64_t n_parts, c
   GCR_CHECK_ARG(desc != nullptr && rowptr != nullptr && x != nullptr);
   GCR_CHECK_ARG(y != nullptr || acc_out != nullptr);
   GCR_CHECK_ARG(acc_in2 == nullptr || acc_out != nullptr);
+  GCR_CHECK_ARG(col_active_bits == nullptr || keep_bits == nullptr);       // one predicate per launch
   GCR_CHECK_ARG(n_long_rows == 0 || (long_row != nullptr && long_slot0 != nullptr && partials != nullptr));
   GCR_CHECK_ARG((flags & ~GCR_SPMM_ROW_L2NORM) == 0);
-  Epilogue ep{val_scale, y, acc_in, acc_out, acc_scale, flags, inv_norm_out, nullptr, acc_in2, acc_in2_scale};
+  Epilogue ep{val_scale, y, acc_in, acc_out, acc_scale, flags, inv_norm_out, nullptr, acc_in2, acc_in2_scale, col_active_bits};
   hipStream_t s = (hipStream_t)stream;
 #define GCR_GO(NV, D64) \
   return launch_spmm<NV, D64>(desc, n_parts, long_row, long_slot0, n_long_rows, rowptr, col, val, keep_bits, x, d, ep, partials, s)
@@ -323,7 +337,7 @@ extern "C" int32_t gcr_spmm_csr_f32(const int64_t* desc, int64_t n_parts, const 
                                     float* partials, int64_t n_rows, int64_t n_cols, void* stream) {
   return gcr_spmm_csr_acc2_f32(desc, n_parts, long_row, long_slot0, n_long_rows, rowptr, col, val, keep_bits, val_scale,
                                x, d, y, acc_in, nullptr, 0.f, acc_out, acc_scale, flags, inv_norm_out, partials, n_rows,
-                               n_cols, stream);
+                               n_cols, nullptr, stream);
 }
 
 extern "C" int32_t gcr_spmm_csr_dual_f32(const int64_t* desc, int64_t n_parts, const int32_t* long_row,
@@ -339,7 +353,7 @@ extern "C" int32_t gcr_spmm_csr_dual_f32(const int64_t* desc, int64_t n_parts, c
   GCR_CHECK_ARG(desc != nullptr && rowptr != nullptr && x != nullptr && y_raw != nullptr && y_norm != nullptr);
   GCR_CHECK_ARG(y_raw != y_norm);
   GCR_CHECK_ARG(n_long_rows == 0 || (long_row != nullptr && long_slot0 != nullptr && partials != nullptr));
-  Epilogue ep{val_scale, y_norm, nullptr, nullptr, 1.0f, GCR_SPMM_ROW_L2NORM, inv_norm_out, y_raw, nullptr, 0.f};
+  Epilogue ep{val_scale, y_norm, nullptr, nullptr, 1.0f, GCR_SPMM_ROW_L2NORM, inv_norm_out, y_raw, nullptr, 0.f, nullptr};
   hipStream_t s = (hipStream_t)stream;
 #define GCR_GO(NV, D64) \
   return launch_spmm<NV, D64>(desc, n_parts, long_row, long_slot0, n_long_rows, rowptr, col, val, keep_bits, x, d, ep, partials, s)

@@ -25,11 +25,15 @@ def _check_dense(x, n_rows, name):
 
 
 def spmm_into(graph: CsrGraph, x, *, y=None, acc_in=None, acc_out=None, acc_scale=1.0, val_scale=1.0,
-              keep_bits=None, l2norm=False, inv_norm_out=None, acc_in2=None, acc_in2_scale=1.0):
+              keep_bits=None, l2norm=False, inv_norm_out=None, acc_in2=None, acc_in2_scale=1.0, col_active_bits=None):
     """Raw launch of gcr_spmm_csr_acc2_f32: y = epilogue(val_scale * A[keep] x); optional fused layer
     combine acc_out = (acc_in + acc_in2_scale * acc_in2 + y) * acc_scale (lightgcn.py:26, ncl.py:421) and row L2
-    normalise (sept.py:224).  Outputs are caller-allocated; nothing is recorded for autograd."""
-    _lib.require_cuda(x, y, acc_in, acc_out, keep_bits, inv_norm_out, acc_in2)
+    normalise (sept.py:224).  col_active_bits: an int32 bitmap over the rows of x, clear = that row is zero (its
+    non-zeros are skipped; `active_rows_bitmap`).  Outputs are caller-allocated; nothing is recorded for autograd."""
+    _lib.require_cuda(x, y, acc_in, acc_out, keep_bits, inv_norm_out, acc_in2, col_active_bits)
+    if col_active_bits is not None and (col_active_bits.dtype != torch.int32 or col_active_bits.numel() * 32 < graph.n_cols
+                                        or keep_bits is not None):
+        raise ValueError("col_active_bits must be an int32 bitmap with >= n_cols bits (and excludes keep_bits)")
     x = x.contiguous()
     _check_dense(x, graph.n_cols, "x")
     d = x.shape[1]
@@ -57,12 +61,23 @@ def spmm_into(graph: CsrGraph, x, *, y=None, acc_in=None, acc_out=None, acc_scal
         _lib.dptr(graph.rowptr), _lib.dptr(graph.col), _lib.dptr(graph.val), _lib.dptr(keep_bits), float(val_scale),
         _lib.dptr(x), d, _lib.dptr(y), _lib.dptr(acc_in), _lib.dptr(acc_in2), float(acc_in2_scale), _lib.dptr(acc_out),
         float(acc_scale), SPMM_ROW_L2NORM if l2norm else 0, _lib.dptr(inv_norm_out), _lib.dptr(ws),
-        graph.n_rows, graph.n_cols, _lib.cur_stream(x.device))
+        graph.n_rows, graph.n_cols, _lib.dptr(col_active_bits), _lib.cur_stream(x.device))
     _lib.check(rc, "gcr_spmm_csr_acc2_f32")
     if sink is not None:
         ev1.record()
         sink.append((ev0, ev1))
     return y if y is not None else acc_out
+
+
+def active_rows_bitmap(idx, n_rows):
+    """int32 bitmap with bit r set for every r in `idx` (int64 ids; out-of-range ids ignored): the `col_active_bits` of a
+    launch whose input is zero outside those rows (gcr_bitmap_set)."""
+    idx = _as_index(idx, idx.device if isinstance(idx, torch.Tensor) else None).reshape(-1)
+    _lib.require_cuda(idx)
+    bits = torch.zeros((int(n_rows) + 31) // 32, dtype=torch.int32, device=idx.device)
+    _lib.check(_lib.lib().gcr_bitmap_set(_lib.dptr(idx), idx.numel(), int(n_rows), _lib.dptr(bits), _lib.cur_stream(idx.device)),
+               "gcr_bitmap_set")
+    return bits
 
 
 class _SpMM(torch.autograd.Function):

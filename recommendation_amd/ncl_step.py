@@ -13,7 +13,8 @@ buffer or a separate add pass:
                   in place, the prototype rows' gradients scattered on top                       (ncl.py:358-375)
             Zg  = d loss / d final from BPR, scattered into the step's only zero-filled buffer      (ncl.py:314-317)
             Horner recurrence of the K-layer pass on A^T:  h_K = Zg (+ g_ctx / c if the context layer is the last),
-                  h_k = Zg + A^T h_{k+1}, with the context rows' sparse gradient ADDED AFTER the launch that produces
+                  h_k = Zg + A^T h_{k+1} — the FIRST launch with a column bitmap of the <= 3 B non-zero rows of h_K, so it
+                  gathers almost nothing — with the context rows' sparse gradient ADDED AFTER the launch that produces
                   its layer's h (4096 row atomics instead of a dense addend), dx0 = c (Zg + G0 / c + A^T h_1): the last
                   launch takes G0 as the epilogue's second addend                                   (ncl.py:415-422)
             Adam (gcr_adam_step_f32 / _dev_f32) on the two parameter views of the stacked table      (ncl.py:305,327-329)
@@ -197,17 +198,23 @@ class FusedNCLStep:
                        "gcr_scatter_add_rows_f32")
 
         h = zg
+        # h_K is zero outside the batch rows (<= 3 B, + 2 B context rows when the context layer is the last): the first
+        # launch skips every non-zero whose column is clear in this bitmap before its gather
+        active = [user_idx, pos_idx + n_u, neg_idx + n_u]
         if ci == K:
             h = zg.clone()
             add_ctx(h)
+            active.append(gat)
+        bits = Fn.active_rows_bitmap(torch.cat(active), n)
         for k in range(K - 1, 0, -1):
             out = torch.empty_like(x0)
-            Fn.spmm_into(gt, h, acc_in=zg, acc_out=out)
+            Fn.spmm_into(gt, h, acc_in=zg, acc_out=out, col_active_bits=bits)
+            bits = None                            # the product of a sparse input is dense enough already
             if k == ci:
                 add_ctx(out)                       # the context layer's sparse gradient joins h_k after the launch
             h = out
         dx0 = torch.empty_like(x0)
-        Fn.spmm_into(gt, h, acc_in=zg, acc_in2=g0, acc_in2_scale=inv_c, acc_out=dx0, acc_scale=c)
+        Fn.spmm_into(gt, h, acc_in=zg, acc_in2=g0, acc_in2_scale=inv_c, acc_out=dx0, acc_scale=c, col_active_bits=bits)
 
         # ---- Adam on the two parameter views of the stacked table (ncl.py:327-329) ----
         pu, pi = enc.embedding_dict["user_emb"], enc.embedding_dict["item_emb"]

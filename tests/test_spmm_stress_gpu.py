@@ -76,3 +76,30 @@ def test_random_graphs_all_variants(seed):
     if desc.shape[0]:
         assert desc[0, 0] == 0 and desc[-1, 1] == nnz and np.array_equal(desc[1:, 0], desc[:-1, 1])
         assert (desc[:, 1] - desc[:, 0]).max() <= L
+
+
+def test_column_bitmap_skips_only_zero_rows():
+    """gcr_spmm_csr_acc2_f32 with col_active_bits: a launch whose input is zero outside a few thousand rows (the first
+    backward launch of the NCL step) skips the non-zeros of every other column — and a skipped term is w * 0, so the result
+    is bit for bit the unmasked one (also through split rows and the fused combine)."""
+    import recommendation_amd as ra
+    from recommendation_amd import functional as Fn
+    n_u, n_i = 20000, 1500
+    u, i = O.synthetic_interactions(n_u, n_i, 300000, seed=11)
+    g = ra.CsrGraph.bipartite_sym_norm(u, i, n_u, n_i, "cuda")
+    assert g.plan.n_long > 0
+    n = n_u + n_i
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    rows = torch.randint(0, n, (700,), device="cuda", generator=gen)
+    x = torch.zeros(n, 64, device="cuda")
+    x[rows] = torch.randn(700, 64, device="cuda", generator=gen)
+    acc = torch.randn(n, 64, device="cuda", generator=gen)
+    bits = Fn.active_rows_bitmap(rows, n)
+    a, b = torch.empty_like(x), torch.empty_like(x)
+    Fn.spmm_into(g, x, acc_in=acc, acc_out=a, acc_scale=0.25)
+    Fn.spmm_into(g, x, acc_in=acc, acc_out=b, acc_scale=0.25, col_active_bits=bits)
+    assert torch.equal(a, b)
+    ref = torch.zeros(n, dtype=torch.bool, device="cuda")
+    ref[rows] = True
+    got = ((bits.view(-1, 1) >> torch.arange(32, device="cuda", dtype=torch.int32)) & 1).reshape(-1)[:n].bool()
+    assert torch.equal(got, ref)

@@ -282,6 +282,13 @@ constexpr float kDefer = 8.0f;
 //          the reference) go sub-normal, which v_cvt_pk_f16_f32 produces and v_mfma_f32_32x32x16_f16 honours
 //          (scripts/exp/f16_denorm_probe.hip, run on the box): their absolute error stays <= 2^-25 of the scaled unit.
 // ------------------------------------------------------------------------------------------
+// operand-split form of EngH2 inside the two-product loop (EngH2::split): measured on one box at 2048 x 1M x 64 —
+//   MODE 1 (flash forward)        form 0: 1.81 ms   form 1: 1.70   form 2: same as form 1 within noise (1.55-1.59 both)
+//   MODE 0 (table-side backward)  form 0: 1.78 ms   form 1: 1.88   form 2: 1.90
+// fewer vector instructions do NOT make the backward loop faster (the mixed-precision forms are opaque asm statements to
+// the scheduler, and the loop is bound by waits, not by its instruction count: DESIGN 4.2b); each mode keeps its best.
+template <int MODE>
+constexpr int kSplitForm = MODE == 1 ? 1 : 0;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 struct EngB3 {
@@ -293,7 +300,7 @@ struct EngB3 {
   static constexpr float kDeferE = kDefer;
   static __host__ __device__ constexpr int ta(int t) { constexpr int v[6] = {2, 0, 1, 1, 0, 0}; return v[t]; }   // streamed-side
   static __host__ __device__ constexpr int tb(int t) { constexpr int v[6] = {0, 2, 1, 0, 1, 0}; return v[t]; }   // plane / other
-  template <bool MIX = true>
+  template <int MIX = 1>
   static __device__ __forceinline__ void split(float a, float b, unsigned (&p)[3]) { split3(a, b, p[0], p[1], p[2]); }
   static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) { return mfma_bf16(a, b, c); }
 };
@@ -307,16 +314,25 @@ struct EngH2 {
   static constexpr float kDeferE = 1.0f;
   static __host__ __device__ constexpr int ta(int t) { constexpr int v[3] = {1, 0, 0}; return v[t]; }
   static __host__ __device__ constexpr int tb(int t) { constexpr int v[3] = {0, 1, 0}; return v[t]; }
-  // MIX: the residuals a - hi[0], b - hi[1] by one mixed-precision FMA each (v_fma_mix_f32 reads the f16 half in
-  // place, no f16 -> f32 convert; the compiler does not form it from the plain expression).  Measured on one box
-  // (2048 x 1M x 64): flash forward 1.81 -> 1.70 ms with it, the backward loop 1.77 -> 1.88 without — so the
-  // backward (MODE 0) keeps the convert + subtract
-  template <bool MIX = true>
+  // The lo plane = f16(x - hi) straight out of ONE mixed-precision FMA per value: v_fma_mixlo_f16 / v_fma_mixhi_f16 read
+  // the f16 half of `hi` in place, subtract it from the f32 value in f32 (exact: the difference of a value and its 11-bit
+  // rounding has <= 13 significant bits) and round the result to f16 into the low / high half of the destination (RNE,
+  // sub-normals kept, like v_cvt_pk_f16_f32): THREE instructions per pair of values, bit for bit the planes of the plain
+  // form (convert, two f16 -> f32 converts, two subtracts, convert: six; `MIX = 0`, kept for reference and A/B).
+  // Round 2's v_fma_mix_f32 form (residual in f32, then a second convert: four) is `MIX = 1`.
+  template <int MIX = 1>
   static __device__ __forceinline__ void split(float a, float b, unsigned (&p)[2]) {
     const f16x2 hi = __builtin_convertvector((f32x2){a, b}, f16x2);                 // v_cvt_pk_f16_f32, RNE
     p[0] = __builtin_bit_cast(unsigned, hi);
+    if (MIX == 2) {
+      unsigned lo;
+      asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(p[0]), "v"(a));
+      asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(p[0]), "v"(b));
+      p[1] = lo;
+      return;
+    }
     float ra, rb;
-    if (MIX) {
+    if (MIX == 1) {
       asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(p[0]), "v"(a));
       asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(p[0]), "v"(b));
     } else {
@@ -1345,9 +1361,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
       const int idx = tid + THREADS * u;
       const int row = idx / (D / 4), c4 = idx % (D / 4);
       if (k == 0) {
-        E::template split<MODE == 1>(st[u].x, st[u].y, sa[u]);
+        E::template split<kSplitForm<MODE>>(st[u].x, st[u].y, sa[u]);
       } else if (k == 1) {
-        E::template split<MODE == 1>(st[u].z, st[u].w, sb[u]);
+        E::template split<kSplitForm<MODE>>(st[u].z, st[u].w, sb[u]);
       } else {
         unsigned char* p = rm + row * S::ROWB + c4 * 8;
         if (THREADS * NLDW == F4T || idx < F4T) {
@@ -1397,6 +1413,17 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
         p_off = E::kPExp - m_use;
       }
     };
+    // streamed rows' statistics (MODE 0, SIDES != 1): accumulator register r = 4 g + e of lane half h is tile row
+    // 8 g + 4 h + e, so ONE ds_read_b128 per array serves four consecutive P units; group g + 1 is fetched while group g
+    // is being used (16 registers).  Per-unit ds_read_b32 pairs were 32 LDS instructions per tile: 9 % of the backward
+    // (timing-only build with constants: 1.82 -> 1.66 ms).
+    float4 sl4[2], sw4[2];
+    auto stats_begin = [&](int sbuf) {
+      if (MODE == 0 && SIDES != 1) {
+        sl4[0] = *reinterpret_cast<const float4*>(&st_lse[sbuf][4 * h]);
+        sw4[0] = *reinterpret_cast<const float4*>(&st_w[sbuf][4 * h]);
+      }
+    };
     auto p_unit = [&](int m, f32x16& acc, int sbuf, unsigned (&pq)[2][NPL][4]) {
       if (m < 16) {
         const int r = m;
@@ -1404,7 +1431,17 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
           acc[r] = __builtin_amdgcn_exp2f(fmaf(acc[r], E::kSInv, p_off));
           psum += acc[r];
         } else {
-          const float lre = st_lse[sbuf][acc_row(r, h)], wre = st_w[sbuf][acc_row(r, h)];
+          float lre = 0.f, wre = 0.f;
+          if (SIDES != 1) {
+            const int g = r >> 2, e = r & 3;
+            if (e == 0 && g < 3) {
+              sl4[(g + 1) & 1] = *reinterpret_cast<const float4*>(&st_lse[sbuf][8 * (g + 1) + 4 * h]);
+              sw4[(g + 1) & 1] = *reinterpret_cast<const float4*>(&st_w[sbuf][8 * (g + 1) + 4 * h]);
+            }
+            const float4 l4 = sl4[g & 1], w4 = sw4[g & 1];
+            lre = e == 0 ? l4.x : (e == 1 ? l4.y : (e == 2 ? l4.z : l4.w));
+            wre = e == 0 ? w4.x : (e == 1 ? w4.y : (e == 2 ? w4.z : w4.w));
+          }
           const float sc = acc[r];
           if (SIDES == 1) acc[r] = wl * __builtin_amdgcn_exp2f(fmaf(sc, E::kSInv, -lse2l));
           else if (SIDES == 2) acc[r] = wre * __builtin_amdgcn_exp2f(fmaf(sc, E::kSInv, -lre));
@@ -1413,7 +1450,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
       } else {
         const int e = m - 16;                            // pair (2e, 2e + 1): k-chunk e / 4, dword e % 4
         unsigned q[NPL];
-        E::template split<MODE == 1>(acc[2 * e], acc[2 * e + 1], q);
+        E::template split<kSplitForm<MODE>>(acc[2 * e], acc[2 * e + 1], q);
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) pq[e >> 2][pl][e & 3] = q[pl];
       }
@@ -1456,6 +1493,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
     __syncthreads();
     score_plain(lds_rm[0], acc);
     prepare(acc, tile0);
+    stats_begin(0);
 #pragma unroll
     for (int m = 0; m < 24; ++m) p_unit(m, acc, 0, pqa);
     finish_p();
@@ -1502,6 +1540,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
       }
       if (NW == 8) __syncthreads();                      // interval boundary: the partner group moves on to its score phase
       if (MODE == 0 || real_next) prepare(acc, t + 1);
+      stats_begin(slot1);
       __builtin_amdgcn_sched_barrier(0);
       // phase B: second product of tile t || P(t+1)
       // A operand yhat^T[feature][tile row] straight from the ROW-MAJOR planes with the transposing LDS read

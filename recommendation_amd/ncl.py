@@ -19,7 +19,7 @@ from . import functional as Fn
 from . import losses as Ls
 from .encoders import Interaction, LGCNEncoder
 from .evaluate import ranking_evaluation, test as rank_test
-from .kmeans import FAISS_NITER, FAISS_SEED, assign_to_centroids, run_kmeans
+from .kmeans import FAISS_MIN_POINTS_PER_CENTROID, FAISS_NITER, FAISS_SEED, assign_to_centroids, run_kmeans
 from .ncl_step import FusedNCLStep
 from .optim import FusedAdam
 from .sampler import next_batch_pairwise
@@ -59,6 +59,7 @@ class NCLModel:
         self.model = LGCNEncoder(self.data, self.emb_size, self.n_layers)
         self.user_centroids = self.item_centroids = None
         self._user_2cluster = self._item_2cluster = self._e_inputs = None
+        self.concurrent_e_step, self._e_streams = True, None
         self.bestPerformance = []
 
     @classmethod
@@ -85,11 +86,31 @@ class NCLModel:
             # ncl.py:350-351 clamps `self.k = min(self.k, max(2, n // 39))` and KEEPS it: the item k-means
             # inherits the users' clamp and, from the second e_step on, the users inherit the items'
             # ncl.py:352 builds a fresh faiss.Kmeans for each table: both run with the same seed
-            self.user_centroids, self._user_2cluster = run_kmeans(user_emb.contiguous(), self.k, niter=self.kmeans_niter,
-                                                                  seed=self.kmeans_seed, assign_points=assign_all)
-            self.k = int(self.user_centroids.shape[0])
-            self.item_centroids, self._item_2cluster = run_kmeans(item_emb.contiguous(), self.k, niter=self.kmeans_niter,
-                                                                  seed=self.kmeans_seed, assign_points=assign_all)
+            k_users = min(int(self.k), max(2, user_emb.shape[0] // FAISS_MIN_POINTS_PER_CENTROID))
+            k_items = min(k_users, max(2, item_emb.shape[0] // FAISS_MIN_POINTS_PER_CENTROID))
+            kw = dict(niter=self.kmeans_niter, seed=self.kmeans_seed, assign_points=assign_all)
+            if user_emb.is_cuda and self.concurrent_e_step:
+                # the two k-means are independent and each is a chain of short launches that leaves most of the chip idle
+                # (~300 workgroups per search): run them side by side on two streams, join on the caller's
+                dev = user_emb.device
+                cur = torch.cuda.current_stream(dev)
+                if self._e_streams is None:
+                    self._e_streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+                res = []
+                for s, (x, k) in zip(self._e_streams, ((user_emb, k_users), (item_emb, k_items))):
+                    s.wait_stream(cur)
+                    with torch.cuda.stream(s):
+                        res.append(run_kmeans(x.contiguous(), k, **kw))
+                for s in self._e_streams:
+                    cur.wait_stream(s)
+                for c, a in res:
+                    c.record_stream(cur)
+                    if a is not None:
+                        a.record_stream(cur)
+                (self.user_centroids, self._user_2cluster), (self.item_centroids, self._item_2cluster) = res
+            else:
+                self.user_centroids, self._user_2cluster = run_kmeans(user_emb.contiguous(), k_users, **kw)
+                self.item_centroids, self._item_2cluster = run_kmeans(item_emb.contiguous(), k_items, **kw)
             self.k = int(self.item_centroids.shape[0])
             self._e_inputs = None if assign_all else (user_emb, item_emb)
 

@@ -44,6 +44,14 @@ class FusedNCLStep:
         # False: leave the per-batch e_step (ncl.py:324) out and contrast against the centroids the owner already holds —
         # NOT the reference's loop body; bench.py uses it to report the e_step's share of the step
         self.e_step_every_batch = True
+        # True: the table-side gradient branch of the backward runs on a side stream beside the SpMM recurrence
+        self.overlap_backward = True
+        self._side = None
+
+    def _side_stream(self, dev):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=dev)
+        return self._side
 
     @staticmethod
     def supported(owner):
@@ -156,33 +164,55 @@ class FusedNCLStep:
         total = rec_loss + l2 / o_.batch_size + ssl_loss + proto_loss
 
         # =================================== backward ===================================
-        # G0: gradient w.r.t. the layer-0 table through the structure contrast's candidate side
+        # Two independent branches meet in the LAST launch of the Horner recurrence:
+        #   branch T (matrix-core bound, ~2.4 ms at cfg3): G0 = gradient w.r.t. the layer-0 table through the structure
+        #            contrast's candidate side (+ positives, F.normalize backward, prototype rows)
+        #   branch S (HBM bound, ~1.0 ms): anchor-side gradients, Zg from BPR, every launch of the recurrence but the last
+        # With `overlap_backward` branch T runs on a side stream beside branch S (the table-side kernel leaves one wave slot
+        # per SIMD that an SpMM wave fits into); the join is in front of the launch that takes G0 as its second addend.
         g0 = torch.empty_like(x0)
-        Fn._infonce_bwd_raw(xu, sbu, rows_c[:bsz], sa[:bsz], inv_tau, None, None, lse[:bsz], w[:bsz], engine_flag=eng, out=g0[:n_u])
-        Fn._infonce_bwd_raw(xi, sbi, rows_c[bsz:], sa[bsz:], inv_tau, None, None, lse[bsz:], w[bsz:], engine_flag=eng, out=g0[n_u:])
+        main = torch.cuda.current_stream(dev)
+        side = self._side_stream(dev) if (self.overlap_backward and K > 1) else None
+
+        def branch_table():
+            st = _lib.cur_stream(dev)
+            Fn._infonce_bwd_raw(xu, sbu, rows_c[:bsz], sa[:bsz], inv_tau, None, None, lse[:bsz], w[:bsz], engine_flag=eng, out=g0[:n_u])
+            Fn._infonce_bwd_raw(xi, sbi, rows_c[bsz:], sa[bsz:], inv_tau, None, None, lse[bsz:], w[bsz:], engine_flag=eng, out=g0[n_u:])
+            for a_sl, tab, stab, pos, g_tab in ((slice(0, bsz), xu, sbu, user_idx, g0[:n_u]), (slice(bsz, 2 * bsz), xi, sbi, pos_idx, g0[n_u:])):
+                _lib.check(L.gcr_infonce_pos_bwd_f32(_lib.dptr(rows_c[a_sl]), _lib.dptr(sa[a_sl]), _lib.dptr(tab), _lib.dptr(stab),
+                                                     _lib.dptr(pos), _lib.dptr(neg_w[a_sl]), bsz, tab.shape[0], d, inv_tau,
+                                                     None, _lib.dptr(g_tab), st), "gcr_infonce_pos_bwd_f32")
+            _lib.check(L.gcr_normalize_bwd_f32(_lib.dptr(x0), _lib.dptr(sb), _lib.dptr(g0), n, d, _lib.dptr(g0), st),
+                       "gcr_normalize_bwd_f32")
+            # prototype rows: only the anchors get a gradient (the centroids are constants of the e_step)
+            gp = o_p * (wp * inv_tau)
+            neg_wp = torch.full((2 * bsz,), -wp, dtype=torch.float32, device=dev)
+            for lo in (0, bsz):
+                sl = slice(lo, lo + bsz)
+                _lib.check(L.gcr_infonce_pos_bwd_f32(_lib.dptr(rows_0[sl]), _lib.dptr(s0[sl]), _lib.dptr(cents[sl]), _lib.dptr(sc[sl]),
+                                                     None, _lib.dptr(neg_wp[sl]), bsz, bsz, d, inv_tau, _lib.dptr(gp[sl]), None,
+                                                     st), "gcr_infonce_pos_bwd_f32")
+            _lib.check(L.gcr_normalize_bwd_f32(_lib.dptr(rows_0), _lib.dptr(s0), _lib.dptr(gp), 2 * bsz, d, _lib.dptr(gp), st),
+                       "gcr_normalize_bwd_f32")
+            _lib.check(L.gcr_scatter_add_rows_f32(_lib.dptr(gp), _lib.dptr(gat), 2 * bsz, d, n, _lib.dptr(g0), st),
+                       "gcr_scatter_add_rows_f32")
+
+        neg_w = -w
+        if side is not None:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                branch_table()
+        else:
+            branch_table()
+
         # anchor side: softmax part = w * inv_tau * o (the flash forward kept o), positives added, then F.normalize backward
         ga = o * (w * inv_tau).unsqueeze(1)
-        neg_w = -w
-        for a_sl, tab, stab, pos, g_tab in ((slice(0, bsz), xu, sbu, user_idx, g0[:n_u]), (slice(bsz, 2 * bsz), xi, sbi, pos_idx, g0[n_u:])):
+        for a_sl, tab, stab, pos in ((slice(0, bsz), xu, sbu, user_idx), (slice(bsz, 2 * bsz), xi, sbi, pos_idx)):
             _lib.check(L.gcr_infonce_pos_bwd_f32(_lib.dptr(rows_c[a_sl]), _lib.dptr(sa[a_sl]), _lib.dptr(tab), _lib.dptr(stab),
                                                  _lib.dptr(pos), _lib.dptr(neg_w[a_sl]), bsz, tab.shape[0], d, inv_tau,
-                                                 _lib.dptr(ga[a_sl]), _lib.dptr(g_tab), stream), "gcr_infonce_pos_bwd_f32")
+                                                 _lib.dptr(ga[a_sl]), None, stream), "gcr_infonce_pos_bwd_f32")
         _lib.check(L.gcr_normalize_bwd_f32(_lib.dptr(rows_c), _lib.dptr(sa), _lib.dptr(ga), 2 * bsz, d, _lib.dptr(ga), stream),
                    "gcr_normalize_bwd_f32")
-        _lib.check(L.gcr_normalize_bwd_f32(_lib.dptr(x0), _lib.dptr(sb), _lib.dptr(g0), n, d, _lib.dptr(g0), stream),
-                   "gcr_normalize_bwd_f32")
-        # prototype rows: only the anchors get a gradient (the centroids are constants of the e_step)
-        gp = o_p * (wp * inv_tau)
-        neg_wp = torch.full((2 * bsz,), -wp, dtype=torch.float32, device=dev)
-        for lo in (0, bsz):
-            sl = slice(lo, lo + bsz)
-            _lib.check(L.gcr_infonce_pos_bwd_f32(_lib.dptr(rows_0[sl]), _lib.dptr(s0[sl]), _lib.dptr(cents[sl]), _lib.dptr(sc[sl]),
-                                                 None, _lib.dptr(neg_wp[sl]), bsz, bsz, d, inv_tau, _lib.dptr(gp[sl]), None,
-                                                 stream), "gcr_infonce_pos_bwd_f32")
-        _lib.check(L.gcr_normalize_bwd_f32(_lib.dptr(rows_0), _lib.dptr(s0), _lib.dptr(gp), 2 * bsz, d, _lib.dptr(gp), stream),
-                   "gcr_normalize_bwd_f32")
-        _lib.check(L.gcr_scatter_add_rows_f32(_lib.dptr(gp), _lib.dptr(gat), 2 * bsz, d, n, _lib.dptr(g0), stream),
-                   "gcr_scatter_add_rows_f32")
 
         # Zg: d total / d final (BPR rows), the only zero-filled [N, d] buffer of the step
         zg = torch.zeros_like(x0)
@@ -213,6 +243,8 @@ class FusedNCLStep:
             if k == ci:
                 add_ctx(out)                       # the context layer's sparse gradient joins h_k after the launch
             h = out
+        if side is not None:
+            main.wait_stream(side)                 # G0 complete
         dx0 = torch.empty_like(x0)
         Fn.spmm_into(gt, h, acc_in=zg, acc_in2=g0, acc_in2_scale=inv_c, acc_out=dx0, acc_scale=c, col_active_bits=bits)
 

@@ -26,7 +26,11 @@ def encode_raw_ids(values):
     the order Python's `sorted()` gives the ids (ncl.py:60-61): integers by value, strings by code point (= by UTF-8
     byte, packed big-endian eight bytes per word, NUL-padded: a prefix sorts first).  None: ids of another type (the
     caller then keeps the host dict path)."""
+    if not all(isinstance(v, (str, int, np.integer, np.str_)) and not isinstance(v, bool) for v in values[:64]):
+        return None
     arr = np.asarray(values)
+    if arr.ndim != 1 or arr.shape[0] != len(values):
+        return None
     if arr.dtype.kind in "iu":
         return (arr.astype(np.int64).view(np.uint64) ^ np.uint64(1 << 63)).reshape(-1, 1)
     if arr.dtype.kind == "U":

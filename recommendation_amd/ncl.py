@@ -36,12 +36,13 @@ _CONF_DEFAULTS = {"batch_size": ("batch.size", 2048), "emb_size": ("embedding.si
 
 class NCLModel:
     def __init__(self, conf, train_set, test_set, device=None, seed=0, kmeans_niter=FAISS_NITER, kmeans_seed=FAISS_SEED,
-                 fused_step=True, graph_capture=False):
+                 fused_step=True, graph_capture=False, reorder=None):
         """kmeans_niter / kmeans_seed: the two parameters of `faiss.Kmeans(d, k, gpu=False)` that ncl.py:352 leaves at
         faiss' defaults (ClusteringParameters: niter = 25, seed = 1234; see kmeans.py for provenance — faiss is absent,
         parity with it unpinned), explicit here.  fused_step: run the loop body as the hand-derived launch sequence of
         ncl_step.FusedNCLStep when the configuration allows it (same arithmetic as the autograd path);
-        graph_capture: replay that sequence from a hipGraph."""
+        graph_capture: replay that sequence from a hipGraph.  reorder="spectral": locality renumbering of users / items
+        (reorder.py; ids stay consistent everywhere because every id comes from `self.data`)."""
         self.config, self.seed = conf, seed
         self.kmeans_niter, self.kmeans_seed = int(kmeans_niter), int(kmeans_seed)
         self.fused_step, self.graph_capture = bool(fused_step), bool(graph_capture)
@@ -55,7 +56,8 @@ class NCLModel:
         self.max_N = max(self.topN)
         # `train_set` may be a prepared data object (user_num, item_num, norm_adj, device, ...) instead of the triple list:
         # NCLModel.from_graph builds one around a device-resident operator (graphs too large for Python id maps)
-        self.data = train_set if hasattr(train_set, "norm_adj") else Interaction(conf, train_set, test_set, device=device)
+        self.data = train_set if hasattr(train_set, "norm_adj") else Interaction(conf, train_set, test_set, device=device,
+                                                                                  reorder=reorder)
         self.model = LGCNEncoder(self.data, self.emb_size, self.n_layers)
         self.user_centroids = self.item_centroids = None
         self._user_2cluster = self._item_2cluster = self._e_inputs = None
@@ -72,13 +74,15 @@ class NCLModel:
         return cls(conf, data, None, device=norm_adj.device, **kw)
 
     # ncl.py:340-356
-    def e_step(self, user_emb=None, item_emb=None, assign_all=True):
+    def e_step(self, user_emb=None, item_emb=None, assign_all=True, join=True):
         """`user_emb` / `item_emb`: the encoder outputs when the caller has just computed them with the
         current parameters (the training step has: the reference runs the same forward a second time,
         ncl.py:341, with identical results).
         assign_all=False: train the centroids only; `user_2cluster` / `item_2cluster` — `kmeans.index.search(x, 1)` over
         ALL rows, of which ncl.py:371-372 reads the batch's 2 x B entries — are then computed when (and if) somebody
-        reads the attribute, from the same embeddings and centroids (the hand-derived step assigns just its batch rows)."""
+        reads the attribute, from the same embeddings and centroids (the hand-derived step assigns just its batch rows).
+        join=False (concurrent form only): the caller's stream does NOT wait for the two k-means streams; the caller
+        goes on issuing independent work and calls `e_step_join()` in front of the first use of the centroids."""
         with torch.no_grad():
             if user_emb is None or item_emb is None:
                 user_emb, item_emb, _ = self.model()
@@ -101,18 +105,26 @@ class NCLModel:
                     s.wait_stream(cur)
                     with torch.cuda.stream(s):
                         res.append(run_kmeans(x.contiguous(), k, **kw))
-                for s in self._e_streams:
-                    cur.wait_stream(s)
-                for c, a in res:
-                    c.record_stream(cur)
-                    if a is not None:
-                        a.record_stream(cur)
                 (self.user_centroids, self._user_2cluster), (self.item_centroids, self._item_2cluster) = res
+                self._e_unjoined = True
+                if join:
+                    self.e_step_join()
             else:
                 self.user_centroids, self._user_2cluster = run_kmeans(user_emb.contiguous(), k_users, **kw)
                 self.item_centroids, self._item_2cluster = run_kmeans(item_emb.contiguous(), k_items, **kw)
             self.k = int(self.item_centroids.shape[0])
             self._e_inputs = None if assign_all else (user_emb, item_emb)
+
+    def e_step_join(self):
+        """The caller's current stream waits for the e_step's two k-means streams (no-op when already joined)."""
+        if getattr(self, "_e_unjoined", False):
+            cur = torch.cuda.current_stream(self.user_centroids.device)
+            for s in self._e_streams:
+                cur.wait_stream(s)
+            for t in (self.user_centroids, self._user_2cluster, self.item_centroids, self._item_2cluster):
+                if t is not None:
+                    t.record_stream(cur)
+            self._e_unjoined = False
 
     @property
     def user_2cluster(self):

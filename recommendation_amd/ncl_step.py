@@ -47,6 +47,9 @@ class FusedNCLStep:
         # True: the table-side gradient branch of the backward runs on a side stream beside the SpMM recurrence
         self.overlap_backward = True
         self._side = None
+        # True: the e_step's streams are joined only in front of the prototype contrast (the structure contrast's forward
+        # is issued meanwhile)
+        self.early_e_step = True
 
     def _side_stream(self, dev):
         if self._side is None:
@@ -104,6 +107,11 @@ class FusedNCLStep:
         final = acc
         fu, fi = final[:n_u], final[n_u:]
 
+        # ---- e_step (ncl.py:324, every batch): k-means of the CURRENT encoder outputs, no host read-back.  Issued as soon
+        # as `final` exists, on its own two streams (NCLModel.e_step): it only has to be back for the prototype contrast ----
+        if self.e_step_every_batch:
+            o_.e_step(fu, fi, assign_all=False, join=not self.early_e_step)      # the full assignment vectors on demand
+
         # ---- BPR + the three squared norms of l2_reg_loss (ncl.py:314-317,116-123) ----
         dldx = torch.empty(max(bsz, 1), dtype=torch.float32, device=dev)
         sums = torch.zeros(5, dtype=torch.float32, device=dev)
@@ -137,9 +145,9 @@ class FusedNCLStep:
         w[bsz:].fill_(float(o_.ssl_reg * o_.alpha))
         ssl_loss = ((lse - pl) * w).sum()
 
-        # ---- e_step (ncl.py:324, every batch): k-means of the CURRENT encoder outputs, no host read-back ----
+        # ---- e_step joined here (issued right after the propagation, see above) ----
         if self.e_step_every_batch:
-            o_.e_step(fu, fi, assign_all=False)      # centroids now; the full assignment vectors on demand
+            o_.e_step_join()
 
         # ---- prototype contrast (ncl.py:369-375): InfoNCE(e0[idx], centroid of idx's cluster) * batch_size ----
         rows_0 = torch.empty(2 * bsz, d, dtype=torch.float32, device=dev)

@@ -136,3 +136,48 @@ def test_grouped_plan_covers_every_partition_once():
     Fn.spmm_into(plain, xin, y=a)
     Fn.spmm_into(grouped, xin, y=b)
     assert torch.equal(a, b)
+
+
+def test_renumbered_model_ranks_like_the_reference_numbering():
+    """End to end through the drop-in classes: an NCLModel built with reorder='spectral' whose embedding rows are the
+    permuted copy of a plain model's must produce the same propagated embeddings (per raw id), the same full-ranking
+    recommendation lists and the same metric report — the renumbering is invisible above `Interaction`."""
+    from recommendation_amd.ncl import NCLModel
+    rng = np.random.default_rng(0)
+    n_u, n_i = 400, 150
+    pairs = set()
+    while len(pairs) < 6000:
+        u = int(rng.integers(0, n_u))
+        i = int(rng.integers(0, n_i // 5)) * 5 + u % 5 if rng.random() < 0.85 else int(rng.integers(0, n_i))
+        pairs.add((u, i))
+    pairs = sorted(pairs)
+    rng.shuffle(pairs)
+    train = [[f"u{u}", f"i{i}", 1.0] for u, i in pairs[:5000]]
+    test = [[f"u{u}", f"i{i}", 1.0] for u, i in pairs[5000:]]
+    conf = {"model": {"name": "NCL", "type": "graph"}, "embedding.size": 64, "batch.size": 512, "learning.rate": 0.005,
+            "reg.lambda": 1e-4, "max.epoch": 1, "item.ranking.topN": [10, 20],
+            "NCL": {"n_layers": 2, "tau": 0.1, "ssl_reg": 1e-4, "proto_reg": 1e-4, "alpha": 1.0, "num_clusters": 8,
+                    "hyper_layers": 1}}
+    ref = NCLModel(conf, train, test, device="cuda", seed=1)
+    new = NCLModel(conf, train, test, device="cuda", seed=1, reorder="spectral")
+    assert new.data.perm_user is not None
+    pu = torch.from_numpy(new.data.perm_user).cuda()
+    pi = torch.from_numpy(new.data.perm_item).cuda()
+    with torch.no_grad():
+        new.model.embedding_dict["user_emb"][pu] = ref.model.embedding_dict["user_emb"] * 0.1
+        new.model.embedding_dict["item_emb"][pi] = ref.model.embedding_dict["item_emb"] * 0.1
+        ref.model.table.mul_(0.1)
+        for m in (ref, new):
+            m.model.eval()
+            m.user_emb, m.item_emb, _ = m.model()
+    torch.testing.assert_close(new.user_emb[pu], ref.user_emb, rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(new.item_emb[pi], ref.item_emb, rtol=1e-5, atol=1e-7)
+    rec_ref, rec_new = ref.test(), new.test()
+    assert rec_ref.keys() == rec_new.keys()
+    same = sum([i for i, _ in rec_ref[u]] == [i for i, _ in rec_new[u]] for u in rec_ref)
+    assert same >= 0.98 * len(rec_ref)                      # fp32 near-ties may swap neighbours in a list
+    from recommendation_amd.evaluate import ranking_evaluation
+    a, b = ranking_evaluation(ref.data.test_set, rec_ref, [10, 20]), ranking_evaluation(new.data.test_set, rec_new, [10, 20])
+    va = [float(x.split(":")[1]) for x in a if ":" in x]
+    vb = [float(x.split(":")[1]) for x in b if ":" in x]
+    np.testing.assert_allclose(va, vb, atol=2e-3)

@@ -39,8 +39,8 @@ def test_bpr_golden_value_and_grads(Fn, golden, variant, name):
     b, ut, it = _load(golden)
     sums = Fn.bpr_sums(ut, it, b["u_idx"], b["i_idx"], b["j_idx"], variant)
     loss = sums[0] / len(b["u_idx"])
-    assert float(loss) == pytest.approx(float(b[f"{name}_loss"]), rel=1e-5)
-    assert float(sums[4]) == 0.0
+    assert float(loss.detach()) == pytest.approx(float(b[f"{name}_loss"]), rel=1e-5)
+    assert float(sums[4].detach()) == 0.0
     loss.backward()
     _close(ut.grad, b[f"{name}_gu"])
     _close(it.grad, b[f"{name}_gi"])
@@ -52,7 +52,7 @@ def test_lightgcn_loss_block(Fn, golden, jkey, name):
     b, ut, it = _load(golden)
     sums = Fn.bpr_sums(ut, it, b["u_idx"], b["i_idx"], b[jkey], Fn.BPR_LOG_SIGMOID)
     loss = sums[0] / len(b["u_idx"]) + 1e-4 * (sums[1] + sums[2])
-    assert float(loss) == pytest.approx(float(b[f"{name}_loss"]), rel=1e-5)
+    assert float(loss.detach()) == pytest.approx(float(b[f"{name}_loss"]), rel=1e-5)
     loss.backward()
     _close(ut.grad, b[f"{name}_gu"])
     _close(it.grad, b[f"{name}_gi"])
@@ -182,7 +182,7 @@ def test_sorted_backward_matches_goldens(Fn, golden, monkeypatch, jkey, name, va
     b, ut, it = _load(golden)
     sums = Fn.bpr_sums(ut, it, b["u_idx"], b["i_idx"], b[jkey], variant)
     loss = sums[0] / len(b["u_idx"]) + (1e-4 * (sums[1] + sums[2]) if variant == 2 else 0.0)
-    assert float(loss) == pytest.approx(float(b[f"{name}_loss"]), rel=1e-5)
+    assert float(loss.detach()) == pytest.approx(float(b[f"{name}_loss"]), rel=1e-5)
     loss.backward()
     _close(ut.grad, b[f"{name}_gu"])
     _close(it.grad, b[f"{name}_gi"])

@@ -41,6 +41,14 @@ def test_cfg2_three_layer_propagation_matches_c_oracle(cfg2):
     got = final.cpu().numpy()
     scale = np.abs(ref).max()
     assert np.abs(got - ref).max() <= 1e-5 * scale
+    # 8192 sampled rows + the 64 longest (hub item) rows at PER-ROW tolerance: a small row cannot hide behind the global
+    # maximum.  Both sides sum a row's terms in fp32 in different orders (the C oracle front to back, the kernel in chunks of
+    # 512 non-zeros), so the bar is 1e-5 of the row's own largest element
+    deg = np.diff(g.rowptr_host)
+    rs = np.concatenate([np.random.default_rng(4).integers(0, g.n_rows, 8192), np.argsort(deg)[-64:]])
+    denom = np.abs(ref[rs]).max(1, keepdims=True) + 1e-30
+    worst = (np.abs(got[rs] - ref[rs]) / denom).max()
+    assert worst <= 1e-5, worst
     # row-sum identity on the last layer input: A 1 = rowsum(val)
     ones = Fn.spmm(g, torch.ones_like(x0))
     rowsum = torch.zeros(g.n_rows, device=x0.device, dtype=torch.float64).index_add_(0, rows, g.val.double())

@@ -168,8 +168,8 @@ def test_full_ncl_training_step_against_dense_cpu(golden):
     ref_total, ref_parts = step(uw, iw, dense_enc, dense, "cpu")
     ref_total.backward()
     for got, ref in zip(parts, ref_parts):
-        assert float(got) == pytest.approx(float(ref), rel=1e-5)
-    assert float(total) == pytest.approx(float(ref_total), rel=1e-5)
+        assert float(got.detach()) == pytest.approx(float(ref.detach()), rel=1e-5)
+    assert float(total.detach()) == pytest.approx(float(ref_total.detach()), rel=1e-5)
     for got, ref in ((enc.embedding_dict["user_emb"].grad, uw.grad), (enc.embedding_dict["item_emb"].grad, iw.grad)):
         ref = ref.numpy()
         np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-4, atol=2e-5 * np.abs(ref).max())

@@ -243,10 +243,13 @@ def _committed_pmc(key, digest, allow_stale=False):
     return ent
 
 
-def _event_ms(fn, reps):
+def _event_ms(fn, reps, warm=1):
     """Average device time of fn() in ms, HIP events on the stream the kernels are launched on (torch's
-    current stream is the one every gcr_* launch receives)."""
-    fn()
+    current stream is the one every gcr_* launch receives).  `warm` untimed calls first: a matrix-core kernel timed over a
+    few milliseconds right after a memory-bound phase (or idle) reads 10-15 % slow while the clock ramps
+    (scripts/exp/fwd_bimodal_probe.py: 0.93 -> 0.86 ms over four 2.5 ms windows after 0.5 s idle, 0.825 ms sustained)."""
+    for _ in range(max(1, warm)):
+        fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -385,7 +388,7 @@ def infonce_roofline(Fn, x0, n_u, dev):
     ef = Fn._resolve_engine(unit_rows=True)
     lse = Fn.infonce_lse_raw(anchors, sa, table, sb, inv_tau, engine_flag=ef)
     w = torch.ones(m, device=dev)
-    t_f = _event_ms(lambda: Fn.infonce_lse_raw(anchors, sa, table, sb, inv_tau, engine_flag=ef), 10)
+    t_f = _event_ms(lambda: Fn.infonce_lse_raw(anchors, sa, table, sb, inv_tau, engine_flag=ef), 50, warm=20)   # sustained rate
     flops = 2.0 * m * n_u * d
     from recommendation_amd import _lib
     engine = int(_lib.lib().gcr_infonce_engine(d))
@@ -403,10 +406,10 @@ def infonce_roofline(Fn, x0, n_u, dev):
 
     # training path of a row-softmax loss (ncl.py:358-367): flash-style forward (lse + weighted row sum, the
     # anchor-side gradient is a scale of it) and ONE backward launch for the table side
-    t_b = _event_ms(lambda: Fn._infonce_bwd_raw(table, sb, anchors, sa, inv_tau, None, None, lse, w, engine_flag=ef), 5)
+    t_b = _event_ms(lambda: Fn._infonce_bwd_raw(table, sb, anchors, sa, inv_tau, None, None, lse, w, engine_flag=ef), 20, warm=5)
     fwd_o = None
     if Fn.infonce_fwd_o_supported(d):
-        t_fo = _event_ms(lambda: Fn.infonce_fwd_o_raw(anchors, sa, table, sb, inv_tau, engine_flag=ef), 5)
+        t_fo = _event_ms(lambda: Fn.infonce_fwd_o_raw(anchors, sa, table, sb, inv_tau, engine_flag=ef), 20, warm=5)
         fwd_o = leg(f"infonce_pipe_kernel<{planes.split(':')[0]}, 64, MODE 1> (score + softmax-weighted row sum; {planes})",
                     t_fo, 2)
     out = {

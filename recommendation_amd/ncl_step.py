@@ -39,7 +39,7 @@ class FusedNCLStep:
         enc = owner.model
         self.enc, self.graph = enc, enc.norm_adj
         self.n_u, self.n_i = owner.data.user_num, owner.data.item_num
-        self._graph = None
+        self._cuda_graph = None
         self._static = None
         # False: leave the per-batch e_step (ncl.py:324) out and contrast against the centroids the owner already holds —
         # NOT the reference's loop body; bench.py uses it to report the e_step's share of the step
@@ -92,7 +92,7 @@ class FusedNCLStep:
         gat = torch.cat([user_idx, pos_idx + n_u])                                # rows of the stacked table
 
         # ---- forward: K-layer message pass, mean of the K + 1 layer outputs in the epilogue (ncl.py:415-422) ----
-        cur, acc, ctx_rows = x0, x0, None
+        cur, acc, ctx_layer = x0, x0, None
         for k in range(1, K + 1):
             last = k == K
             need_y = (not last) or ci == K
@@ -273,7 +273,7 @@ class FusedNCLStep:
             raise ValueError("capture() needs FusedAdam(capturable=True)")
         z = torch.zeros(int(batch_size), dtype=torch.int64, device=dev)
         self._static = [z.clone(), z.clone(), z.clone()]
-        self._graph, self._warm, self._warmup, self._out = None, 0, int(warmup), None
+        self._cuda_graph, self._warm, self._warmup, self._out = None, 0, int(warmup), None
         return self
 
     def capturable_for(self, batch_size):
@@ -287,7 +287,7 @@ class FusedNCLStep:
         dev = st[0].device
         for dst, src in zip(st, (user_idx, pos_idx, neg_idx)):
             dst.copy_(torch.as_tensor(src, device=dev), non_blocking=True)
-        if self._graph is None:
+        if self._cuda_graph is None:
             if self._warm < self._warmup:
                 s = torch.cuda.Stream(device=dev)
                 s.wait_stream(torch.cuda.current_stream(dev))
@@ -299,6 +299,6 @@ class FusedNCLStep:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._out = self(*st)
-            self._graph = g               # capturing does not execute: the replay below trains on this batch
-        self._graph.replay()
+            self._cuda_graph = g               # capturing does not execute: the replay below trains on this batch
+        self._cuda_graph.replay()
         return self._out

@@ -104,7 +104,7 @@ def test_graph_replay_equals_eager_sequence():
         lg = graphed.train_step(batch, og, check_negatives=False)
         le = eager.train_step(batch, oe, check_negatives=False, fused=True)
         assert float(lg[3].detach()) == pytest.approx(float(le[3].detach()), rel=1e-3)
-    assert graphed._fused._graph is not None                       # the graph path really ran
+    assert graphed._fused._cuda_graph is not None                       # the graph path really ran
     assert int(og.state[graphed.model.embedding_dict["user_emb"]]["step_dev"]) == 6
     diff = (graphed.model.table - eager.model.table).abs()
     # Adam's normalised update amplifies round-off on elements with tiny gradients: compare in units of lr

@@ -181,3 +181,30 @@ def test_renumbered_model_ranks_like_the_reference_numbering():
     va = [float(x.split(":")[1]) for x in a if ":" in x]
     vb = [float(x.split(":")[1]) for x in b if ":" in x]
     np.testing.assert_allclose(va, vb, atol=2e-3)
+
+
+def test_dense_ids_edge_cases():
+    """gcr_dense_ids_u64: a single record, all-equal keys, already-dense keys, and the empty input."""
+    from recommendation_amd import _lib
+    from recommendation_amd.encoders import dense_ids_device
+    for order in ("sorted", "first_seen"):
+        d, first = dense_ids_device(np.array([[7]], dtype=np.uint64), "cuda", order)
+        assert d.cpu().tolist() == [0] and first.tolist() == [0]
+        d, first = dense_ids_device(np.full((1000, 1), 42, dtype=np.uint64), "cuda", order)
+        assert int(d.abs().sum()) == 0 and first.tolist() == [0]
+        keys = np.arange(5000, dtype=np.uint64)[::-1].copy().reshape(-1, 1)
+        d, first = dense_ids_device(keys, "cuda", order)
+        want = (np.arange(5000)[::-1] if order == "sorted" else np.arange(5000))
+        assert np.array_equal(d.cpu().numpy(), want)
+    L = _lib.lib()
+    nu = torch.full((1,), -1, dtype=torch.int64, device="cuda")
+    _lib.check(L.gcr_dense_ids_u64(None, 0, 0, None, None, _lib.dptr(nu), None, _lib.cur_stream()), "empty")
+    assert int(nu) == 0
+    assert L.gcr_dense_ids_u64(None, 5, 0, None, None, _lib.dptr(nu), None, _lib.cur_stream()) != 0      # null buffers
+
+
+def test_bitmap_set_ignores_out_of_range_ids():
+    from recommendation_amd import functional as Fn
+    idx = torch.tensor([0, 31, 32, 95, 95, -1, 96, 10 ** 9], device="cuda")
+    bits = Fn.active_rows_bitmap(idx, 96).cpu().numpy().view(np.uint32)
+    assert bits.tolist() == [0x80000001, 0x00000001, 0x80000000]

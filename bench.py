@@ -772,6 +772,8 @@ def main_sharded(args, rank, world, dev, ra):
             "roofline": {"bound": "hbm", "kernel": "spmm_parts (per-layer wall time incl. collectives)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                          "frac": round(achieved / (HBM_PEAK_GBS * world), 4), "traffic": None,
+                         "frac_basis": "alg: the no-reuse byte model over the per-layer WALL time incl. collectives / (8 TB/s x N); "
+                                       "no PMC capture exists for N > 1 (the 1-GPU line carries the counter-based fraction)",
                          "frac_alg": round(achieved / (HBM_PEAK_GBS * world), 4),
                          "collective_bytes_per_rank_per_layer": 2 * items_padded * d * 4 * (world - 1) // world},
             "cpu_baseline": None, "dist_backend": dist.get_backend(), "dist_world": dist.get_world_size(),

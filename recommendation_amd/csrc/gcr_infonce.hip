@@ -413,8 +413,41 @@ __device__ __forceinline__ void score_tile_e(const unsigned char* __restrict__ t
 }
 
 
-template <class E, int D, bool COLSUM, bool EXD = false>
-__global__ __launch_bounds__(256, 2) void infonce_fwd_e_kernel(const float* __restrict__ a,
+// staging with a workgroup of THREADS lanes (the 512-thread form of infonce_fwd_e_kernel: one float4 per lane at d = 64)
+template <int D, int THREADS>
+__device__ __forceinline__ void stage_load_t(const float* __restrict__ b, const float* __restrict__ b_scale, int64_t n_rows,
+                                             int64_t j0, int tid, float4 (&regs)[(kTileJ * D / 4) / THREADS], float mult) {
+#pragma unroll
+  for (int u = 0; u < (kTileJ * D / 4) / THREADS; ++u) {
+    const int idx = tid + THREADS * u;
+    const int row = idx / (D / 4), c4 = idx % (D / 4);
+    const int64_t j = j0 + row;
+    const int64_t jj = j < n_rows ? j : n_rows - 1;
+    float4 v = *reinterpret_cast<const float4*>(b + jj * D + 4 * c4);
+    float s = b_scale != nullptr ? b_scale[jj] * mult : mult;
+    s = j < n_rows ? s : 0.f;
+    v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+    regs[u] = v;
+  }
+}
+
+template <class E, int D, int THREADS>
+__device__ __forceinline__ void stage_store_t_one(unsigned char* __restrict__ tile, int tid, const float4& v, int u) {
+  using S = ShapeB3<D>;
+  const int idx = tid + THREADS * u;
+  const int row = idx / (D / 4), c4 = idx % (D / 4);
+  unsigned qa[E::NPL], qb[E::NPL];
+  E::split(v.x, v.y, qa);
+  E::split(v.z, v.w, qb);
+  unsigned char* p = tile + row * S::ROWB + c4 * 8;
+#pragma unroll
+  for (int pl = 0; pl < E::NPL; ++pl) *reinterpret_cast<uint2*>(p + pl * S::PLANE) = make_uint2(qa[pl], qb[pl]);
+}
+
+// NW = 8: a 512-thread workgroup of 512 anchors shares each staged table tile — half the staging (operand split + LDS
+// stores) per MFMA of the 256-thread form; chosen for long splits at d = 64 (launch_fwd).
+template <class E, int D, bool COLSUM, bool EXD = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 2) void infonce_fwd_e_kernel(const float* __restrict__ a,
                                                                 const float* __restrict__ a_scale, int64_t m_rows,
                                                                 const float* __restrict__ b,
                                                                 const float* __restrict__ b_scale, int64_t n_rows,
@@ -423,12 +456,14 @@ __global__ __launch_bounds__(256, 2) void infonce_fwd_e_kernel(const float* __re
                                                                 float col_bound2) {
   using S = ShapeB3<D>;
   constexpr int NPL = E::NPL, NTERM = E::NTERM;
+  constexpr int THREADS = 64 * NW, NLD = (kTileJ * D / 4) / THREADS;
+  static_assert(NLD >= 1, "more lanes than float4s in a tile");
   __shared__ __align__(16) unsigned char lds[2][NPL * S::PLANE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i32 = lane & 31, h = lane >> 5;
   const int64_t mblk = blockIdx.x / nsplit;
   const int split = blockIdx.x % nsplit;
-  const int64_t i0 = (mblk * 4 + wave) * (32 * S::NT);
+  const int64_t i0 = (mblk * NW + wave) * (32 * S::NT);
 
   u32x4 bq[S::NT][NPL][S::KC];
 #pragma unroll
@@ -451,7 +486,7 @@ __global__ __launch_bounds__(256, 2) void infonce_fwd_e_kernel(const float* __re
   const int64_t total_tiles = (n_rows + kTileJ - 1) / kTileJ;
   const int64_t tile0 = (int64_t)split * tiles_per_split;
   const int64_t tile1 = min(total_tiles, tile0 + tiles_per_split);
-  float4 regs[S::NLD];
+  float4 regs[NLD];
   auto colsum = [&](const f32x16 (&acc)[S::NT], int64_t tt) {
     const int64_t j0 = tt * kTileJ;
 #pragma unroll
@@ -493,18 +528,22 @@ __global__ __launch_bounds__(256, 2) void infonce_fwd_e_kernel(const float* __re
     // under its own exp2 / max / add stream (two waves of a SIMD otherwise fall into lock-step and
     // serialise: measured 48 % MFMA utilisation before, scripts/perf_infonce_engine_ab.py).
     constexpr int NS = NTERM * S::KC * S::NT;                     // MFMA slots per step
-    constexpr int NU = 22 * S::NT + S::NLD + (COLSUM ? 16 : 0);   // VALU micro-units per step
+    constexpr int NU = 22 * S::NT + NLD + (COLSUM ? 16 : 0);      // VALU micro-units per step
     const int64_t last = tile1 - 1;
     f32x16 acc_a[S::NT], acc_b[S::NT];
-    stage_load<D>(b, b_scale, n_rows, tile0 * kTileJ, tid, regs, E::kSY);
-    stage_store_e<E, D>(lds[0], tid, regs);
-    stage_load<D>(b, b_scale, n_rows, min(tile0 + 1, last) * kTileJ, tid, regs, E::kSY);
+    auto store_all = [&](unsigned char* tile) {
+#pragma unroll
+      for (int u = 0; u < NLD; ++u) stage_store_t_one<E, D, THREADS>(tile, tid, regs[u], u);
+    };
+    stage_load_t<D, THREADS>(b, b_scale, n_rows, tile0 * kTileJ, tid, regs, E::kSY);
+    store_all(lds[0]);
+    stage_load_t<D, THREADS>(b, b_scale, n_rows, min(tile0 + 1, last) * kTileJ, tid, regs, E::kSY);
     __syncthreads();
     score_tile_e<E, D, S::NT>(lds[0], i32, h, bq, acc_a);
-    stage_store_e<E, D>(lds[1], tid, regs);
+    store_all(lds[1]);
     __syncthreads();
     auto step = [&](f32x16 (&cur)[S::NT], f32x16 (&nxt)[S::NT], int64_t tt, int nb) {
-      stage_load<D>(b, b_scale, n_rows, min(tt + 2, last) * kTileJ, tid, regs, E::kSY);
+      stage_load_t<D, THREADS>(b, b_scale, n_rows, min(tt + 2, last) * kTileJ, tid, regs, E::kSY);
       const unsigned char* base = lds[nb] + i32 * S::ROWB + h * (S::KH * 2);
       unsigned char* out = lds[nb ^ 1];
       float tmax[S::NT], m_new[S::NT], sum[S::NT];
@@ -518,9 +557,9 @@ __global__ __launch_bounds__(256, 2) void infonce_fwd_e_kernel(const float* __re
       // then the operand split + LDS store of one staged float4; then (COLSUM) one register's column sums
       auto micro = [&](int m) {
         const int u = m / S::NT, t = m % S::NT;
-        if (m >= 22 * S::NT + S::NLD) {
+        if (m >= 22 * S::NT + NLD) {
           if (COLSUM) {
-            const int r = m - 22 * S::NT - S::NLD;
+            const int r = m - 22 * S::NT - NLD;
             float e = 0.f;
 #pragma unroll
             for (int q = 0; q < S::NT; ++q) e += a_valid[q] * __builtin_amdgcn_exp2f(fmaf(cur[q][r], E::kSInv, -col_bound2));
@@ -529,7 +568,7 @@ __global__ __launch_bounds__(256, 2) void infonce_fwd_e_kernel(const float* __re
             if (i32 == 31 && j < n_rows) atomicAdd(col_sum + j, e);
           }
         } else if (m >= 22 * S::NT) {
-          stage_store_e_one<E, D>(out, tid, regs[m - 22 * S::NT], m - 22 * S::NT);
+          stage_store_t_one<E, D, THREADS>(out, tid, regs[m - 22 * S::NT], m - 22 * S::NT);
         } else if (u < 4) {
           if (EXD) {                                    // excluded diagonal pair: -inf before it is seen by max / exp2
 #pragma unroll
@@ -1831,7 +1870,21 @@ int32_t launch_fwd(const float* a, const float* a_scale, int64_t m, const float*
                        n, inv_tau * kLog2e, p.nsplit, p.tiles_per_split, part, col_sum, cb2)
       if constexpr (D <= 64) {
         if (use_h2(D, inv_tau, unit_rows, force_f32)) {
-          GCR_FWD_E(EngH2);
+          bool eight = false;
+          if constexpr (D == 64) {
+            // 512 anchors per workgroup, one workgroup per CU: each staged table tile feeds twice the MFMAs
+            const FwdPlan p8 = plan_fwd(m, n, 512, 256);
+            if (!exd && col_sum == nullptr && m >= 512 && p8.tiles_per_split >= 256) {
+              p = p8;
+              hipLaunchKernelGGL((infonce_fwd_e_kernel<EngH2, D, false, false, 8>), dim3((unsigned)(p.m_blocks * p.nsplit)),
+                                 dim3(512), 0, s, a, a_scale, m, b, b_scale, n, inv_tau * kLog2e, p.nsplit,
+                                 p.tiles_per_split, part, col_sum, cb2);
+              eight = true;
+            }
+          }
+          if (!eight) {
+            GCR_FWD_E(EngH2);
+          }
         } else {
           GCR_FWD_E(EngB3);
         }
@@ -2244,6 +2297,10 @@ extern "C" int64_t gcr_infonce_fwd_workspace_bytes(int64_t m, int64_t n, int32_t
   if (d <= 128) {
     const FwdPlan q = plan_fwd(m, n, d <= 64 ? 256 : 128, 512);
     if (q.nsplit > nsplit) nsplit = q.nsplit;
+    if (d == 64) {                                        // the 512-anchor form of the two-plane format
+      const FwdPlan q8 = plan_fwd(m, n, 512, 256);
+      if (q8.nsplit > nsplit) nsplit = q8.nsplit;
+    }
   }
   return nsplit * m * (int64_t)sizeof(float2);
 }

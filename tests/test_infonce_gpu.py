@@ -524,6 +524,15 @@ def test_eight_wave_form_of_the_loop_matches_three_plane_format(Fn, engine):
                     Fn._infonce_bwd_raw(a, sa, b, sb, inv_tau, lse, w, col, v, engine_flag=eng))
     for x, y in zip(res[h2], res[b3]):
         close(x, y)
+    # the lse-only forward takes its own 512-thread form (512 anchors per workgroup) from 2048 x 524K on: ragged last tile,
+    # anchors that do not fill the last workgroup
+    m2, n2 = 2048 + 300, 600_011
+    a2 = torch.randn(m2, d, device="cuda", generator=g)
+    b2 = torch.randn(n2, d, device="cuda", generator=g)
+    b2[77] = 2.0 * a2[2100]
+    sa2, sb2 = Fn.row_inv_norm(a2), Fn.row_inv_norm(b2)
+    close(Fn.infonce_lse_raw(a2, sa2, b2, sb2, inv_tau, engine_flag=h2), Fn.infonce_lse_raw(a2, sa2, b2, sb2, inv_tau, engine_flag=b3),
+          tol=2e-6)
     k = 50_000
     x = torch.randn(k, d, device="cuda", generator=g)
     sx = Fn.row_inv_norm(x)

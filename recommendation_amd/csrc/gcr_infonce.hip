@@ -664,6 +664,11 @@ bool use_h2(int d, float inv_tau, bool unit_rows, bool force_f32) {
   return use_b3(d, force_f32) && unit_rows && d <= 64 && inv_tau > 0.f && inv_tau <= kH2MaxInvTau;
 }
 constexpr int64_t kBwdHeader = 256;   // d <= 64: the backward's workspace starts with the two floats of h2_wscale_kernel
+// ... followed by the three per-row arrays of h2_fold_kernel (streamed rows: exponent offset, signed score scale, signed
+// staging scale), rounded to 256 B; the per-split partial gradients start behind them
+constexpr int64_t bwd_header_bytes(int64_t ny, int d) {
+  return d <= 64 ? kBwdHeader + ((3 * ny * (int64_t)sizeof(float) + 255) / 256) * 256 : 0;
+}
 
 // natural-log LSE of the scaled logits from the per-split (max2, sum2) partials
 __global__ void infonce_merge_kernel(const float2* __restrict__ part, int nsplit, int64_t m_rows,
@@ -1313,6 +1318,24 @@ __global__ __launch_bounds__(1024) void h2_wscale_kernel(const float* __restrict
   }
 }
 
+// Table-side backward with the statistics on the streamed rows only (SIDES = 2), two-f16-plane engine: the weight of
+// row j moves INTO the exponent and its sign into the staged row,
+//   P_ij y_j = w_j e^{s_ij - lse_j} y_j = 2^(c_j s'_ij + e_j) (sgn_j y_j),   s'_ij = x_i . (sgn_j y_j) the score the loop sees,
+//   e_j = log2(|w_j| hw[0]) - lse_j log2 e,   c_j = sgn_j kSInv,   ys_j = sgn_j y_scale_j kSY,
+// so that a probability costs one fma and one exp2 in the loop instead of fma, exp2 and a multiply (16 of ~175 vector
+// instructions per tile).  w_j = 0 gives e_j = -inf, i.e. P = 0, like the rows behind the end (filled in by the loop).
+__global__ __launch_bounds__(256) void h2_fold_kernel(const float* __restrict__ w_y, const float* __restrict__ lse_y,
+                                                      const float* __restrict__ y_scale, int64_t ny,
+                                                      const float* __restrict__ hw, float* __restrict__ fold) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= ny) return;
+  const float w = w_y[j] * hw[0];
+  const float sgn = w < 0.f ? -1.0f : 1.0f;
+  fold[j] = fmaf(-lse_y[j], kLog2e, __log2f(fabsf(w)));
+  fold[ny + j] = sgn * EngH2::kSInv;
+  fold[2 * ny + j] = sgn * EngH2::kSY * (y_scale != nullptr ? y_scale[j] : 1.0f);
+}
+
 // (LDS rows of 36 dwords: the 16 rows of every ds_read_b128 lane group start in 16 different bank quads, but rows q
 // and q + 2 of the four that one ds_read_b64_tr_b16 gathers share 8 banks — every transposing read takes two passes,
 // 22-28 % of the loop's LDS cycles are conflicts (SQ_LDS_BANK_CONFLICT).  Placing tile row 16kc + 8g + 4h + q in LDS row
@@ -1337,6 +1360,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
   constexpr int NLDW = (F4T + THREADS - 1) / THREADS;        // ... per thread
   constexpr int RING = NW == 8 ? 4 : 3;
   static_assert(NW == 4 || NW == 8, "four or eight waves");
+  // FOLD (h2_fold_kernel ran in front): lse_y = e, w_y = c, y_scale = ys — the weights live in the exponent
+  constexpr bool FOLD = MODE == 0 && SIDES == 2 && std::is_same<E, EngH2>::value;
   __shared__ __align__(16) unsigned char lds_rm[RING][RM];   // ring: tile t (B, transposed reads), t+1 (A), t+2 (staging)
   __shared__ __align__(16) float st_lse[RING][kTileJ];
   __shared__ __align__(16) float st_w[RING][kTileJ];
@@ -1381,7 +1406,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
         const int row = idx / (D / 4), c4 = idx % (D / 4);
         const int rr = min(row, rem - 1);
         float4 v = *reinterpret_cast<const float4*>(tb + rr * D + 4 * c4);
-        float sc = ts != nullptr ? ts[rr] * E::kSY : E::kSY;
+        float sc = FOLD ? ts[rr] : (ts != nullptr ? ts[rr] * E::kSY : E::kSY);
         sc = row < rem ? sc : 0.f;
         v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
         r[u] = v;
@@ -1389,8 +1414,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
       if (MODE == 0 && tid < kTileJ) {
         const int64_t j = j0 + tid;
         const bool on = j < ny && w_y != nullptr;
-        sw = on ? w_y[j] * w_mul : 0.f;
-        sl = on ? lse_y[j] * kLog2e : 1.0e30f;
+        if (FOLD) {
+          sw = on ? w_y[j] : E::kSInv;
+          sl = on ? lse_y[j] : -1.0e30f;
+        } else {
+          sw = on ? w_y[j] * w_mul : 0.f;
+          sl = on ? lse_y[j] * kLog2e : 1.0e30f;
+        }
       }
     };
     // one third of the staging of one float4: split (x, y), split (z, w), row-major plane stores
@@ -1427,7 +1457,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
     auto prepare = [&](f32x16& acc, int64_t t) {        // masks (ragged tile / excluded diagonal); MODE 1: reference point
       const int64_t j0 = t * kTileJ;
       const int lim = (int)min((int64_t)kTileJ, ny - j0);   // rows of this tile that exist (wave-uniform)
-      if (EXD || lim < kTileJ) {
+      // (FOLD: rows behind the end carry e = -1e30 and a zero staging scale: P = 0 whatever the score, and a score
+      // of -inf under a negative c would turn into +inf)
+      if (EXD || (lim < kTileJ && !FOLD)) {
         // a real (scalar) branch: if-converted, the 16 selects with their compares would run for every tile
         if (!EXD) asm volatile("" ::: "memory");
         const int xr = EXD ? diag_offset(row_i, j0, h) : -1;
@@ -1483,6 +1515,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
           }
           const float sc = acc[r];
           if (SIDES == 1) acc[r] = wl * __builtin_amdgcn_exp2f(fmaf(sc, E::kSInv, -lse2l));
+          else if (FOLD) acc[r] = __builtin_amdgcn_exp2f(fmaf(sc, wre, lre));
           else if (SIDES == 2) acc[r] = wre * __builtin_amdgcn_exp2f(fmaf(sc, E::kSInv, -lre));
           else acc[r] = wl * __builtin_amdgcn_exp2f(fmaf(sc, E::kSInv, -lse2l)) + wre * __builtin_amdgcn_exp2f(fmaf(sc, E::kSInv, -lre));
         }
@@ -1781,7 +1814,7 @@ int32_t launch_bwd(const float* x, const float* x_scale, int64_t mx, const float
       const FwdPlan p8 = plan_h2_rows8(mx, ny, D);
       const bool w8 = h2 && h2_eight_waves(D, p8);
       const FwdPlan p = w8 ? p8 : plan_bwd_rows(mx, ny, D, BwdB3<D>::ROWS_PER_BLOCK);
-      float* gpart = p.nsplit == 1 ? g : reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + (D <= 64 ? kBwdHeader : 0));
+      float* gpart = p.nsplit == 1 ? g : reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + bwd_header_bytes(ny, D));
       const dim3 grid((unsigned)(p.m_blocks * p.nsplit));
       const bool has_x = w_x != nullptr && lse_x != nullptr, has_y = w_y != nullptr && lse_y != nullptr;
       float* hw = reinterpret_cast<float*>(workspace);
@@ -1789,6 +1822,16 @@ int32_t launch_bwd(const float* x, const float* x_scale, int64_t mx, const float
         hipLaunchKernelGGL(h2_wscale_kernel, dim3(1), dim3(1024), 0, s, w_x, mx, w_y, ny, hw);
         int32_t st = GCR_LAUNCH_STATUS();
         if (st != GCR_OK) return st;
+        if (!exd && has_y && !has_x) {                     // SIDES = 2: weights into the exponent (h2_fold_kernel)
+          float* fold = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + kBwdHeader);
+          hipLaunchKernelGGL(h2_fold_kernel, dim3((unsigned)((ny + 255) / 256)), dim3(256), 0, s, w_y, lse_y, y_scale, ny,
+                             (const float*)hw, fold);
+          st = GCR_LAUNCH_STATUS();
+          if (st != GCR_OK) return st;
+          lse_y = fold;
+          w_y = fold + ny;
+          y_scale = fold + 2 * ny;
+        }
       }
 #define GCR_BWD3(EX, SD)                                                                                                \
   if constexpr (D <= 64) {                                                                                              \
@@ -1824,7 +1867,7 @@ int32_t launch_bwd(const float* x, const float* x_scale, int64_t mx, const float
     }
   }
   const FwdPlan p = plan_bwd<D>(mx, ny);
-  float* gpart = p.nsplit == 1 ? g : reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + (D <= 64 ? kBwdHeader : 0));
+  float* gpart = p.nsplit == 1 ? g : reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + bwd_header_bytes(ny, D));
   for (int pass = 0; pass < BwdShape<D>::PASSES; ++pass) {
     if (exd)
       hipLaunchKernelGGL((infonce_bwd_kernel<D, true>), dim3((unsigned)(p.m_blocks * p.nsplit)), dim3(256), 0, s, x,
@@ -2407,7 +2450,7 @@ extern "C" int64_t gcr_infonce_bwd_workspace_bytes(int64_t mx, int64_t ny, int32
       if (q8.nsplit > nsplit) nsplit = q8.nsplit;
     }
   }
-  return (nsplit > 1 ? nsplit * mx * d * (int64_t)sizeof(float) : 0) + (d <= 64 ? kBwdHeader : 0);
+  return (nsplit > 1 ? nsplit * mx * d * (int64_t)sizeof(float) : 0) + bwd_header_bytes(ny, d);
 }
 
 extern "C" int32_t gcr_infonce_bwd_ex_f32(const float* x, const float* x_scale, int64_t mx, const float* y,

@@ -408,6 +408,40 @@ def test_two_product_loop_random_shapes(Fn, engine):
         assert np.abs(ga - ref_ga).max() <= 2e-5 * max(np.abs(ref_ga).max(), 1e-6), tag
 
 
+@pytest.mark.parametrize("m,n,d", [(70, 500, 64), (2048, 3000, 64), (333, 1000, 32)])
+def test_table_side_backward_weights_in_the_exponent(Fn, engine, m, n, d):
+    """Statistics on the streamed rows only: the two-f16-plane loop carries each weight as 2^(log2|w| - lse log2 e) inside
+    the exponent and its sign in the staged row (h2_fold_kernel).  Weights of both signs, exact zeros, 25 orders of
+    magnitude and a ragged last tile against float64; the rows whose weight is zero must contribute exactly nothing."""
+    ef = Fn._resolve_engine(unit_rows=True)
+    rng = np.random.default_rng(m + n + d)
+    a = rng.standard_normal((m, d)).astype(np.float32)
+    b = rng.standard_normal((n, d)).astype(np.float32)
+    at, bt = _t(a), _t(b)
+    sa, sb = Fn.row_inv_norm(at), Fn.row_inv_norm(bt)
+    inv_tau = 10.0
+    lse = Fn.infonce_lse_raw(at, sa, bt, sb, inv_tau, engine_flag=ef)
+    w = (rng.standard_normal(m) * 10.0 ** rng.uniform(-20, 0, m)).astype(np.float32)
+    w[rng.random(m) < 0.2] = 0.0
+    w[0] = -3.0
+    an = a.astype(np.float64) / np.linalg.norm(a.astype(np.float64), axis=1, keepdims=True)
+    bn = b.astype(np.float64) / np.linalg.norm(b.astype(np.float64), axis=1, keepdims=True)
+    sm = np.exp(inv_tau * an @ bn.T - lse.cpu().numpy().astype(np.float64)[:, None])
+    gb = Fn._infonce_bwd_raw(bt, sb, at, sa, inv_tau, None, None, lse, _t(w), engine_flag=ef).cpu().numpy()
+    ref = inv_tau * (sm * w[:, None].astype(np.float64)).T @ an
+    assert np.isfinite(gb).all()
+    assert np.abs(gb - ref).max() <= 1e-5 * np.abs(ref).max()
+    # only the zero-weight anchors differ: same result with their rows replaced by garbage of unit norm
+    a2 = a.copy()
+    a2[w == 0] = rng.standard_normal((int((w == 0).sum()), d)).astype(np.float32)
+    a2t = _t(a2)
+    gb2 = Fn._infonce_bwd_raw(bt, sb, a2t, Fn.row_inv_norm(a2t), inv_tau, None, None, lse, _t(w), engine_flag=ef).cpu().numpy()
+    np.testing.assert_array_equal(gb, gb2)
+    # all weights zero: an exactly zero gradient (the scale pre-pass sees max |w| = 0)
+    gz = Fn._infonce_bwd_raw(bt, sb, at, sa, inv_tau, None, None, lse, _t(np.zeros(m, np.float32)), engine_flag=ef)
+    assert float(gz.abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("m,d", [(33, 64), (65, 64), (129, 64), (257, 64), (300, 32), (1000, 64)])
 def test_exclude_diagonal_backward_raw_multi_tile(Fn, engine, m, d):
     """gcr_infonce_bwd_ex_f32 with GCR_INFONCE_EXCLUDE_DIAGONAL on a self-similarity problem of 2..32 tiles (the pipelined

@@ -664,10 +664,11 @@ bool use_h2(int d, float inv_tau, bool unit_rows, bool force_f32) {
   return use_b3(d, force_f32) && unit_rows && d <= 64 && inv_tau > 0.f && inv_tau <= kH2MaxInvTau;
 }
 constexpr int64_t kBwdHeader = 256;   // d <= 64: the backward's workspace starts with the two floats of h2_wscale_kernel
-// ... followed by the three per-row arrays of h2_fold_kernel (streamed rows: exponent offset, signed score scale, signed
-// staging scale), rounded to 256 B; the per-split partial gradients start behind them
+// ... followed by h2_fold_kernel's image of the streamed rows (two per-row arrays and the scaled rows themselves, padded
+// to whole tiles), rounded to 256 B; the per-split partial gradients start behind them
+constexpr int64_t fold_rows(int64_t ny) { return (ny + kTileJ - 1) / kTileJ * kTileJ; }
 constexpr int64_t bwd_header_bytes(int64_t ny, int d) {
-  return d <= 64 ? kBwdHeader + ((3 * ny * (int64_t)sizeof(float) + 255) / 256) * 256 : 0;
+  return d <= 64 ? kBwdHeader + ((fold_rows(ny) * (2 + d) * (int64_t)sizeof(float) + 255) / 256) * 256 : 0;
 }
 
 // natural-log LSE of the scaled logits from the per-split (max2, sum2) partials
@@ -1319,21 +1320,39 @@ __global__ __launch_bounds__(1024) void h2_wscale_kernel(const float* __restrict
 }
 
 // Table-side backward with the statistics on the streamed rows only (SIDES = 2), two-f16-plane engine: the weight of
-// row j moves INTO the exponent and its sign into the staged row,
+// row j moves INTO the exponent and its sign into the row,
 //   P_ij y_j = w_j e^{s_ij - lse_j} y_j = 2^(c_j s'_ij + e_j) (sgn_j y_j),   s'_ij = x_i . (sgn_j y_j) the score the loop sees,
-//   e_j = log2(|w_j| hw[0]) - lse_j log2 e,   c_j = sgn_j kSInv,   ys_j = sgn_j y_scale_j kSY,
-// so that a probability costs one fma and one exp2 in the loop instead of fma, exp2 and a multiply (16 of ~175 vector
-// instructions per tile).  w_j = 0 gives e_j = -inf, i.e. P = 0, like the rows behind the end (filled in by the loop).
-__global__ __launch_bounds__(256) void h2_fold_kernel(const float* __restrict__ w_y, const float* __restrict__ lse_y,
-                                                      const float* __restrict__ y_scale, int64_t ny,
-                                                      const float* __restrict__ hw, float* __restrict__ fold) {
-  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (j >= ny) return;
-  const float w = w_y[j] * hw[0];
-  const float sgn = w < 0.f ? -1.0f : 1.0f;
-  fold[j] = fmaf(-lse_y[j], kLog2e, __log2f(fabsf(w)));
-  fold[ny + j] = sgn * EngH2::kSInv;
-  fold[2 * ny + j] = sgn * EngH2::kSY * (y_scale != nullptr ? y_scale[j] : 1.0f);
+//   e_j = log2(|w_j| hw[0]) - lse_j log2 e,   c_j = sgn_j kSInv,   yhat_j = sgn_j y_scale_j kSY y_j,
+// so that a probability costs one fma and one exp2 in the loop instead of fma, exp2 and a multiply, and the loop stages
+// the streamed tile from a scaled, zero-padded copy (the streamed side of this launch is the small one — the anchors of a
+// batch): no scale loads, no multiplies, no end-of-array clamps or selects per tile.  The loop's time is its count of vector
+// instructions.  w_j = 0 gives e_j = -inf, i.e. P = 0, like the padding rows (e = -1e30, zero row).
+// Layout of `fold`: e[rows], c[rows], yhat[rows][D], rows = fold_rows(ny).
+template <int D>
+__global__ __launch_bounds__(256) void h2_fold_kernel(const float* __restrict__ y, const float* __restrict__ y_scale,
+                                                      const float* __restrict__ w_y, const float* __restrict__ lse_y,
+                                                      int64_t ny, const float* __restrict__ hw, float* __restrict__ fold) {
+  const int64_t rows = fold_rows(ny);
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= rows * (D / 4)) return;
+  const int64_t j = k / (D / 4);
+  const int c4 = (int)(k % (D / 4));
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  float e = -1.0e30f, c = EngH2::kSInv;
+  if (j < ny) {
+    const float w = w_y[j] * hw[0];
+    const float sgn = w < 0.f ? -1.0f : 1.0f;
+    e = fmaf(-lse_y[j], kLog2e, __log2f(fabsf(w)));
+    c = sgn * EngH2::kSInv;
+    const float sc = sgn * EngH2::kSY * (y_scale != nullptr ? y_scale[j] : 1.0f);
+    v = *reinterpret_cast<const float4*>(y + j * D + 4 * c4);
+    v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+  }
+  *reinterpret_cast<float4*>(fold + 2 * rows + j * D + 4 * c4) = v;
+  if (c4 == 0) {
+    fold[j] = e;
+    fold[rows + j] = c;
+  }
 }
 
 // (LDS rows of 36 dwords: the 16 rows of every ds_read_b128 lane group start in 16 different bank quads, but rows q
@@ -1360,7 +1379,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
   constexpr int NLDW = (F4T + THREADS - 1) / THREADS;        // ... per thread
   constexpr int RING = NW == 8 ? 4 : 3;
   static_assert(NW == 4 || NW == 8, "four or eight waves");
-  // FOLD (h2_fold_kernel ran in front): lse_y = e, w_y = c, y_scale = ys — the weights live in the exponent
+  // FOLD (h2_fold_kernel ran in front): lse_y = e, w_y = c, y = the scaled rows, all padded to whole tiles
   constexpr bool FOLD = MODE == 0 && SIDES == 2 && std::is_same<E, EngH2>::value;
   __shared__ __align__(16) unsigned char lds_rm[RING][RM];   // ring: tile t (B, transposed reads), t+1 (A), t+2 (staging)
   __shared__ __align__(16) float st_lse[RING][kTileJ];
@@ -1400,13 +1419,23 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
       const int rem = (int)min((int64_t)kTileJ, ny - j0);
       const float* tb = y + j0 * D;
       const float* ts = y_scale != nullptr ? y_scale + j0 : nullptr;
+      if (FOLD) {                                            // scaled and padded already: uniform base + a constant offset per lane
+#pragma unroll
+        for (int u = 0; u < NLDW; ++u)
+          r[u] = *reinterpret_cast<const float4*>(tb + 4u * (unsigned)min(tid + THREADS * u, F4T - 1));
+        if (tid < kTileJ) {
+          sw = w_y[j0 + tid];
+          sl = lse_y[j0 + tid];
+        }
+        return;
+      }
 #pragma unroll
       for (int u = 0; u < NLDW; ++u) {
         const int idx = min(tid + THREADS * u, F4T - 1);     // (more threads than float4s: the surplus reloads the last one)
         const int row = idx / (D / 4), c4 = idx % (D / 4);
         const int rr = min(row, rem - 1);
         float4 v = *reinterpret_cast<const float4*>(tb + rr * D + 4 * c4);
-        float sc = FOLD ? ts[rr] : (ts != nullptr ? ts[rr] * E::kSY : E::kSY);
+        float sc = ts != nullptr ? ts[rr] * E::kSY : E::kSY;
         sc = row < rem ? sc : 0.f;
         v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
         r[u] = v;
@@ -1414,13 +1443,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
       if (MODE == 0 && tid < kTileJ) {
         const int64_t j = j0 + tid;
         const bool on = j < ny && w_y != nullptr;
-        if (FOLD) {
-          sw = on ? w_y[j] : E::kSInv;
-          sl = on ? lse_y[j] : -1.0e30f;
-        } else {
-          sw = on ? w_y[j] * w_mul : 0.f;
-          sl = on ? lse_y[j] * kLog2e : 1.0e30f;
-        }
+        sw = on ? w_y[j] * w_mul : 0.f;
+        sl = on ? lse_y[j] * kLog2e : 1.0e30f;
       }
     };
     // one third of the staging of one float4: split (x, y), split (z, w), row-major plane stores
@@ -1822,15 +1846,19 @@ int32_t launch_bwd(const float* x, const float* x_scale, int64_t mx, const float
         hipLaunchKernelGGL(h2_wscale_kernel, dim3(1), dim3(1024), 0, s, w_x, mx, w_y, ny, hw);
         int32_t st = GCR_LAUNCH_STATUS();
         if (st != GCR_OK) return st;
-        if (!exd && has_y && !has_x) {                     // SIDES = 2: weights into the exponent (h2_fold_kernel)
-          float* fold = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + kBwdHeader);
-          hipLaunchKernelGGL(h2_fold_kernel, dim3((unsigned)((ny + 255) / 256)), dim3(256), 0, s, w_y, lse_y, y_scale, ny,
-                             (const float*)hw, fold);
-          st = GCR_LAUNCH_STATUS();
-          if (st != GCR_OK) return st;
-          lse_y = fold;
-          w_y = fold + ny;
-          y_scale = fold + 2 * ny;
+        if constexpr (D <= 64) {
+          if (!exd && has_y && !has_x) {                   // SIDES = 2: weights into the exponent (h2_fold_kernel)
+            float* fold = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + kBwdHeader);
+            const int64_t rows = fold_rows(ny);
+            hipLaunchKernelGGL(h2_fold_kernel<D>, dim3((unsigned)((rows * (D / 4) + 255) / 256)), dim3(256), 0, s, y, y_scale,
+                               w_y, lse_y, ny, (const float*)hw, fold);
+            st = GCR_LAUNCH_STATUS();
+            if (st != GCR_OK) return st;
+            lse_y = fold;
+            w_y = fold + rows;
+            y = fold + 2 * rows;
+            y_scale = nullptr;
+          }
         }
       }
 #define GCR_BWD3(EX, SD)                                                                                                \

@@ -282,13 +282,17 @@ constexpr float kDefer = 8.0f;
 //          the reference) go sub-normal, which v_cvt_pk_f16_f32 produces and v_mfma_f32_32x32x16_f16 honours
 //          (scripts/exp/f16_denorm_probe.hip, run on the box): their absolute error stays <= 2^-25 of the scaled unit.
 // ------------------------------------------------------------------------------------------
-// operand-split form of EngH2 inside the two-product loop (EngH2::split): measured on one box at 2048 x 1M x 64 —
-//   MODE 1 (flash forward)        form 0: 1.81 ms   form 1: 1.70   form 2: same as form 1 within noise (1.55-1.59 both)
-//   MODE 0 (table-side backward)  form 0: 1.78 ms   form 1: 1.88   form 2: 1.90
-// fewer vector instructions do NOT make the backward loop faster (the mixed-precision forms are opaque asm statements to
-// the scheduler, and the loop is bound by waits, not by its instruction count: DESIGN 4.2b); each mode keeps its best.
+// operand-split form of EngH2 inside the two-product loop (EngH2::split): 0 = convert, two f16 -> f32 converts, two
+// subtracts, convert (six instructions per pair); 1 = the residual out of one v_fma_mix_f32 per value (four); 2 = the lo
+// plane straight out of v_fma_mixlo_f16 / v_fma_mixhi_f16 (three).  Measured on one box at 2048 x 1M x 64:
+//   MODE 1 (flash forward)        form 0: 1.81 ms   form 1: 1.70   form 2: same as form 1 within noise
+//   MODE 0 (table-side backward)  round 2 (175 vector instructions per tile): form 0: 1.78 ms, 1: 1.88, 2: 1.90;
+//                                 round 3 (110 per tile after the fold pre-pass): form 0: 1.39 ms, 1: 1.32, 2: 1.33
+//                                 (100K x 100K, 8 waves: 7.00 / 6.49 / 6.53; d = 32: 0.814 / 0.773 / 0.787)
+// Form 2 never beats form 1 although it is one instruction shorter per pair: the f16-destination mixed forms issue at
+// about twice the cost of a plain vector instruction.
 template <int MODE>
-constexpr int kSplitForm = MODE == 1 ? 1 : 0;
+constexpr int kSplitForm = 1;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 struct EngB3 {

@@ -1323,39 +1323,51 @@ __global__ __launch_bounds__(1024) void h2_wscale_kernel(const float* __restrict
   }
 }
 
-// Table-side backward with the statistics on the streamed rows only (SIDES = 2), two-f16-plane engine: the weight of
-// row j moves INTO the exponent and its sign into the row,
-//   P_ij y_j = w_j e^{s_ij - lse_j} y_j = 2^(c_j s'_ij + e_j) (sgn_j y_j),   s'_ij = x_i . (sgn_j y_j) the score the loop sees,
-//   e_j = log2(|w_j| hw[0]) - lse_j log2 e,   c_j = sgn_j kSInv,   yhat_j = sgn_j y_scale_j kSY y_j,
-// so that a probability costs one fma and one exp2 in the loop instead of fma, exp2 and a multiply, and the loop stages
-// the streamed tile from a scaled, zero-padded copy (the streamed side of this launch is the small one — the anchors of a
-// batch): no scale loads, no multiplies, no end-of-array clamps or selects per tile.  The loop's time is its count of vector
-// instructions.  w_j = 0 gives e_j = -inf, i.e. P = 0, like the padding rows (e = -1e30, zero row).
-// Layout of `fold`: e[rows], c[rows], yhat[rows][D], rows = fold_rows(ny).
-template <int D>
-__global__ __launch_bounds__(256) void h2_fold_kernel(const float* __restrict__ y, const float* __restrict__ y_scale,
-                                                      const float* __restrict__ w_y, const float* __restrict__ lse_y,
-                                                      int64_t ny, const float* __restrict__ hw, float* __restrict__ fold) {
+// Pre-pass of the two-f16-plane backward loop (MODE 0): a scaled, zero-padded image of the STREAMED rows and of their
+// statistics, so that the loop stages a tile with two plain loads per lane — no scale loads, multiplies, end-of-array
+// clamps or selects per tile.  The loop's time is its count of vector instructions, and the streamed side of
+// a backward launch is read once per row block: mx / 128 times.
+//   FOLDW = false:  l_j = lse_j log2 e,  w'_j = w_j hw[0],  yhat_j = y_scale_j kSY y_j   (padding: 1e30, 0, zero row)
+//   FOLDW = true (statistics on the streamed rows only, SIDES = 2): the weight of row j moves INTO the exponent and its
+//   sign into the row,
+//     P_ij y_j = w_j e^{s_ij - lse_j} y_j = 2^(c_j s'_ij + e_j) (sgn_j y_j),   s'_ij = x_i . (sgn_j y_j) the score the loop sees,
+//     e_j = log2(|w_j| hw[0]) - lse_j log2 e,   c_j = sgn_j kSInv,   yhat_j = sgn_j y_scale_j kSY y_j,
+//   so that a probability costs one fma and one exp2 in the loop instead of fma, exp2 and a multiply.  w_j = 0 gives
+//   e_j = -inf, i.e. P = 0, like the padding rows (e = -1e30, zero row).
+// Layout of `img`: l or e [rows], w' or c [rows], yhat[rows][D], rows = fold_rows(ny).
+template <int D, bool FOLDW>
+__global__ __launch_bounds__(256) void h2_prestage_kernel(const float* __restrict__ y, const float* __restrict__ y_scale,
+                                                          const float* __restrict__ w_y, const float* __restrict__ lse_y,
+                                                          int64_t ny, const float* __restrict__ hw, float* __restrict__ img,
+                                                          bool write_stats) {
   const int64_t rows = fold_rows(ny);
   const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (k >= rows * (D / 4)) return;
   const int64_t j = k / (D / 4);
   const int c4 = (int)(k % (D / 4));
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  float e = -1.0e30f, c = EngH2::kSInv;
+  float s0 = FOLDW ? -1.0e30f : 1.0e30f, s1 = FOLDW ? EngH2::kSInv : 0.f;
   if (j < ny) {
-    const float w = w_y[j] * hw[0];
-    const float sgn = w < 0.f ? -1.0f : 1.0f;
-    e = fmaf(-lse_y[j], kLog2e, __log2f(fabsf(w)));
-    c = sgn * EngH2::kSInv;
+    float sgn = 1.0f;
+    if (w_y != nullptr) {
+      const float w = w_y[j] * hw[0];
+      if (FOLDW) {
+        sgn = w < 0.f ? -1.0f : 1.0f;
+        s0 = fmaf(-lse_y[j], kLog2e, __log2f(fabsf(w)));
+        s1 = sgn * EngH2::kSInv;
+      } else {
+        s0 = lse_y[j] * kLog2e;
+        s1 = w;
+      }
+    }
     const float sc = sgn * EngH2::kSY * (y_scale != nullptr ? y_scale[j] : 1.0f);
     v = *reinterpret_cast<const float4*>(y + j * D + 4 * c4);
     v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
   }
-  *reinterpret_cast<float4*>(fold + 2 * rows + j * D + 4 * c4) = v;
-  if (c4 == 0) {
-    fold[j] = e;
-    fold[rows + j] = c;
+  *reinterpret_cast<float4*>(img + 2 * rows + j * D + 4 * c4) = v;
+  if (c4 == 0 && write_stats) {                            // (w_y == nullptr: every row like the padding)
+    img[j] = s0;
+    img[rows + j] = s1;
   }
 }
 
@@ -1383,8 +1395,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
   constexpr int NLDW = (F4T + THREADS - 1) / THREADS;        // ... per thread
   constexpr int RING = NW == 8 ? 4 : 3;
   static_assert(NW == 4 || NW == 8, "four or eight waves");
-  // FOLD (h2_fold_kernel ran in front): lse_y = e, w_y = c, y = the scaled rows, all padded to whole tiles
-  constexpr bool FOLD = MODE == 0 && SIDES == 2 && std::is_same<E, EngH2>::value;
+  // PRE (h2_prestage_kernel ran in front): y = the scaled rows, lse_y / w_y = the streamed rows' statistics in the loop's
+  // units, all padded to whole tiles; FOLD: the statistics are (e, c), the weights live in the exponent
+  constexpr bool PRE = MODE == 0 && std::is_same<E, EngH2>::value;
+  constexpr bool FOLD = PRE && SIDES == 2;
   __shared__ __align__(16) unsigned char lds_rm[RING][RM];   // ring: tile t (B, transposed reads), t+1 (A), t+2 (staging)
   __shared__ __align__(16) float st_lse[RING][kTileJ];
   __shared__ __align__(16) float st_w[RING][kTileJ];
@@ -1394,13 +1408,20 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
   const int split = blockIdx.x % nsplit;
   const int64_t row_i = (mblk * NW + wave) * 32 + i32;
 
-  u32x4 bq[1][NPL][S::KC];
-  load_stationary_e<E, D>(x, x_scale, mx, row_i, h, scale2 * E::kSX, bq[0]);
   // MODE 0 on EngH2: weights pre-scaled into f16 range (h2_wscale_kernel); hw == nullptr otherwise
   const float w_mul = hw != nullptr ? hw[0] : 1.0f;
   const bool on_x = MODE == 0 && row_i < mx && w_x != nullptr;
   const float wl = on_x ? w_x[row_i] * w_mul : 0.f;
   const float lse2l = on_x ? lse_x[row_i] * kLog2e : 1.0e30f;
+  // FOLDX (statistics on the stationary rows only): the same move as FOLD inside the kernel — |w_i| into the exponent,
+  // sgn w_i into the stationary operand (the scores flip with it, hence c_x) and back out of the gradient row at the end:
+  //   P_ij = w_i e^{s_ij - lse_i} = sgn_i 2^(c_x s'_ij + e_x)
+  constexpr bool FOLDX = MODE == 0 && SIDES == 1;
+  const float sgn_x = FOLDX && wl < 0.f ? -1.0f : 1.0f;
+  const float c_x = sgn_x * E::kSInv;
+  const float e_x = on_x ? fmaf(-lse_x[row_i], kLog2e, __log2f(fabsf(wl))) : -1.0e30f;
+  u32x4 bq[1][NPL][S::KC];
+  load_stationary_e<E, D>(x, x_scale, mx, row_i, h, scale2 * E::kSX * sgn_x, bq[0]);
   float m_run = kNegBig, l_run = 0.f;                   // MODE 1
   f32x16 gacc[B::CT];
 #pragma unroll
@@ -1423,11 +1444,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
       const int rem = (int)min((int64_t)kTileJ, ny - j0);
       const float* tb = y + j0 * D;
       const float* ts = y_scale != nullptr ? y_scale + j0 : nullptr;
-      if (FOLD) {                                            // scaled and padded already: uniform base + a constant offset per lane
+      if (PRE) {                                             // scaled and padded already: uniform base + a constant offset per lane
 #pragma unroll
         for (int u = 0; u < NLDW; ++u)
           r[u] = *reinterpret_cast<const float4*>(tb + 4u * (unsigned)min(tid + THREADS * u, F4T - 1));
-        if (tid < kTileJ) {
+        if (SIDES != 1 && tid < kTileJ) {
           sw = w_y[j0 + tid];
           sl = lse_y[j0 + tid];
         }
@@ -1485,9 +1506,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
     auto prepare = [&](f32x16& acc, int64_t t) {        // masks (ragged tile / excluded diagonal); MODE 1: reference point
       const int64_t j0 = t * kTileJ;
       const int lim = (int)min((int64_t)kTileJ, ny - j0);   // rows of this tile that exist (wave-uniform)
-      // (FOLD: rows behind the end carry e = -1e30 and a zero staging scale: P = 0 whatever the score, and a score
-      // of -inf under a negative c would turn into +inf)
-      if (EXD || (lim < kTileJ && !FOLD)) {
+      // (MODE 0 never needs the end-of-array mask: rows behind the end are staged as zero rows — a finite P times zero —
+      // and carry w' = 0 or e = -1e30; under FOLD / FOLDX a score of -inf would turn into +inf when c is negative)
+      if (EXD || (lim < kTileJ && MODE == 1)) {
         // a real (scalar) branch: if-converted, the 16 selects with their compares would run for every tile
         if (!EXD) asm volatile("" ::: "memory");
         const int xr = EXD ? diag_offset(row_i, j0, h) : -1;
@@ -1542,7 +1563,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
             wre = e == 0 ? w4.x : (e == 1 ? w4.y : (e == 2 ? w4.z : w4.w));
           }
           const float sc = acc[r];
-          if (SIDES == 1) acc[r] = wl * __builtin_amdgcn_exp2f(fmaf(sc, E::kSInv, -lse2l));
+          if (SIDES == 1) acc[r] = __builtin_amdgcn_exp2f(fmaf(sc, c_x, e_x));
           else if (FOLD) acc[r] = __builtin_amdgcn_exp2f(fmaf(sc, wre, lre));
           else if (SIDES == 2) acc[r] = wre * __builtin_amdgcn_exp2f(fmaf(sc, E::kSInv, -lre));
           else acc[r] = wl * __builtin_amdgcn_exp2f(fmaf(sc, E::kSInv, -lse2l)) + wre * __builtin_amdgcn_exp2f(fmaf(sc, E::kSInv, -lre));
@@ -1712,7 +1733,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
     if (h == 0 && row_i < mx)
       part[(int64_t)split * mx + row_i] = make_float2(m_run, (l_run + l_o) * __builtin_amdgcn_exp2f(-E::kPExp));
   }
-  const float o_mul = out_scale * (hw != nullptr ? hw[1] : 1.0f);
+  const float o_mul = out_scale * (hw != nullptr ? hw[1] : 1.0f) * sgn_x;
   if (row_i < mx) {
 #pragma unroll
     for (int c = 0; c < B::CT; ++c)
@@ -1850,19 +1871,26 @@ int32_t launch_bwd(const float* x, const float* x_scale, int64_t mx, const float
         hipLaunchKernelGGL(h2_wscale_kernel, dim3(1), dim3(1024), 0, s, w_x, mx, w_y, ny, hw);
         int32_t st = GCR_LAUNCH_STATUS();
         if (st != GCR_OK) return st;
-        if constexpr (D <= 64) {
-          if (!exd && has_y && !has_x) {                   // SIDES = 2: weights into the exponent (h2_fold_kernel)
-            float* fold = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + kBwdHeader);
-            const int64_t rows = fold_rows(ny);
-            hipLaunchKernelGGL(h2_fold_kernel<D>, dim3((unsigned)((rows * (D / 4) + 255) / 256)), dim3(256), 0, s, y, y_scale,
-                               w_y, lse_y, ny, (const float*)hw, fold);
-            st = GCR_LAUNCH_STATUS();
-            if (st != GCR_OK) return st;
-            lse_y = fold;
-            w_y = fold + rows;
-            y = fold + 2 * rows;
-            y_scale = nullptr;
+        if constexpr (D <= 64) {                           // the loop's image of the streamed side (h2_prestage_kernel)
+          float* img = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + kBwdHeader);
+          const int64_t rows = fold_rows(ny);
+          const dim3 pg((unsigned)((rows * (D / 4) + 255) / 256));
+          const bool foldw = !exd && has_y && !has_x;      // SIDES = 2: weights into the exponent
+          const bool stats = exd || has_y || !has_x;       // SIDES != 1: the loop reads the streamed rows' statistics
+          if (foldw)
+            hipLaunchKernelGGL((h2_prestage_kernel<D, true>), pg, dim3(256), 0, s, y, y_scale, w_y, lse_y, ny, (const float*)hw,
+                               img, true);
+          else
+            hipLaunchKernelGGL((h2_prestage_kernel<D, false>), pg, dim3(256), 0, s, y, y_scale, has_y ? w_y : nullptr, lse_y, ny,
+                               (const float*)hw, img, stats);
+          st = GCR_LAUNCH_STATUS();
+          if (st != GCR_OK) return st;
+          if (stats) {
+            lse_y = img;
+            w_y = img + rows;
           }
+          y = img + 2 * rows;
+          y_scale = nullptr;
         }
       }
 #define GCR_BWD3(EX, SD)                                                                                                \

@@ -38,5 +38,13 @@ for (m, n, d) in shapes:
     t_o = ms(lambda: Fn.infonce_fwd_o_raw(a, sa, b, sb, 10.0, engine_flag=ef))
     t_b = ms(lambda: Fn._infonce_bwd_raw(b, sb, a, sa, 10.0, None, None, lse, w, engine_flag=ef))
     fl = 2.0 * m * n * d / 1e9
+    if "--sides" in sys.argv and m == n:       # the other statistics layouts of the backward loop (symmetric / self-similarity)
+        col = Fn.infonce_lse_raw(b, sb, a, sa, 10.0)
+        wn = torch.ones(n, device="cuda")
+        t0 = ms(lambda: Fn._infonce_bwd_raw(a, sa, b, sb, 10.0, lse, w, col, wn, engine_flag=ef))
+        t1 = ms(lambda: Fn._infonce_bwd_raw(a, sa, b, sb, 10.0, lse, w, None, None, engine_flag=ef))
+        tx = ms(lambda: Fn._infonce_bwd_raw(a, sa, a, sa, 10.0, lse, w, lse, w, exclude_diagonal=True, engine_flag=ef))
+        print(f"M={m} N={n} d={d}: bwd both sides {t0:.3f} ms  stationary side only {t1:.3f} ms  "
+              f"self-similarity, excluded diagonal {tx:.3f} ms", flush=True)
     print(f"M={m} N={n} d={d}: fwd {t_f:.3f} ms ({fl / t_f:.0f} TF)  fwd_o {t_o:.3f} ms ({2 * fl / t_o:.0f} TF)  "
           f"bwd(table) {t_b:.3f} ms ({2 * fl / t_b:.0f} TF)", flush=True)

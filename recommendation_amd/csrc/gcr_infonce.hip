@@ -1834,11 +1834,11 @@ FwdPlan plan_bwd(int64_t mx, int64_t ny) {
   return plan_bwd_rows(mx, ny, D, BwdShape<D>::ROWS_PER_BLOCK);
 }
 
-// The two-f16-plane launches of d = 64 with long tile loops run as 512-thread workgroups of 256 stationary rows, one per
-// CU (infonce_pipe_kernel, NW = 8): measured against the 256-thread form on one box — flash forward 2048 x 1M 1.73 ->
-// 1.60 ms, 100K x 100K 7.93 -> 7.73 ms, backward 100K x 100K 9.20 -> 8.94 ms; but the backward of 2048 x 1M (3906 row
-// blocks of only 64 tiles) 1.78 -> 1.85 ms, and d = 32 (nothing to share: 256 lanes already stage a whole tile) 4-14 %
-// slower.  Hence: d = 64 and at least 256 tiles per split.
+// The two-f16-plane flash forward of d = 64 with long tile loops runs as 512-thread workgroups of 256 stationary rows,
+// one per CU (infonce_pipe_kernel, NW = 8): measured against the 256-thread form on one box — 2048 x 1M 1.73 -> 1.60 ms,
+// 100K x 100K 7.93 -> 7.73 ms; d = 32 (nothing to share: 256 lanes already stage a whole tile) 4-14 % slower.  Hence:
+// d = 64 and at least 256 tiles per split.  (The backward used it too in round 2 — 100K x 100K 9.20 -> 8.94 ms — until
+// its staging moved into a pre-pass: launch_bwd.)
 FwdPlan plan_h2_rows8(int64_t mx, int64_t ny, int d) { return plan_bwd_rows(mx, ny, d, 256, 256); }
 bool h2_eight_waves(int d, const FwdPlan& p8) { return d == 64 && p8.tiles_per_split >= 256; }
 
@@ -1860,9 +1860,10 @@ int32_t launch_bwd(const float* x, const float* x_scale, int64_t mx, const float
       // d <= 64: the cross-tile pipelined loop (infonce_pipe_b3_kernel); d = 128: single-buffered (one tile with its
       // transposed copy is 54 KB of LDS)
       const bool h2 = use_h2(D, inv_tau, unit_rows, force_f32);
-      const FwdPlan p8 = plan_h2_rows8(mx, ny, D);
-      const bool w8 = h2 && h2_eight_waves(D, p8);
-      const FwdPlan p = w8 ? p8 : plan_bwd_rows(mx, ny, D, BwdB3<D>::ROWS_PER_BLOCK);
+      // (always the 256-thread form: the 512-thread form of the flash forward halves the STAGING work per MFMA, and the
+      // backward stages from the pre-scaled image — two loads and two splits per lane.  At 100K x 100K the 512-thread
+      // backward, 3-7 % ahead in round 2, is now behind: both sides 8.25 vs 7.44 ms, excluded diagonal 8.93 vs 8.45)
+      const FwdPlan p = plan_bwd_rows(mx, ny, D, BwdB3<D>::ROWS_PER_BLOCK);
       float* gpart = p.nsplit == 1 ? g : reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + bwd_header_bytes(ny, D));
       const dim3 grid((unsigned)(p.m_blocks * p.nsplit));
       const bool has_x = w_x != nullptr && lse_x != nullptr, has_y = w_y != nullptr && lse_y != nullptr;
@@ -1895,12 +1896,7 @@ int32_t launch_bwd(const float* x, const float* x_scale, int64_t mx, const float
       }
 #define GCR_BWD3(EX, SD)                                                                                                \
   if constexpr (D <= 64) {                                                                                              \
-    if (h2 && w8) {                                                                                                     \
-      if constexpr (D == 64)                                                                                            \
-        hipLaunchKernelGGL((infonce_pipe_kernel<EngH2, D, 0, EX, SD, 8>), grid, dim3(512), 0, s, x, x_scale, mx, y,     \
-                           y_scale, ny, inv_tau * kLog2e, inv_tau, lse_x, w_x, lse_y, w_y, p.nsplit, p.tiles_per_split, \
-                           gpart, (float2*)nullptr, (const float*)hw);                                                  \
-    } else if (h2)                                                                                                      \
+    if (h2)                                                                                                             \
       hipLaunchKernelGGL((infonce_pipe_kernel<EngH2, D, 0, EX, SD>), grid, dim3(256), 0, s, x, x_scale, mx, y, y_scale, \
                          ny, inv_tau * kLog2e, inv_tau, lse_x, w_x, lse_y, w_y, p.nsplit, p.tiles_per_split, gpart,     \
                          (float2*)nullptr, (const float*)hw);                                                           \
@@ -2505,10 +2501,6 @@ extern "C" int64_t gcr_infonce_bwd_workspace_bytes(int64_t mx, int64_t ny, int32
   if (d <= 128) {   // either engine (chosen per call)
     const FwdPlan q = plan_bwd_rows(mx, ny, d, 128);
     if (q.nsplit > nsplit) nsplit = q.nsplit;
-    if (d <= 64) {
-      const FwdPlan q8 = plan_h2_rows8(mx, ny, d);
-      if (q8.nsplit > nsplit) nsplit = q8.nsplit;
-    }
   }
   return (nsplit > 1 ? nsplit * mx * d * (int64_t)sizeof(float) : 0) + bwd_header_bytes(ny, d);
 }

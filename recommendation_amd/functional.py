@@ -513,11 +513,14 @@ def _pad_dim(x):
     raise ValueError("embedding dim must be <= 256")
 
 
-def row_inv_norm(x, eps=1e-12):
+def row_inv_norm(x, eps=1e-12, out=None):
     """1 / max(||x_r||, eps) per row — F.normalize's denominator (ncl.py:127, gcl.py:29-30)."""
     _lib.require_cuda(x)
     x = x.contiguous()
-    out = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    elif out.shape != (x.shape[0],) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != x.device:
+        raise ValueError("row_inv_norm: out must be a contiguous float32 [rows] tensor on x's device")
     _lib.check(_lib.lib().gcr_row_inv_norm_f32(_lib.dptr(x), x.shape[0], x.shape[1], float(eps), _lib.dptr(out),
                                                _lib.cur_stream(x.device)), "gcr_row_inv_norm_f32")
     return out

@@ -74,7 +74,7 @@ class NCLModel:
         return cls(conf, data, None, device=norm_adj.device, **kw)
 
     # ncl.py:340-356
-    def e_step(self, user_emb=None, item_emb=None, assign_all=True, join=True):
+    def e_step(self, user_emb=None, item_emb=None, assign_all=True, join=True, after=None):
         """`user_emb` / `item_emb`: the encoder outputs when the caller has just computed them with the
         current parameters (the training step has: the reference runs the same forward a second time,
         ncl.py:341, with identical results).
@@ -82,7 +82,10 @@ class NCLModel:
         ALL rows, of which ncl.py:371-372 reads the batch's 2 x B entries — are then computed when (and if) somebody
         reads the attribute, from the same embeddings and centroids (the hand-derived step assigns just its batch rows).
         join=False (concurrent form only): the caller's stream does NOT wait for the two k-means streams; the caller
-        goes on issuing independent work and calls `e_step_join()` in front of the first use of the centroids."""
+        goes on issuing independent work and calls `e_step_join()` in front of the first use of the centroids.
+        after (concurrent form only): a torch.cuda.Event behind which the embeddings are complete; the two streams wait for
+        IT instead of for everything the caller's stream has been given so far — the caller may then issue the e_step late
+        in program order (behind independent big launches) without making it wait for them."""
         with torch.no_grad():
             if user_emb is None or item_emb is None:
                 user_emb, item_emb, _ = self.model()
@@ -102,7 +105,10 @@ class NCLModel:
                     self._e_streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
                 res = []
                 for s, (x, k) in zip(self._e_streams, ((user_emb, k_users), (item_emb, k_items))):
-                    s.wait_stream(cur)
+                    if after is not None:
+                        s.wait_event(after)
+                    else:
+                        s.wait_stream(cur)
                     with torch.cuda.stream(s):
                         res.append(run_kmeans(x.contiguous(), k, **kw))
                 (self.user_centroids, self._user_2cluster), (self.item_centroids, self._item_2cluster) = res

@@ -47,13 +47,22 @@ class FusedNCLStep:
         # True: the table-side gradient branch of the backward runs on a side stream beside the SpMM recurrence
         self.overlap_backward = True
         self._side = None
+        # True: the structure contrast's forward runs on the side stream beside the message-pass launches that follow its
+        # context layer
+        self.overlap_forward = True
+        self.side_priority = None              # None: -1 when the owner replays a captured step, else 0
         # True: the e_step's streams are joined only in front of the prototype contrast (the structure contrast's forward
         # is issued meanwhile)
         self.early_e_step = True
 
     def _side_stream(self, dev):
         if self._side is None:
-            self._side = torch.cuda.Stream(device=dev)
+            # high priority inside a captured step: its kernels are few and big-tiled (one 512-thread workgroup per CU),
+            # and a gather kernel that got there first holds every wave slot until its grid drains (cfg3, replay: 7.93 ->
+            # 7.69 ms without / 9.85 -> 9.69 ms with the e_step).  NOT in eager mode: beside the e_step's ~150 small
+            # launches on their own two streams a high-priority stream made the step 12-15 ms instead of 9.9.
+            pr = self.side_priority if self.side_priority is not None else (-1 if self.owner.graph_capture else 0)
+            self._side = torch.cuda.Stream(device=dev, priority=pr)
         return self._side
 
     @staticmethod
@@ -91,6 +100,32 @@ class FusedNCLStep:
         eng = Fn._resolve_engine(unit_rows=True)
         gat = torch.cat([user_idx, pos_idx + n_u])                                # rows of the stacked table
 
+        # ---- structure contrast, forward (ncl.py:358-367): batch rows of the context layer against ALL layer-0 rows.  It
+        # needs the context layer only (2 of K = 3 launches at the reference's hyper_layers = 1): with `overlap_forward`
+        # it runs on the side stream beside the remaining launches of the message pass — matrix-core work next to an
+        # HBM-bound gather — and is joined where its losses are summed ----
+        rows_c = torch.empty(2 * bsz, d, dtype=torch.float32, device=dev)
+        sa = torch.empty(2 * bsz, dtype=torch.float32, device=dev)
+        sb = torch.empty(n, dtype=torch.float32, device=dev)
+        lse = torch.empty(2 * bsz, dtype=torch.float32, device=dev)
+        pl = torch.empty(2 * bsz, dtype=torch.float32, device=dev)
+        o = torch.empty(2 * bsz, d, dtype=torch.float32, device=dev)
+        xu, xi, sbu, sbi = x0[:n_u], x0[n_u:], sb[:n_u], sb[n_u:]
+
+        Fn.row_inv_norm(x0, out=sb)                                                # F.normalize(iu) / F.normalize(ii)
+
+        def contrast_rows(ctx):                                                    # the small launches stay on the main stream:
+            _lib.check(L.gcr_gather_rows_f32(_lib.dptr(ctx), _lib.dptr(gat), 2 * bsz, d, n, _lib.dptr(rows_c), stream),
+                       "gcr_gather_rows_f32")                                      # the fork releases the two big ones together
+            Fn.row_inv_norm(rows_c, out=sa)
+
+        def structure_contrast():
+            self._contrast_fwd(rows_c[:bsz], sa[:bsz], xu, sbu, user_idx, inv_tau, eng, lse[:bsz], o[:bsz], pl[:bsz])
+            self._contrast_fwd(rows_c[bsz:], sa[bsz:], xi, sbi, pos_idx, inv_tau, eng, lse[bsz:], o[bsz:], pl[bsz:])
+
+        main = torch.cuda.current_stream(dev)
+        fwd_side = self._side_stream(dev) if (self.overlap_forward and ci < K) else None
+
         # ---- forward: K-layer message pass, mean of the K + 1 layer outputs in the epilogue (ncl.py:415-422) ----
         cur, acc, ctx_layer = x0, x0, None
         for k in range(1, K + 1):
@@ -104,13 +139,26 @@ class FusedNCLStep:
                 cur = y
             if k == ci:
                 ctx_layer = y
+                if fwd_side is not None:
+                    contrast_rows(ctx_layer)
+                    fwd_side.wait_stream(main)
+                    with torch.cuda.stream(fwd_side):
+                        structure_contrast()
         final = acc
         fu, fi = final[:n_u], final[n_u:]
 
-        # ---- e_step (ncl.py:324, every batch): k-means of the CURRENT encoder outputs, no host read-back.  Issued as soon
-        # as `final` exists, on its own two streams (NCLModel.e_step): it only has to be back for the prototype contrast ----
+        # ---- e_step (ncl.py:324, every batch): k-means of the CURRENT encoder outputs, no host read-back, on its own two
+        # streams (NCLModel.e_step).  It only has to be back for the prototype contrast, which `early_e_step` places behind
+        # the backward recurrence (nothing else in the step reads the centroids).  It waits for `final` (this event), but
+        # is ISSUED behind the backward's big launches: its ~150 short launches in front of them kept them waiting —
+        # in eager mode for the host, and in a replayed graph too (its nodes are dispatched in capture order) ----
+        ev_final = None
         if self.e_step_every_batch:
-            o_.e_step(fu, fi, assign_all=False, join=not self.early_e_step)      # the full assignment vectors on demand
+            if self.early_e_step:
+                ev_final = torch.cuda.Event()
+                ev_final.record(main)
+            else:
+                o_.e_step(fu, fi, assign_all=False, join=True)
 
         # ---- BPR + the three squared norms of l2_reg_loss (ncl.py:314-317,116-123) ----
         dldx = torch.empty(max(bsz, 1), dtype=torch.float32, device=dev)
@@ -128,58 +176,25 @@ class FusedNCLStep:
         gs[0:1].fill_(1.0 / bsz)
         gs[1:4].copy_((0.5 * o_.reg / (bsz * o_.batch_size)) / roots)
 
-        # ---- structure contrast (ncl.py:358-367): batch rows of the context layer against ALL layer-0 rows ----
-        rows_c = torch.empty(2 * bsz, d, dtype=torch.float32, device=dev)
-        _lib.check(L.gcr_gather_rows_f32(_lib.dptr(ctx_layer), _lib.dptr(gat), 2 * bsz, d, n, _lib.dptr(rows_c), stream),
-                   "gcr_gather_rows_f32")
-        sa = Fn.row_inv_norm(rows_c)
-        sb = Fn.row_inv_norm(x0)                                                   # F.normalize(iu) / F.normalize(ii)
-        lse = torch.empty(2 * bsz, dtype=torch.float32, device=dev)
-        pl = torch.empty(2 * bsz, dtype=torch.float32, device=dev)
-        o = torch.empty(2 * bsz, d, dtype=torch.float32, device=dev)
-        xu, xi, sbu, sbi = x0[:n_u], x0[n_u:], sb[:n_u], sb[n_u:]
-        self._contrast_fwd(rows_c[:bsz], sa[:bsz], xu, sbu, user_idx, inv_tau, eng, lse[:bsz], o[:bsz], pl[:bsz])
-        self._contrast_fwd(rows_c[bsz:], sa[bsz:], xi, sbi, pos_idx, inv_tau, eng, lse[bsz:], o[bsz:], pl[bsz:])
+        # ---- structure contrast: joined (or run here) ----
+        if fwd_side is not None:
+            main.wait_stream(fwd_side)
+        else:
+            contrast_rows(ctx_layer)
+            structure_contrast()
         w = torch.empty(2 * bsz, dtype=torch.float32, device=dev)                  # d total / d lse  (= - d total / d pos)
         w[:bsz].fill_(float(o_.ssl_reg))
         w[bsz:].fill_(float(o_.ssl_reg * o_.alpha))
         ssl_loss = ((lse - pl) * w).sum()
 
-        # ---- e_step joined here (issued right after the propagation, see above) ----
-        if self.e_step_every_batch:
-            o_.e_step_join()
-
-        # ---- prototype contrast (ncl.py:369-375): InfoNCE(e0[idx], centroid of idx's cluster) * batch_size ----
-        rows_0 = torch.empty(2 * bsz, d, dtype=torch.float32, device=dev)
-        _lib.check(L.gcr_gather_rows_f32(_lib.dptr(x0), _lib.dptr(gat), 2 * bsz, d, n, _lib.dptr(rows_0), stream),
-                   "gcr_gather_rows_f32")
-        # kmeans.index.search(x, 1) for the batch's rows only (ncl.py:371-372 read user_2cluster[user_idx] / item_2cluster[item_idx])
-        from .kmeans import assign_to_centroids
-        rows_f = torch.empty(2 * bsz, d, dtype=torch.float32, device=dev)
-        _lib.check(L.gcr_gather_rows_f32(_lib.dptr(final), _lib.dptr(gat), 2 * bsz, d, n, _lib.dptr(rows_f), stream),
-                   "gcr_gather_rows_f32")
-        cents = torch.cat([o_.user_centroids[assign_to_centroids(rows_f[:bsz], o_.user_centroids)],
-                           o_.item_centroids[assign_to_centroids(rows_f[bsz:], o_.item_centroids)]])
-        s0, sc = Fn.row_inv_norm(rows_0), Fn.row_inv_norm(cents)
-        lse_p = torch.empty(2 * bsz, dtype=torch.float32, device=dev)
-        pl_p = torch.empty(2 * bsz, dtype=torch.float32, device=dev)
-        o_p = torch.empty(2 * bsz, d, dtype=torch.float32, device=dev)
-        for lo in (0, bsz):
-            sl = slice(lo, lo + bsz)
-            self._contrast_fwd(rows_0[sl], s0[sl], cents[sl], sc[sl], None, inv_tau, eng, lse_p[sl], o_p[sl], pl_p[sl])
-        wp = o_.proto_reg * o_.batch_size / bsz                                    # mean over the batch, * batch_size
-        proto_loss = wp * (lse_p - pl_p).sum()
-        total = rec_loss + l2 / o_.batch_size + ssl_loss + proto_loss
-
         # =================================== backward ===================================
         # Two independent branches meet in the LAST launch of the Horner recurrence:
-        #   branch T (matrix-core bound, ~2.4 ms at cfg3): G0 = gradient w.r.t. the layer-0 table through the structure
-        #            contrast's candidate side (+ positives, F.normalize backward, prototype rows)
+        #   branch T (matrix-core bound, ~1.7 ms at cfg3): G0 = gradient w.r.t. the layer-0 table through the structure
+        #            contrast's candidate side (+ positives, F.normalize backward); the prototype rows join it at the end
         #   branch S (HBM bound, ~1.0 ms): anchor-side gradients, Zg from BPR, every launch of the recurrence but the last
         # With `overlap_backward` branch T runs on a side stream beside branch S (the table-side kernel leaves one wave slot
         # per SIMD that an SpMM wave fits into); the join is in front of the launch that takes G0 as its second addend.
         g0 = torch.empty_like(x0)
-        main = torch.cuda.current_stream(dev)
         side = self._side_stream(dev) if (self.overlap_backward and K > 1) else None
 
         def branch_table():
@@ -192,18 +207,6 @@ class FusedNCLStep:
                                                      None, _lib.dptr(g_tab), st), "gcr_infonce_pos_bwd_f32")
             _lib.check(L.gcr_normalize_bwd_f32(_lib.dptr(x0), _lib.dptr(sb), _lib.dptr(g0), n, d, _lib.dptr(g0), st),
                        "gcr_normalize_bwd_f32")
-            # prototype rows: only the anchors get a gradient (the centroids are constants of the e_step)
-            gp = o_p * (wp * inv_tau)
-            neg_wp = torch.full((2 * bsz,), -wp, dtype=torch.float32, device=dev)
-            for lo in (0, bsz):
-                sl = slice(lo, lo + bsz)
-                _lib.check(L.gcr_infonce_pos_bwd_f32(_lib.dptr(rows_0[sl]), _lib.dptr(s0[sl]), _lib.dptr(cents[sl]), _lib.dptr(sc[sl]),
-                                                     None, _lib.dptr(neg_wp[sl]), bsz, bsz, d, inv_tau, _lib.dptr(gp[sl]), None,
-                                                     st), "gcr_infonce_pos_bwd_f32")
-            _lib.check(L.gcr_normalize_bwd_f32(_lib.dptr(rows_0), _lib.dptr(s0), _lib.dptr(gp), 2 * bsz, d, _lib.dptr(gp), st),
-                       "gcr_normalize_bwd_f32")
-            _lib.check(L.gcr_scatter_add_rows_f32(_lib.dptr(gp), _lib.dptr(gat), 2 * bsz, d, n, _lib.dptr(g0), st),
-                       "gcr_scatter_add_rows_f32")
 
         neg_w = -w
         if side is not None:
@@ -251,8 +254,47 @@ class FusedNCLStep:
             if k == ci:
                 add_ctx(out)                       # the context layer's sparse gradient joins h_k after the launch
             h = out
+        # ---- the e_step is issued and joined HERE: it depends on `final` only, so it runs beside the structure contrast's
+        # backward and the recurrence above; everything that needs the centroids is the 2 B-row prototype contrast below ----
+        if ev_final is not None:
+            o_.e_step(fu, fi, assign_all=False, join=False, after=ev_final)
+            o_.e_step_join()
+
+        # ---- prototype contrast (ncl.py:369-375): InfoNCE(e0[idx], centroid of idx's cluster) * batch_size ----
+        rows_0 = torch.empty(2 * bsz, d, dtype=torch.float32, device=dev)
+        _lib.check(L.gcr_gather_rows_f32(_lib.dptr(x0), _lib.dptr(gat), 2 * bsz, d, n, _lib.dptr(rows_0), stream),
+                   "gcr_gather_rows_f32")
+        # kmeans.index.search(x, 1) for the batch's rows only (ncl.py:371-372 read user_2cluster[user_idx] / item_2cluster[item_idx])
+        from .kmeans import assign_to_centroids
+        rows_f = torch.empty(2 * bsz, d, dtype=torch.float32, device=dev)
+        _lib.check(L.gcr_gather_rows_f32(_lib.dptr(final), _lib.dptr(gat), 2 * bsz, d, n, _lib.dptr(rows_f), stream),
+                   "gcr_gather_rows_f32")
+        cents = torch.cat([o_.user_centroids[assign_to_centroids(rows_f[:bsz], o_.user_centroids)],
+                           o_.item_centroids[assign_to_centroids(rows_f[bsz:], o_.item_centroids)]])
+        s0, sc = Fn.row_inv_norm(rows_0), Fn.row_inv_norm(cents)
+        lse_p = torch.empty(2 * bsz, dtype=torch.float32, device=dev)
+        pl_p = torch.empty(2 * bsz, dtype=torch.float32, device=dev)
+        o_p = torch.empty(2 * bsz, d, dtype=torch.float32, device=dev)
+        for lo in (0, bsz):
+            sl = slice(lo, lo + bsz)
+            self._contrast_fwd(rows_0[sl], s0[sl], cents[sl], sc[sl], None, inv_tau, eng, lse_p[sl], o_p[sl], pl_p[sl])
+        wp = o_.proto_reg * o_.batch_size / bsz                                    # mean over the batch, * batch_size
+        proto_loss = wp * (lse_p - pl_p).sum()
+        total = rec_loss + l2 / o_.batch_size + ssl_loss + proto_loss
+        # its backward: only the anchors get a gradient (the centroids are constants of the e_step)
+        gp = o_p * (wp * inv_tau)
+        neg_wp = torch.full((2 * bsz,), -wp, dtype=torch.float32, device=dev)
+        for lo in (0, bsz):
+            sl = slice(lo, lo + bsz)
+            _lib.check(L.gcr_infonce_pos_bwd_f32(_lib.dptr(rows_0[sl]), _lib.dptr(s0[sl]), _lib.dptr(cents[sl]), _lib.dptr(sc[sl]),
+                                                 None, _lib.dptr(neg_wp[sl]), bsz, bsz, d, inv_tau, _lib.dptr(gp[sl]), None,
+                                                 stream), "gcr_infonce_pos_bwd_f32")
+        _lib.check(L.gcr_normalize_bwd_f32(_lib.dptr(rows_0), _lib.dptr(s0), _lib.dptr(gp), 2 * bsz, d, _lib.dptr(gp), stream),
+                   "gcr_normalize_bwd_f32")
         if side is not None:
             main.wait_stream(side)                 # G0 complete
+        _lib.check(L.gcr_scatter_add_rows_f32(_lib.dptr(gp), _lib.dptr(gat), 2 * bsz, d, n, _lib.dptr(g0), stream),
+                   "gcr_scatter_add_rows_f32")
         dx0 = torch.empty_like(x0)
         Fn.spmm_into(gt, h, acc_in=zg, acc_in2=g0, acc_in2_scale=inv_c, acc_out=dx0, acc_scale=c, col_active_bits=bits)
 

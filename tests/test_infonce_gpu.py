@@ -531,10 +531,11 @@ def test_two_operand_formats_agree_on_random_problems(engine):
 
 
 def test_eight_wave_form_of_the_loop_matches_three_plane_format(Fn, engine):
-    """Problems whose splits are >= 256 tiles long run the two-product loop as 512-thread workgroups (two wave groups
-    one barrier interval apart, sharing each staged tile): flash forward and backward (statistics on the stationary rows,
-    on both sides, excluded diagonal) at 2048 x 300K and 50K x 50K against the three-bf16-plane format, which never
-    takes that form."""
+    """Problems whose splits are >= 256 tiles long run the flash forward as 512-thread workgroups (two wave groups one
+    barrier interval apart, sharing each staged tile): lse and o at 2048 x 300K and 50K x 50K (excluded diagonal) against
+    the three-bf16-plane format, which never takes that form; the backward launches of the same problems (statistics on the
+    stationary rows, on both sides, excluded diagonal; 256-thread form over the pre-scaled image of the streamed side)
+    ride along."""
     if engine != "auto":
         pytest.skip("compares the two formats itself")
     g = torch.Generator(device="cuda").manual_seed(9)

@@ -667,12 +667,17 @@ constexpr float kH2MaxInvTau = 20.0f;
 bool use_h2(int d, float inv_tau, bool unit_rows, bool force_f32) {
   return use_b3(d, force_f32) && unit_rows && d <= 64 && inv_tau > 0.f && inv_tau <= kH2MaxInvTau;
 }
+// ... and the two-product loop (flash forward, backward) also at d = 128: two planes of 128 features fit the pipelined
+// loop's registers (12-99 spilled dwords at 256), three do not (infonce_fwdo_b3_kernel / infonce_bwd_b3_kernel)
+bool use_h2_loop(int d, float inv_tau, bool unit_rows, bool force_f32) {
+  return use_b3(d, force_f32) && unit_rows && d <= 128 && inv_tau > 0.f && inv_tau <= kH2MaxInvTau;
+}
 constexpr int64_t kBwdHeader = 256;   // d <= 64: the backward's workspace starts with the two floats of h2_wscale_kernel
 // ... followed by h2_fold_kernel's image of the streamed rows (two per-row arrays and the scaled rows themselves, padded
 // to whole tiles), rounded to 256 B; the per-split partial gradients start behind them
 constexpr int64_t fold_rows(int64_t ny) { return (ny + kTileJ - 1) / kTileJ * kTileJ; }
 constexpr int64_t bwd_header_bytes(int64_t ny, int d) {
-  return d <= 64 ? kBwdHeader + ((fold_rows(ny) * (2 + d) * (int64_t)sizeof(float) + 255) / 256) * 256 : 0;
+  return d <= 128 ? kBwdHeader + ((fold_rows(ny) * (2 + d) * (int64_t)sizeof(float) + 255) / 256) * 256 : 0;
 }
 
 // natural-log LSE of the scaled logits from the per-split (max2, sum2) partials
@@ -1387,7 +1392,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
     int64_t tiles_per_split, float* __restrict__ gpart, float2* __restrict__ part, const float* __restrict__ hw) {
   using S = ShapeB3<D>;
   using B = BwdB3<D>;
-  static_assert(D <= 64, "the pipelined loop keeps five plane sets in LDS");
+  static_assert(D <= 64 || (D == 128 && std::is_same<E, EngH2>::value), "d = 128: two planes only (registers)");
   constexpr int NPL = E::NPL, NTERM = E::NTERM;
   constexpr int RM = NPL * S::PLANE;
   constexpr int THREADS = 64 * NW;
@@ -1859,7 +1864,7 @@ int32_t launch_bwd(const float* x, const float* x_scale, int64_t mx, const float
     if (use_b3(D, force_f32)) {
       // d <= 64: the cross-tile pipelined loop (infonce_pipe_b3_kernel); d = 128: single-buffered (one tile with its
       // transposed copy is 54 KB of LDS)
-      const bool h2 = use_h2(D, inv_tau, unit_rows, force_f32);
+      const bool h2 = use_h2_loop(D, inv_tau, unit_rows, force_f32);
       // (always the 256-thread form: the 512-thread form of the flash forward halves the STAGING work per MFMA, and the
       // backward stages from the pre-scaled image — two loads and two splits per lane.  At 100K x 100K the 512-thread
       // backward, 3-7 % ahead in round 2, is now behind: both sides 8.25 vs 7.44 ms, excluded diagonal 8.93 vs 8.45)
@@ -1872,7 +1877,7 @@ int32_t launch_bwd(const float* x, const float* x_scale, int64_t mx, const float
         hipLaunchKernelGGL(h2_wscale_kernel, dim3(1), dim3(1024), 0, s, w_x, mx, w_y, ny, hw);
         int32_t st = GCR_LAUNCH_STATUS();
         if (st != GCR_OK) return st;
-        if constexpr (D <= 64) {                           // the loop's image of the streamed side (h2_prestage_kernel)
+        {                                                  // the loop's image of the streamed side (h2_prestage_kernel)
           float* img = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + kBwdHeader);
           const int64_t rows = fold_rows(ny);
           const dim3 pg((unsigned)((rows * (D / 4) + 255) / 256));
@@ -1904,7 +1909,11 @@ int32_t launch_bwd(const float* x, const float* x_scale, int64_t mx, const float
       hipLaunchKernelGGL((infonce_pipe_kernel<EngB3, D, 0, EX, SD>), grid, dim3(256), 0, s, x, x_scale, mx, y, y_scale, \
                          ny, inv_tau * kLog2e, inv_tau, lse_x, w_x, lse_y, w_y, p.nsplit, p.tiles_per_split, gpart,     \
                          (float2*)nullptr, (const float*)nullptr);                                                      \
-  } else                                                                                                                \
+  } else if (h2)                                                                                                        \
+    hipLaunchKernelGGL((infonce_pipe_kernel<EngH2, D, 0, EX, SD>), grid, dim3(256), 0, s, x, x_scale, mx, y, y_scale,   \
+                       ny, inv_tau * kLog2e, inv_tau, lse_x, w_x, lse_y, w_y, p.nsplit, p.tiles_per_split, gpart,       \
+                       (float2*)nullptr, (const float*)hw);                                                             \
+  else                                                                                                                  \
     hipLaunchKernelGGL((infonce_bwd_b3_kernel<D, EX, SD>), grid, dim3(256), 0, s, x, x_scale, mx, y, y_scale,    \
                        ny, inv_tau * kLog2e, inv_tau, lse_x, w_x, lse_y, w_y, p.nsplit, p.tiles_per_split, gpart)
       if (exd) {
@@ -2017,16 +2026,16 @@ int32_t launch_fwd(const float* a, const float* a_scale, int64_t m, const float*
 template <int D>
 int32_t launch_fwd_o(const float* a, const float* a_scale, int64_t m, const float* b, const float* b_scale, int64_t n,
                      float inv_tau, float* lse, float* o, void* workspace, bool exd, bool unit_rows, hipStream_t s) {
-  const bool h2o = D <= 64 && use_h2(D, inv_tau, unit_rows, false);
+  const bool h2o = use_h2_loop(D, inv_tau, unit_rows, false);
   const FwdPlan p8 = plan_h2_rows8(m, n, D);
   const bool w8 = h2o && h2_eight_waves(D, p8);
   const FwdPlan p = w8 ? p8 : plan_bwd_rows(m, n, D, BwdB3<D>::ROWS_PER_BLOCK);
   float2* part = reinterpret_cast<float2*>(workspace);
   float* opart = reinterpret_cast<float*>(part + (int64_t)p.nsplit * m);
   const dim3 grid((unsigned)(p.m_blocks * p.nsplit));
+  const float* none = nullptr;
+  const float h2_out = 1.0f / (EngH2::kSY * 16384.0f);               // streamed operand x 2^8, P x 2^kPExp
   if constexpr (D <= 64) {
-    const float* none = nullptr;
-    const float h2_out = 1.0f / (EngH2::kSY * 16384.0f);             // streamed operand x 2^8, P x 2^kPExp
 #define GCR_FWDO(ENG, EX, OS, NWV)                                                                                       \
   hipLaunchKernelGGL((infonce_pipe_kernel<ENG, D, 1, EX, 0, NWV>), grid, dim3(64 * NWV), 0, s, a, a_scale, m, b, b_scale, \
                      n, inv_tau * kLog2e, OS, none, none, none, none, p.nsplit, p.tiles_per_split, opart, part, none)
@@ -2042,6 +2051,9 @@ int32_t launch_fwd_o(const float* a, const float* a_scale, int64_t m, const floa
       if (exd) GCR_FWDO(EngB3, true, 1.0f, 4);
       else GCR_FWDO(EngB3, false, 1.0f, 4);
     }
+  } else if (h2o) {
+    if (exd) GCR_FWDO(EngH2, true, h2_out, 4);
+    else GCR_FWDO(EngH2, false, h2_out, 4);
 #undef GCR_FWDO
   } else {
     if (exd)

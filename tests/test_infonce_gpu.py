@@ -370,13 +370,14 @@ def test_flash_forward_path_gives_the_same_gradients(Fn, engine, monkeypatch, m,
 def test_two_product_loop_random_shapes(Fn, engine):
     """The cross-tile pipelined loop (prologue of two tiles, steps in pairs, a peeled last step, a ring of three LDS
     images) over 48 random (M, N, d, 1/tau) incl. tile counts 1..6 per split and ragged last tiles: flash forward
-    (lse, o) and the table-side / anchor-side backward against float64."""
+    (lse, o) and the table-side / anchor-side backward against float64.  d = 128 runs the same loop on two f16 planes
+    (three bf16 planes keep their own un-pipelined kernels there)."""
     if engine == "f32":
         pytest.skip("the pipelined loop is the split-operand engine's")
     ef = Fn._resolve_engine(unit_rows=True)
     rng = np.random.default_rng(2024)
     for case in range(48):
-        d = int(rng.choice([32, 64]))
+        d = int(rng.choice([32, 64, 128]))
         m = int(rng.integers(1, 400))
         n = int(rng.choice([rng.integers(1, 200), rng.integers(1, 3000), 32 * rng.integers(1, 7)]))
         inv_tau = float(rng.choice([1.0, 5.0, 10.0, 20.0]))
@@ -408,7 +409,7 @@ def test_two_product_loop_random_shapes(Fn, engine):
         assert np.abs(ga - ref_ga).max() <= 2e-5 * max(np.abs(ref_ga).max(), 1e-6), tag
 
 
-@pytest.mark.parametrize("m,n,d", [(70, 500, 64), (2048, 3000, 64), (333, 1000, 32)])
+@pytest.mark.parametrize("m,n,d", [(70, 500, 64), (2048, 3000, 64), (333, 1000, 32), (333, 1000, 128)])
 def test_table_side_backward_weights_in_the_exponent(Fn, engine, m, n, d):
     """Statistics on the streamed rows only: the two-f16-plane loop carries each weight as 2^(log2|w| - lse log2 e) inside
     the exponent and its sign in the staged row (h2_fold_kernel).  Weights of both signs, exact zeros, 25 orders of
@@ -442,7 +443,7 @@ def test_table_side_backward_weights_in_the_exponent(Fn, engine, m, n, d):
     assert float(gz.abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("m,d", [(33, 64), (65, 64), (129, 64), (257, 64), (300, 32), (1000, 64)])
+@pytest.mark.parametrize("m,d", [(33, 64), (65, 64), (129, 64), (257, 64), (300, 32), (1000, 64), (129, 128), (700, 128)])
 def test_exclude_diagonal_backward_raw_multi_tile(Fn, engine, m, d):
     """gcr_infonce_bwd_ex_f32 with GCR_INFONCE_EXCLUDE_DIAGONAL on a self-similarity problem of 2..32 tiles (the pipelined
     loop's MODE 0 with the diagonal mask in every step), statistics on the streamed side and on the stationary side,

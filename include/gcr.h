@@ -247,10 +247,10 @@ int32_t gcr_infonce_fwd_f32(const float* a, const float* a_scale, int64_t m,
 /* GCR_INFONCE_UNIT_ROWS: the caller promises |a_scale[i] * a_i|_2 <= 1 and |b_scale[j] * b_j|_2 <= 1 — rows normalised
  * by the scales, as every contrast loss of the reference does (F.normalize, ncl.py:127, gcl.py:29-30).  With the
  * operand range known, the split-operand launches (gcr_infonce_fwd_ex_f32, gcr_infonce_fwd_o_f32,
- * gcr_infonce_bwd_ex_f32) of d <= 64 and inv_tau <= 20 run on TWO f16 planes per operand and three product terms
- * instead of three bf16 planes and six (csrc/gcr_infonce.hip, EngH2): half the matrix-core work, operands rounded
- * at 2^-22 instead of 2^-27 — a few f32 roundings per product, inside the 1e-5 of every parity test.  Without the
- * promise nothing changes. */
+ * gcr_infonce_bwd_ex_f32) of d <= 64 — the two-product launches gcr_infonce_fwd_o_f32 / gcr_infonce_bwd_ex_f32 also of
+ * d = 128 — and inv_tau <= 20 run on TWO f16 planes per operand and three product terms instead of three bf16 planes and
+ * six (csrc/gcr_infonce.hip, EngH2): half the matrix-core work, operands rounded at 2^-22 instead of 2^-27 — a few f32
+ * roundings per product, inside the 1e-5 of every parity test.  Without the promise nothing changes. */
 #define GCR_INFONCE_UNIT_ROWS 2u
 int32_t gcr_infonce_fwd_ex_f32(const float* a, const float* a_scale, int64_t m,
                                const float* b, const float* b_scale, int64_t n, int32_t d,

@@ -531,7 +531,8 @@ INFONCE_UNIT_ROWS = 2
 INFONCE_ENGINE_F32 = 4
 
 # "auto": the library default — split-operand engine for d <= 128 (its two-product launches on two f16 planes when
-# the rows are normalised by the op itself, d <= 64: the GCR_INFONCE_UNIT_ROWS promise), f32 MFMA for d = 256;
+# the rows are normalised by the op itself, d <= 64 — flash forward and backward also d = 128: the
+# GCR_INFONCE_UNIT_ROWS promise), f32 MFMA for d = 256;
 # "b3": withhold the unit-rows promise (three bf16 planes everywhere); "f32": force the f32 MFMA.
 # Read ONCE per forward (`_resolve_engine`); the backward reuses what the forward ran on.
 INFONCE_ENGINE = "auto"

@@ -64,14 +64,14 @@ def test_gcl_loss_block_and_ncl_l2reg(Fn, golden):
     n = len(b["u_idx"])
     sums = Fn.bpr_sums(ut, it, b["u_idx"], b["i_idx"], b["j_idx"], Fn.BPR_LOGSIGMOID)
     loss = sums[0] / n + 1e-4 * (sums[1] + sums[2] + sums[3]) / n
-    assert float(loss) == pytest.approx(float(b["gcl_block_loss"]), rel=1e-5)
+    assert float(loss.detach()) == pytest.approx(float(b["gcl_block_loss"]), rel=1e-5)
     loss.backward()
     _close(ut.grad, b["gcl_block_gu"])
     _close(it.grad, b["gcl_block_gi"])
     ut.grad = it.grad = None
     sums = Fn.bpr_sums(ut, it, b["u_idx"], b["i_idx"], b["j_idx"], Fn.BPR_NCL)
     l2 = 1e-4 * (sums[1].sqrt() + sums[2].sqrt() + sums[3].sqrt()) / n
-    assert float(l2) == pytest.approx(float(b["ncl_l2reg_loss"]), rel=1e-5)
+    assert float(l2.detach()) == pytest.approx(float(b["ncl_l2reg_loss"]), rel=1e-5)
     l2.backward()
     _close(ut.grad, b["ncl_l2reg_gu"])
     _close(it.grad, b["ncl_l2reg_gi"])

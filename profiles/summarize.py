@@ -7,7 +7,7 @@ directory.  Usage: python profiles/summarize.py gpurun_out/prof_r02 r02
                                           (separate passes) -> <tag>_<wl>_pmc_hbm.csv + pmc_traffic.json[<wl>]
   <dir>/kt_nce/, pmc_nce/                 profiles/infonce_probe.py -> <tag>_infonce_kernel_stats.csv,
                                           <tag>_infonce_pmc_mfma.csv + pmc_traffic.json["infonce"]
-  <dir>/kt_ncl/, kt_km/, kt_rank/         profiles/ncl_step_probe.py, kmeans_probe.py, rank_probe.py
+  <dir>/kt_ncl/, kt_km/, kt_rank/, kt_lg/ profiles/ncl_step_probe.py, kmeans_probe.py, rank_probe.py, lightgcn_step_probe.py
 pmc_traffic.json entries carry the digest of the kernel sources the probe ran (written by the probe on the
 GPU box) and the git commit of the tree they were summarised in; bench.py attaches an entry only when the
 digest matches the sources it benchmarks.
@@ -96,6 +96,7 @@ stats("kt_nce/*/*_kernel_stats.csv", f"{tag}_infonce_kernel_stats.csv", top=10)
 stats("kt_ncl/*/*_kernel_stats.csv", f"{tag}_ncl_step_kernel_stats.csv", top=16)      # profiles/ncl_step_probe.py
 stats("kt_km/*/*_kernel_stats.csv", f"{tag}_kmeans_kernel_stats.csv", top=6)           # profiles/kmeans_probe.py
 stats("kt_rank/*/*_kernel_stats.csv", f"{tag}_rank_kernel_stats.csv", top=6)           # profiles/rank_probe.py
+stats("kt_lg/*/*_kernel_stats.csv", f"{tag}_lightgcn_step_kernel_stats.csv", top=10)     # profiles/lightgcn_step_probe.py
 
 traffic_path = os.path.join(here, "pmc_traffic.json")
 try:

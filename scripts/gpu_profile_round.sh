@@ -35,6 +35,8 @@ if [ "$WHAT" = "nce" ] || [ "$WHAT" = "all" ]; then
   echo "ncl step pass done"
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_rank" -- python3 "$R/profiles/rank_probe.py" > "$OUT/kt_rank.log" 2>&1
   echo "rank pass done"
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_lg" -- python3 "$R/profiles/lightgcn_step_probe.py" > "$OUT/kt_lg.log" 2>&1
+  echo "lightgcn step pass done"
 fi
 # keep the merge-back small: only the CSV summaries are read afterwards
 find "$OUT" -name "*.db" -delete 2>/dev/null || true

@@ -54,7 +54,8 @@ def leg(capture, e_step, **flags):
 
 
 for e_step in (True, False):
-    for capture in (False, True):
+    for capture in (True, False):
         for of in (False, True):
-            t = leg(capture, e_step, overlap_forward=of)
-            print(f"e_step={e_step} graph={capture} overlap_forward={of}: {t:.3f} ms", flush=True)
+            for ob in (False, True):
+                t = leg(capture, e_step, overlap_forward=of, overlap_backward=ob)
+                print(f"e_step={e_step} graph={capture} overlap_forward={of} overlap_backward={ob}: {t:.3f} ms", flush=True)

@@ -418,31 +418,48 @@ __device__ __forceinline__ void score_tile_e(const unsigned char* __restrict__ t
 
 
 // staging with a workgroup of THREADS lanes (the 512-thread form of infonce_fwd_e_kernel: one float4 per lane at d = 64)
+// one tile's share of a lane between its global load and its LDS store
+template <int N>
+struct StagedRows {
+  float4 v[N];
+  float s[N];
+  bool live[N];
+};
+
+// The loads only: the row AND its scale go to registers untouched, the multiply happens where the tile is staged
+// (stage_store_t_one), most of a tile loop iteration later.  (Multiplying here — and loading the scale inside an
+// `if (b_scale)` — made every iteration open with `global_load ...; s_waitcnt vmcnt(0)`: a whole memory round trip in
+// front of the first MFMA of every tile, for all waves of the workgroup at once.)  `b_scale == nullptr` loads a dummy
+// word of `b` through a zero stride instead of branching (the value is replaced by 1 where it is used; both pointers are
+// global, so the load stays a global_load — a generic-address load would tie vmcnt to lgkmcnt).
+
 template <int D, int THREADS>
 __device__ __forceinline__ void stage_load_t(const float* __restrict__ b, const float* __restrict__ b_scale, int64_t n_rows,
-                                             int64_t j0, int tid, float4 (&regs)[(kTileJ * D / 4) / THREADS], float mult) {
+                                             int64_t j0, int tid, StagedRows<(kTileJ * D / 4) / THREADS>& g) {
+  const float* __restrict__ sp = b_scale != nullptr ? b_scale : b;               // wave-uniform
+  const int64_t stride = b_scale != nullptr ? 1 : 0;
 #pragma unroll
   for (int u = 0; u < (kTileJ * D / 4) / THREADS; ++u) {
     const int idx = tid + THREADS * u;
     const int row = idx / (D / 4), c4 = idx % (D / 4);
     const int64_t j = j0 + row;
     const int64_t jj = j < n_rows ? j : n_rows - 1;
-    float4 v = *reinterpret_cast<const float4*>(b + jj * D + 4 * c4);
-    float s = b_scale != nullptr ? b_scale[jj] * mult : mult;
-    s = j < n_rows ? s : 0.f;
-    v.x *= s; v.y *= s; v.z *= s; v.w *= s;
-    regs[u] = v;
+    g.v[u] = *reinterpret_cast<const float4*>(b + jj * D + 4 * c4);
+    g.s[u] = sp[jj * stride];
+    g.live[u] = j < n_rows;                                  // rows behind the end: scale 0, applied with the multiply
   }
 }
 
 template <class E, int D, int THREADS>
-__device__ __forceinline__ void stage_store_t_one(unsigned char* __restrict__ tile, int tid, const float4& v, int u) {
+__device__ __forceinline__ void stage_store_t_one(unsigned char* __restrict__ tile, int tid, const float4& v, float sc,
+                                                  bool live, bool has_scale, int u) {
   using S = ShapeB3<D>;
   const int idx = tid + THREADS * u;
   const int row = idx / (D / 4), c4 = idx % (D / 4);
   unsigned qa[E::NPL], qb[E::NPL];
-  E::split(v.x, v.y, qa);
-  E::split(v.z, v.w, qb);
+  sc = live ? (has_scale ? sc * E::kSY : E::kSY) : 0.f;
+  E::split(v.x * sc, v.y * sc, qa);
+  E::split(v.z * sc, v.w * sc, qb);
   unsigned char* p = tile + row * S::ROWB + c4 * 8;
 #pragma unroll
   for (int pl = 0; pl < E::NPL; ++pl) *reinterpret_cast<uint2*>(p + pl * S::PLANE) = make_uint2(qa[pl], qb[pl]);
@@ -490,7 +507,7 @@ __global__ __launch_bounds__(64 * NW, 2) void infonce_fwd_e_kernel(const float* 
   const int64_t total_tiles = (n_rows + kTileJ - 1) / kTileJ;
   const int64_t tile0 = (int64_t)split * tiles_per_split;
   const int64_t tile1 = min(total_tiles, tile0 + tiles_per_split);
-  float4 regs[NLD];
+  StagedRows<NLD> ga, gb;                                  // two tiles in flight: loaded in one step, staged in the next
   auto colsum = [&](const f32x16 (&acc)[S::NT], int64_t tt) {
     const int64_t j0 = tt * kTileJ;
 #pragma unroll
@@ -535,19 +552,25 @@ __global__ __launch_bounds__(64 * NW, 2) void infonce_fwd_e_kernel(const float* 
     constexpr int NU = 22 * S::NT + NLD + (COLSUM ? 16 : 0);      // VALU micro-units per step
     const int64_t last = tile1 - 1;
     f32x16 acc_a[S::NT], acc_b[S::NT];
-    auto store_all = [&](unsigned char* tile) {
+    auto store_all = [&](unsigned char* tile, const StagedRows<NLD>& g) {
 #pragma unroll
-      for (int u = 0; u < NLD; ++u) stage_store_t_one<E, D, THREADS>(tile, tid, regs[u], u);
+      for (int u = 0; u < NLD; ++u) stage_store_t_one<E, D, THREADS>(tile, tid, g.v[u], g.s[u], g.live[u], b_scale != nullptr, u);
     };
-    stage_load_t<D, THREADS>(b, b_scale, n_rows, tile0 * kTileJ, tid, regs, E::kSY);
-    store_all(lds[0]);
-    stage_load_t<D, THREADS>(b, b_scale, n_rows, min(tile0 + 1, last) * kTileJ, tid, regs, E::kSY);
+    stage_load_t<D, THREADS>(b, b_scale, n_rows, tile0 * kTileJ, tid, ga);
+    stage_load_t<D, THREADS>(b, b_scale, n_rows, min(tile0 + 1, last) * kTileJ, tid, gb);
+    store_all(lds[0], ga);
+    stage_load_t<D, THREADS>(b, b_scale, n_rows, min(tile0 + 2, last) * kTileJ, tid, ga);
     __syncthreads();
     score_tile_e<E, D, S::NT>(lds[0], i32, h, bq, acc_a);
-    store_all(lds[1]);
+    store_all(lds[1], gb);
     __syncthreads();
-    auto step = [&](f32x16 (&cur)[S::NT], f32x16 (&nxt)[S::NT], int64_t tt, int nb) {
-      stage_load_t<D, THREADS>(b, b_scale, n_rows, min(tt + 2, last) * kTileJ, tid, regs, E::kSY);
+    // step tt: scores of tile tt + 1 (in lds[nb]) || softmax of tile tt || staging of tile tt + 2 (loaded one step
+    // earlier, in `st`) into the other buffer || the loads of tile tt + 3 into `ld`: a load has a whole step to land — it
+    // used to be issued at the top of the step that staged it, with its scale multiplied in on the spot, i.e. behind a
+    // `s_waitcnt vmcnt(0)` that every wave of the workgroup sat out in front of the step's first MFMA
+    auto step = [&](f32x16 (&cur)[S::NT], f32x16 (&nxt)[S::NT], int64_t tt, int nb, StagedRows<NLD>& ld,
+                    const StagedRows<NLD>& st) {
+      stage_load_t<D, THREADS>(b, b_scale, n_rows, min(tt + 3, last) * kTileJ, tid, ld);
       const unsigned char* base = lds[nb] + i32 * S::ROWB + h * (S::KH * 2);
       unsigned char* out = lds[nb ^ 1];
       float tmax[S::NT], m_new[S::NT], sum[S::NT];
@@ -572,7 +595,8 @@ __global__ __launch_bounds__(64 * NW, 2) void infonce_fwd_e_kernel(const float* 
             if (i32 == 31 && j < n_rows) atomicAdd(col_sum + j, e);
           }
         } else if (m >= 22 * S::NT) {
-          stage_store_t_one<E, D, THREADS>(out, tid, regs[m - 22 * S::NT], m - 22 * S::NT);
+          stage_store_t_one<E, D, THREADS>(out, tid, st.v[m - 22 * S::NT], st.s[m - 22 * S::NT], st.live[m - 22 * S::NT],
+                                           b_scale != nullptr, m - 22 * S::NT);
         } else if (u < 4) {
           if (EXD) {                                    // excluded diagonal pair: -inf before it is seen by max / exp2
 #pragma unroll
@@ -630,11 +654,11 @@ __global__ __launch_bounds__(64 * NW, 2) void infonce_fwd_e_kernel(const float* 
     };
     int64_t tt = tile0;
     for (; tt + 2 <= last; tt += 2) {
-      step(acc_a, acc_b, tt, 1);
-      step(acc_b, acc_a, tt + 1, 0);
+      step(acc_a, acc_b, tt, 1, gb, ga);
+      step(acc_b, acc_a, tt + 1, 0, ga, gb);
     }
     if (tt < last) {
-      step(acc_a, acc_b, tt, 1);
+      step(acc_a, acc_b, tt, 1, gb, ga);
       epilogue_any(acc_b, last);
     } else {
       epilogue_any(acc_a, last);
@@ -1440,19 +1464,20 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
   if (tile0 < tile1) {
     constexpr int NP = 3 * NLDW, NS1 = NTERM * S::KC, NG = B::CT * 2 * NTERM;
     const int64_t last = tile1 - 1;
-    float4 ra[NLDW], rb[NLDW];
+    StagedRows<NLDW> ra, rb;                                // (raw rows + their scales: multiplied where they are staged)
     float sla = 0.f, swa = 0.f, slb = 0.f, swb = 0.f;
-    auto load_tile = [&](int64_t t, float4 (&r)[NLDW], float& sl, float& sw) {
+    auto load_tile = [&](int64_t t, StagedRows<NLDW>& r, float& sl, float& sw) {
       const int64_t j0 = min(t, last) * kTileJ;
       // wave-uniform tile base + 32-bit per-thread offsets (a ragged last tile clamps its rows to the last valid
       // one and zeroes their scale): no 64-bit vector arithmetic in the loop
       const int rem = (int)min((int64_t)kTileJ, ny - j0);
       const float* tb = y + j0 * D;
-      const float* ts = y_scale != nullptr ? y_scale + j0 : nullptr;
+      const float* sp = y_scale != nullptr ? y_scale + j0 : y;               // (no scale: a dummy word through a zero stride)
+      const int sstride = y_scale != nullptr ? 1 : 0;
       if (PRE) {                                             // scaled and padded already: uniform base + a constant offset per lane
 #pragma unroll
         for (int u = 0; u < NLDW; ++u)
-          r[u] = *reinterpret_cast<const float4*>(tb + 4u * (unsigned)min(tid + THREADS * u, F4T - 1));
+          r.v[u] = *reinterpret_cast<const float4*>(tb + 4u * (unsigned)min(tid + THREADS * u, F4T - 1));
         if (SIDES != 1 && tid < kTileJ) {
           sw = w_y[j0 + tid];
           sl = lse_y[j0 + tid];
@@ -1464,11 +1489,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
         const int idx = min(tid + THREADS * u, F4T - 1);     // (more threads than float4s: the surplus reloads the last one)
         const int row = idx / (D / 4), c4 = idx % (D / 4);
         const int rr = min(row, rem - 1);
-        float4 v = *reinterpret_cast<const float4*>(tb + rr * D + 4 * c4);
-        float sc = ts != nullptr ? ts[rr] * E::kSY : E::kSY;
-        sc = row < rem ? sc : 0.f;
-        v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
-        r[u] = v;
+        // loads only: the scale is multiplied in where the row is staged, two steps from here (doing it on the spot put
+        // a `s_waitcnt vmcnt(0)` behind the loads — a memory round trip in front of every step's first MFMA)
+        r.v[u] = *reinterpret_cast<const float4*>(tb + rr * D + 4 * c4);
+        r.s[u] = sp[rr * sstride];
+        r.live[u] = row < rem;
       }
       if (MODE == 0 && tid < kTileJ) {
         const int64_t j = j0 + tid;
@@ -1478,15 +1503,20 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
       }
     };
     // one third of the staging of one float4: split (x, y), split (z, w), row-major plane stores
-    auto stage_part = [&](int pi, const float4 (&st)[NLDW], unsigned (&sa)[NLDW][NPL], unsigned (&sb)[NLDW][NPL],
-                          unsigned char* rm, int sbuf, float sl, float sw) {
+    auto stage_part = [&](int pi, const StagedRows<NLDW>& st, float4 (&tm)[NLDW], unsigned (&sa)[NLDW][NPL],
+                          unsigned (&sb)[NLDW][NPL], unsigned char* rm, int sbuf, float sl, float sw) {
       const int u = pi / 3, k = pi % 3;
       const int idx = tid + THREADS * u;
       const int row = idx / (D / 4), c4 = idx % (D / 4);
       if (k == 0) {
-        E::template split<kSplitForm<MODE>>(st[u].x, st[u].y, sa[u]);
+        tm[u] = st.v[u];
+        if (!PRE) {
+          const float sc = st.live[u] ? (y_scale != nullptr ? st.s[u] * E::kSY : E::kSY) : 0.f;
+          tm[u].x *= sc; tm[u].y *= sc; tm[u].z *= sc; tm[u].w *= sc;
+        }
+        E::template split<kSplitForm<MODE>>(tm[u].x, tm[u].y, sa[u]);
       } else if (k == 1) {
-        E::template split<kSplitForm<MODE>>(st[u].z, st[u].w, sb[u]);
+        E::template split<kSplitForm<MODE>>(tm[u].z, tm[u].w, sb[u]);
       } else {
         unsigned char* p = rm + row * S::ROWB + c4 * 8;
         if (THREADS * NLDW == F4T || idx < F4T) {
@@ -1499,10 +1529,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
         }
       }
     };
-    auto stage_all = [&](const float4 (&st)[NLDW], unsigned char* rm, int sbuf, float sl, float sw) {
+    auto stage_all = [&](const StagedRows<NLDW>& st, unsigned char* rm, int sbuf, float sl, float sw) {
       unsigned sa[NLDW][NPL], sb[NLDW][NPL];
+      float4 tm[NLDW];
 #pragma unroll
-      for (int pi = 0; pi < NP; ++pi) stage_part(pi, st, sa, sb, rm, sbuf, sl, sw);
+      for (int pi = 0; pi < NP; ++pi) stage_part(pi, st, tm, sa, sb, rm, sbuf, sl, sw);
     };
     // micro-unit m of P(t) from the finished scores of tile t: MODE 0: 0..15 one register each, 16..23 one split3
     // each; MODE 1: the same after `prepare` fixed the reference point.
@@ -1627,7 +1658,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
 
     // step t: tile t's P planes in `pc`, tile t+2 in `st` registers; produces P(t+1) in `pn`, loads tile t+3 to `ld`
     auto step = [&](auto next_c, int64_t t, int k3, unsigned (&pc)[2][NPL][4], unsigned (&pn)[2][NPL][4],
-                    const float4 (&st)[NLDW], float st_l, float st_w_v, float4 (&ld)[NLDW], float& ld_l, float& ld_w) {
+                    const StagedRows<NLDW>& st, float st_l, float st_w_v, StagedRows<NLDW>& ld, float& ld_l, float& ld_w) {
       constexpr bool real_next = decltype(next_c)::value;    // false only for the split's last tile (compile time:
                                                              // no branch may sit between the MFMAs of a phase)
       load_tile(t + 3, ld, ld_l, ld_w);
@@ -1635,6 +1666,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
       const int slot1 = (k3 + 1) % RING, slot2 = (k3 + 2) % RING;
       unsigned char* rm_out = lds_rm[slot2];
       unsigned sa[NLDW][NPL], sb[NLDW][NPL];
+      float4 tm[NLDW];
       // phase A: S^T of tile t+1 || staging of tile t+2
       {
         const unsigned char* base = lds_rm[slot1] + i32 * S::ROWB + h * (S::KH * 2);
@@ -1659,7 +1691,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
             acc = E::mfma(ap[c & 1][E::ta(term)], bq[0][E::tb(term)][c], cin);
 #pragma unroll
             for (int pi = slot * NP / NS1; pi < (slot + 1) * NP / NS1; ++pi)
-              stage_part(pi, st, sa, sb, rm_out, slot2, st_l, st_w_v);
+              stage_part(pi, st, tm, sa, sb, rm_out, slot2, st_l, st_w_v);
             __builtin_amdgcn_sched_barrier(0);
           }
         }

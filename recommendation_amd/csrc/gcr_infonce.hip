@@ -1542,19 +1542,22 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
     auto prepare = [&](f32x16& acc, int64_t t) {        // masks (ragged tile / excluded diagonal); MODE 1: reference point
       const int64_t j0 = t * kTileJ;
       const int lim = (int)min((int64_t)kTileJ, ny - j0);   // rows of this tile that exist (wave-uniform)
-      // (MODE 0 never needs the end-of-array mask: rows behind the end are staged as zero rows — a finite P times zero —
-      // and carry w' = 0 or e = -1e30; under FOLD / FOLDX a score of -inf would turn into +inf when c is negative)
-      if (EXD || (lim < kTileJ && MODE == 1)) {
+      // (statistics on the streamed rows only, MODE 0 / SIDES 2: no end-of-array mask — rows behind the end carry w' = 0
+      // or e = -1e30, P = 0 whatever their score.  Everywhere else they need it: such a row is staged as a zero row, score
+      // 0, and against real scores that are all far below 0 its stationary-side "probability" e^{0 - lse_i} overflows
+      // the f16 planes — inf times the zero row.  Under FOLDX the masked score is -inf / c_x: +inf for a negative weight.)
+      if (EXD || (lim < kTileJ && !(MODE == 0 && SIDES == 2))) {
         // a real (scalar) branch: if-converted, the 16 selects with their compares would run for every tile
         if (!EXD) asm volatile("" ::: "memory");
         const int xr = EXD ? diag_offset(row_i, j0, h) : -1;
+        const float dead_score = FOLDX ? -INFINITY * sgn_x : -INFINITY;
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int r = 4 * g + e;
             const bool dead = (acc_row(r, h) >= lim) || (EXD && xr == e + 8 * g);
-            acc[r] = dead ? -INFINITY : acc[r];
+            acc[r] = dead ? dead_score : acc[r];
           }
       }
       if (MODE == 1) {

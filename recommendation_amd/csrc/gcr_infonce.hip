@@ -2221,16 +2221,39 @@ __global__ __launch_bounds__(256, 2) void kmeans_assign_b3_kernel(
   }
   const int64_t tiles = (k + kTileJ - 1) / kTileJ;
   const int64_t last = tiles - 1;
-  float4 regs[S::NLD];
-  float bias = 0.f;
-  auto load_tile = [&](int64_t t) {
+  // One centroid tile's share of a lane between its global loads and its LDS stores.  The loads are LOADS ONLY — the rows
+  // as they are (rows past k repeat the last centroid: their bias is -inf, they never win), ½|c|² as it is, from every
+  // lane without a branch — and a tile is loaded a whole step before it is staged.  (The bias used to be negated and
+  // selected on the spot inside `if (tid < 32)`, the rows multiplied by their 0/1 scale on the spot: every tile opened with
+  // `global_load ...; s_waitcnt vmcnt(0)` in wave 0, a memory round trip that the other three waves sat out at the
+  // barrier — half of the 1.9 us a tile took.)
+  struct Staged {
+    float4 v[S::NLD];
+    float hb;
+    bool live;
+  };
+  Staged ga, gb;
+  auto load_tile = [&](int64_t t, Staged& g) {
     const int64_t j0 = min(t, last) * kTileJ;
-    stage_load<D>(cent, nullptr, k, j0, tid, regs);
-    if (tid < kTileJ) bias = (j0 + tid < k) ? -half_sq[j0 + tid] : -INFINITY;   // rows past k never win
+#pragma unroll
+    for (int u = 0; u < S::NLD; ++u) {
+      const int idx = tid + 256 * u;
+      const int row = idx / (D / 4), c4 = idx % (D / 4);
+      const int64_t jj = min(j0 + row, k - 1);
+      g.v[u] = *reinterpret_cast<const float4*>(cent + jj * D + 4 * c4);
+    }
+    const int64_t jb = j0 + (tid & (kTileJ - 1));
+    g.hb = half_sq[min(jb, k - 1)];
+    g.live = jb < k;
+  };
+  auto store_tile = [&](unsigned char* out, int sbuf, const Staged& g) {
+#pragma unroll
+    for (int u = 0; u < S::NLD; ++u) stage_store_b3_one<D>(out, tid, g.v[u], u);
+    if (tid < kTileJ) st_bias[sbuf][tid] = g.live ? -g.hb : -INFINITY;          // rows past k never win
   };
   // one tile: scores of the tile in lds[buf] into `nxt` (C = bias), optionally interleaved with the
-  // arg-max over `cur` (the previous tile, number tt) and the staging of the tile held in `regs`
-  auto tile = [&](auto with_cur, const f32x16 (&cur)[S::NT], f32x16 (&nxt)[S::NT], int64_t tt, int buf) {
+  // arg-max over `cur` (the previous tile, number tt) and the staging of the tile held in `st`
+  auto tile = [&](auto with_cur, const f32x16 (&cur)[S::NT], f32x16 (&nxt)[S::NT], int64_t tt, int buf, const Staged& st) {
     constexpr bool CUR = decltype(with_cur)::value;
     const unsigned char* base = lds[buf] + i32 * S::ROWB + h * (S::KH * 2);
     unsigned char* out = lds[buf ^ 1];
@@ -2251,8 +2274,8 @@ __global__ __launch_bounds__(256, 2) void kmeans_assign_b3_kernel(
         best[t] = fmaxf(best[t], v);
       } else {
         const int u = m - 16 * S::NT;
-        stage_store_b3_one<D>(out, tid, regs[u], u);
-        if (u == 0 && tid < kTileJ) st_bias[buf ^ 1][tid] = bias;
+        stage_store_b3_one<D>(out, tid, st.v[u], u);
+        if (u == 0 && tid < kTileJ) st_bias[buf ^ 1][tid] = st.live ? -st.hb : -INFINITY;
       }
     };
     u32x4 ap[2][3];
@@ -2305,27 +2328,25 @@ __global__ __launch_bounds__(256, 2) void kmeans_assign_b3_kernel(
     }
   };
   f32x16 acc_a[S::NT], acc_b[S::NT];
-  load_tile(0);
-  stage_store_b3<D>(lds[0], tid, regs);
-  if (tid < kTileJ) st_bias[0][tid] = bias;
-  load_tile(1);
+  load_tile(0, ga);
+  load_tile(1, gb);
+  store_tile(lds[0], 0, ga);
+  load_tile(2, ga);
   __syncthreads();
-  tile(std::false_type{}, acc_b, acc_a, 0, 0);          // scores of tile 0; nothing to reduce yet
-  stage_store_b3<D>(lds[1], tid, regs);
-  if (tid < kTileJ) st_bias[1][tid] = bias;
+  tile(std::false_type{}, acc_b, acc_a, 0, 0, gb);      // scores of tile 0; nothing to reduce yet
+  store_tile(lds[1], 1, gb);
   __syncthreads();
   int64_t tt = 0;
-  for (; tt + 2 <= last; tt += 2) {
-    load_tile(tt + 2);
-    tile(std::true_type{}, acc_a, acc_b, tt, 1);
+  for (; tt + 2 <= last; tt += 2) {                     // step tt stages tile tt + 2 (loaded a step ago), loads tile tt + 3
+    load_tile(tt + 3, gb);
+    tile(std::true_type{}, acc_a, acc_b, tt, 1, ga);
     __syncthreads();
-    load_tile(tt + 3);
-    tile(std::true_type{}, acc_b, acc_a, tt + 1, 0);
+    load_tile(tt + 4, ga);
+    tile(std::true_type{}, acc_b, acc_a, tt + 1, 0, gb);
     __syncthreads();
   }
   if (tt < last) {
-    load_tile(tt + 2);
-    tile(std::true_type{}, acc_a, acc_b, tt, 1);
+    tile(std::true_type{}, acc_a, acc_b, tt, 1, ga);
     __syncthreads();
     argmax_only(acc_b, last);
   } else {

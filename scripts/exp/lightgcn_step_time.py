@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""bench.py's lightgcn_full_batch_step leg alone (cfg2, 10M edges): ms per step; --lib for library A/B."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from recommendation_amd import _lib
+if "--lib" in sys.argv:
+    _lib.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
+import bench
+import recommendation_amd as ra
+from recommendation_amd import functional as Fn
+from recommendation_amd.optim import FusedAdam
+dev = torch.device("cuda", 0)
+wl = bench.WORKLOADS["cfg2"]
+users, items = bench.synth_interactions_device(wl["users"], wl["items"], wl["edges"], bench.SEED, dev)
+n_u, n_i = wl["users"], wl["items"]
+graph = ra.CsrGraph.bipartite_sym_norm(users, items, n_u, n_i, dev)
+x0 = torch.empty(n_u + n_i, 64, device=dev)
+torch.nn.init.xavier_uniform_(x0, generator=torch.Generator(device=dev).manual_seed(0))
+xp = torch.nn.Parameter(x0.clone())
+opt = FusedAdam([xp], lr=1e-3)
+gen = torch.Generator(device=dev).manual_seed(1)
+rowptr_u = graph.rowptr[: n_u + 1].contiguous()
+items_u = (graph.col[: int(rowptr_u[-1])] - n_u).contiguous()
+eu = torch.repeat_interleave(torch.arange(n_u, device=dev), rowptr_u[1:] - rowptr_u[:-1])
+ei = items_u.to(torch.int64)
+
+
+def step():
+    neg = torch.randint(0, n_i, (eu.numel(),), device=dev, generator=gen)
+    final = Fn.lightgcn_propagate(graph, xp, wl["layers"], "sum")
+    ue, ie = Fn.split_rows(final, n_u)
+    s = Fn.bpr_sums(ue, ie, eu, ei, neg, Fn.BPR_LOG_SIGMOID)
+    loss = s[0] / eu.numel() + 1e-4 * (s[1] + s[2]) / eu.numel()
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+
+
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+for _ in range(3):
+    t0 = time.perf_counter()
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    print(f"lightgcn full-batch step: {(time.perf_counter() - t0) / 5 * 1e3:.3f} ms", flush=True)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised cross-check of the two operand formats of the split-operand InfoNCE kernels: every launch kind
 (forward with / without column sums / excluded diagonal, flash forward, backward with statistics on either or both
-sides, excluded diagonal) on random shapes, d in {32, 64}, 1/tau in [1, 60] — two f16 planes vs three bf16 planes,
+sides, excluded diagonal) on random shapes, d in {32, 64, 128}, 1/tau in [1, 60] — two f16 planes vs three bf16 planes,
 which must agree to a few f32 roundings.  usage: python scripts/stress_infonce_formats.py [n_cases [max 1/tau]]"""
 import os
 import sys
@@ -29,7 +29,7 @@ def run(n_cases=300, max_inv_tau=60.0, verbose=True):
 
 
     for case in range(n_cases):
-        d = int(rng.choice([32, 64]))
+        d = int(rng.choice([32, 64, 128]))
         m = int(rng.choice([rng.integers(1, 200), rng.integers(1, 1500), 128 * rng.integers(1, 12)]))
         n = int(rng.choice([rng.integers(1, 300), rng.integers(1, 6000), 32 * rng.integers(1, 40)]))
         inv_tau = float(rng.choice([t for t in (1.0, 2.0, 5.0, 10.0, 20.0, 40.0, 60.0) if t <= max_inv_tau]))

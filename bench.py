@@ -970,8 +970,7 @@ def bench_extra(ra, Fn, graph, x0, k_layers, nnz, dev, n_u, n_i):
     def lightgcn_step():
         neg = torch.randint(0, n_i, (eu.numel(),), device=dev, generator=gen)
         final = Fn.lightgcn_propagate(graph, xp, k_layers, "sum")
-        ue, ie = Fn.split_rows(final, n_u)
-        s = Fn.bpr_sums(ue, ie, eu, ei, neg, Fn.BPR_LOG_SIGMOID)
+        s = Fn.bpr_edge_sums(graph, final, n_u, neg, Fn.BPR_LOG_SIGMOID)       # (eu, ei) = the graph's own edge list
         loss = s[0] / eu.numel() + 1e-4 * (s[1] + s[2]) / eu.numel()
         opt.zero_grad()
         loss.backward()

@@ -159,6 +159,10 @@ int32_t gcr_bpr_bwd_f32(const float* user_tab, const float* item_tab, int32_t d,
  * sort last; n and n_keys < 2^31.  (keys_u, perm_u) = order of u_idx, (keys_i, perm_i) of i_idx,
  * (keys_j, perm_j) of the flattened j_idx [batch * n_neg]; orders of index arrays that do not change
  * between steps can be reused.  One row atomic per run of equal keys and 64-entry chunk.
+ * keys_i == perm_i == NULL (i_idx may then be NULL too): the POSITIVE-pair parts are left to the caller — grad_user gets
+ * only - coef * mean_k I[j_bk] (+ the |U[u]|^2 term), grad_item only the negatives' rows (+ the |I[j]|^2 term).  For a
+ * batch that is the training graph's own edge list those parts are one SpMM with per-edge coefficients on the graph's
+ * structure (functional.bpr_edge_sums: gcr_spmm_csr_f32 with val = dL/dx per edge), not two sorted scatters.
  */
 int64_t gcr_sort_index_workspace_bytes(int64_t n);
 int32_t gcr_sort_index(const int64_t* idx, int64_t n, int64_t n_keys, uint32_t* keys_sorted, int32_t* perm,
@@ -171,6 +175,16 @@ int32_t gcr_bpr_bwd_sorted_f32(const float* user_tab, const float* item_tab, int
                                const uint32_t* keys_i, const int32_t* perm_i,
                                const uint32_t* keys_j, const int32_t* perm_j,
                                float* grad_user, float* grad_item, void* stream);
+
+/*
+ * The per-non-zero values of that coefficient operator, for a symmetric bipartite CSR with the users first (2 * n_pairs
+ * non-zeros, the user rows' n_pairs first): val[e] = grad_sums[0] * dloss_dx[pair(e)], pair(e) = e in the user-major half,
+ * mirror[e] (the position of the transposed non-zero, CsrGraph.mirror_perm) in the item-major half; a NaN in dloss_dx (a
+ * sample the forward dropped) gives 0 and adds 1 to dropped_per_item[its positive item] (zero on entry).
+ */
+int32_t gcr_bpr_edge_values_f32(const float* dloss_dx, const int64_t* mirror, const int32_t* col, int64_t n_users,
+                                int64_t n_pairs, const float* grad_sums, float* val, float* dropped_per_item,
+                                void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Counter-based RNG (Philox-4x32-10): negative sampler and edge-dropout bitmaps.

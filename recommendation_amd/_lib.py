@@ -37,6 +37,7 @@ SIGNATURES = {
                                   _P, _P, _P, _P, _P]),
     "gcr_sort_index_workspace_bytes": (c_int64, [c_int64]),
     "gcr_sort_index": (c_int32, [_P, c_int64, c_int64, _P, _P, _P, _P]),
+    "gcr_bpr_edge_values_f32": (c_int32, [_P, _P, _P, c_int64, c_int64, _P, _P, _P, _P]),
     "gcr_bpr_bwd_sorted_f32": (c_int32, [_P, _P, c_int32, _P, _P, _P, c_int64, c_int32, c_int64, c_int64, _P, _P,
                                          _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gcr_neg_sample": (c_int32, [_P, _P, _P, c_int64, c_int32, c_int64, c_int64, c_uint64, c_uint64, c_int32, _P, _P]),

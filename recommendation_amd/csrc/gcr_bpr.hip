@@ -222,7 +222,9 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // SIDE 0: rows of grad_user keyed by u; 1: rows of grad_item keyed by the positive item; 2: keyed by the
 // negative item (entries are the batch * n_neg negative slots).  Same arithmetic as bpr_bwd_kernel.
-template <int SIDE, int NV, bool ONE_NEG>
+// POS = false (SIDE 0 only): the positive item's row is left out — the caller adds the positive-pair parts itself (for a
+// batch that IS the training graph's edge list they are an SpMM with per-edge coefficients: functional.bpr_edge_sums).
+template <int SIDE, int NV, bool ONE_NEG, bool POS = true>
 __global__ __launch_bounds__(256) void bpr_bwd_sorted_kernel(
     const float* __restrict__ user_tab, const float* __restrict__ item_tab, int d, const int64_t* __restrict__ u_idx,
     const int64_t* __restrict__ i_idx, const int64_t* __restrict__ j_idx, int64_t batch, int n_neg, int64_t n_users,
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(256) void bpr_bwd_sorted_kernel(
       const float g = g_loss * dl;
       my_coef = SIDE == 2 ? -g / (float)n_neg : g;
       if (SIDE == 0) {
-        my_i = ok ? i_idx[b] : 0;
+        if (POS) my_i = ok ? i_idx[b] : 0;
         if (ONE_NEG) my_j = ok ? j_idx[b] : 0;
       } else {
         my_u = ok ? u_idx[b] : 0;
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(256) void bpr_bwd_sorted_kernel(
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
           const int c = lane + 64 * v;
-          row[q][v] = c < d ? tab[src * d + c] : 0.f;
+          row[q][v] = (c < d && (POS || SIDE != 0)) ? tab[src * d + c] : 0.f;
         }
         if (SIDE == 0 && ONE_NEG) {
           const int64_t j = live ? lane64(my_j, e) : 0;
@@ -330,6 +332,24 @@ __global__ __launch_bounds__(256) void bpr_bwd_sorted_kernel(
       }
     }
     flush();
+  }
+}
+
+// Per-non-zero values of the coefficient operator of functional.bpr_edge_sums: val[e] = g * dL/dx of the pair that
+// non-zero e stands for — the pair itself in the user-major half [0, E), its mirror image in the item-major half
+// [E, 2E); a NaN (a sample that the forward dropped: an id out of range) counts 0 and is tallied per positive item.
+__global__ __launch_bounds__(256) void bpr_edge_values_kernel(const float* __restrict__ dloss_dx,
+                                                              const int64_t* __restrict__ mirror,
+                                                              const int32_t* __restrict__ col, int64_t n_users, int64_t e_pairs,
+                                                              const float* __restrict__ grad_sums, float* __restrict__ val,
+                                                              float* __restrict__ dropped_per_item) {
+  const float g = grad_sums[0];
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < 2 * e_pairs; e += (int64_t)gridDim.x * 256) {
+    const int64_t pair = e < e_pairs ? e : mirror[e];
+    const float dl = dloss_dx[pair];
+    const bool live = dl == dl;
+    val[e] = live ? g * dl : 0.f;
+    if (!live && e < e_pairs) atomicAdd(dropped_per_item + (col[e] - n_users), 1.0f);
   }
 }
 
@@ -421,8 +441,10 @@ extern "C" int32_t gcr_bpr_bwd_sorted_f32(const float* user_tab, const float* it
   GCR_CHECK_ARG(batch >= 0 && n_neg >= 1 && d >= 1 && d <= 256 && n_users >= 0 && n_items >= 0);
   GCR_CHECK_ARG(batch * n_neg < (1ll << 31));
   if (batch == 0) return GCR_OK;
-  GCR_CHECK_ARG(user_tab && item_tab && u_idx && i_idx && j_idx && dloss_dx && grad_sums && grad_user && grad_item);
-  GCR_CHECK_ARG(keys_u && perm_u && keys_i && perm_i && keys_j && perm_j);
+  GCR_CHECK_ARG(user_tab && item_tab && u_idx && j_idx && dloss_dx && grad_sums && grad_user && grad_item);
+  GCR_CHECK_ARG(keys_u && perm_u && keys_j && perm_j && (keys_i != nullptr) == (perm_i != nullptr));
+  const bool pos = keys_i != nullptr;                     // false: the caller adds the positive-pair parts (gcr.h)
+  GCR_CHECK_ARG(!pos || i_idx != nullptr);
   hipStream_t s = (hipStream_t)stream;
   auto blocks_for = [](int64_t n_entries) {
     const int64_t want = ((n_entries + 63) / 64 + 3) / 4;
@@ -437,15 +459,41 @@ extern "C" int32_t gcr_bpr_bwd_sorted_f32(const float* user_tab, const float* it
     hipLaunchKernelGGL((bpr_bwd_sorted_kernel<SIDE, NV, false>), dim3(blocks_for(NE)), dim3(256), 0, s, user_tab,      \
                        item_tab, d, u_idx, i_idx, j_idx, batch, n_neg, n_users, n_items, dloss_dx, grad_sums, KEYS,    \
                        PERM, NE, OUT)
+#define GCR_NEG0(NV)                                                                                                  \
+  if (n_neg == 1)                                                                                                     \
+    hipLaunchKernelGGL((bpr_bwd_sorted_kernel<0, NV, true, false>), dim3(blocks_for(batch)), dim3(256), 0, s, user_tab, \
+                       item_tab, d, u_idx, i_idx, j_idx, batch, n_neg, n_users, n_items, dloss_dx, grad_sums, keys_u, \
+                       perm_u, batch, grad_user);                                                                     \
+  else                                                                                                                \
+    hipLaunchKernelGGL((bpr_bwd_sorted_kernel<0, NV, false, false>), dim3(blocks_for(batch)), dim3(256), 0, s, user_tab, \
+                       item_tab, d, u_idx, i_idx, j_idx, batch, n_neg, n_users, n_items, dloss_dx, grad_sums, keys_u, \
+                       perm_u, batch, grad_user)
 #define GCR_ALL(NV)                                           \
-  GCR_SIDE(0, NV, keys_u, perm_u, batch, grad_user);          \
-  GCR_SIDE(1, NV, keys_i, perm_i, batch, grad_item);          \
+  if (pos) {                                                  \
+    GCR_SIDE(0, NV, keys_u, perm_u, batch, grad_user);        \
+    GCR_SIDE(1, NV, keys_i, perm_i, batch, grad_item);        \
+  } else {                                                    \
+    GCR_NEG0(NV);                                             \
+  }                                                           \
   GCR_SIDE(2, NV, keys_j, perm_j, batch * n_neg, grad_item)
   if (d <= 64) { GCR_ALL(1); }
   else if (d <= 128) { GCR_ALL(2); }
   else if (d <= 192) { GCR_ALL(3); }
   else { GCR_ALL(4); }
 #undef GCR_ALL
+#undef GCR_NEG0
 #undef GCR_SIDE
+  return GCR_LAUNCH_STATUS();
+}
+
+extern "C" int32_t gcr_bpr_edge_values_f32(const float* dloss_dx, const int64_t* mirror, const int32_t* col, int64_t n_users,
+                                           int64_t n_pairs, const float* grad_sums, float* val, float* dropped_per_item,
+                                           void* stream) {
+  GCR_CHECK_ARG(n_pairs >= 0 && n_users >= 0 && n_pairs < (1ll << 40));
+  if (n_pairs == 0) return GCR_OK;
+  GCR_CHECK_ARG(dloss_dx && mirror && col && grad_sums && val && dropped_per_item);
+  const int64_t want = (2 * n_pairs + 255) / 256;
+  hipLaunchKernelGGL(bpr_edge_values_kernel, dim3((unsigned)(want > 65536 ? 65536 : want)), dim3(256), 0, (hipStream_t)stream,
+                     dloss_dx, mirror, col, n_users, n_pairs, grad_sums, val, dropped_per_item);
   return GCR_LAUNCH_STATUS();
 }

@@ -448,6 +448,89 @@ class _BprSums(torch.autograd.Function):
         return gu, gi, None, None, None, None
 
 
+class _BprEdgeSums(torch.autograd.Function):
+    """`bpr_sums` for the batch that IS the training graph's edge list (lightgcn.py:91-118 trains on every edge at once).
+    Same forward launch; in the backward the positive-pair parts of both gradients,
+        dU[u] += sum_{i in N(u)} c_ui I[i],   dI[i] += sum_{u in N(i)} c_ui U[u],   c_ui = dL/dx of the pair (u, i),
+    are ONE launch of the SpMM kernel on the graph's own structure with the coefficients as values (the item-major half
+    through `CsrGraph.mirror_perm`) instead of two sorted scatters over E samples; the negatives keep their sorted scatter."""
+
+    @staticmethod
+    def forward(ctx, table, graph, n_users, j_idx, variant):
+        L = _lib.lib()
+        table = table.contiguous()
+        n_items = table.shape[0] - n_users
+        u_idx, i_idx = graph.user_major_edges(n_users)
+        batch = u_idx.numel()
+        n_neg = 1 if j_idx.dim() == 1 else j_idx.shape[1]
+        d = table.shape[1]
+        dev = table.device
+        user_tab, item_tab = table[:n_users], table[n_users:]
+        dldx = torch.empty(max(batch, 1), dtype=torch.float32, device=dev)
+        sums = torch.zeros(5, dtype=torch.float32, device=dev)
+        ws = torch.empty(int(L.gcr_bpr_workspace_floats(batch)), dtype=torch.float32, device=dev)
+        _lib.check(L.gcr_bpr_fwd_f32(_lib.dptr(user_tab), _lib.dptr(item_tab), d, _lib.dptr(u_idx), _lib.dptr(i_idx),
+                                     _lib.dptr(j_idx), batch, n_neg, variant, n_users, n_items, _lib.dptr(dldx),
+                                     _lib.dptr(sums), _lib.dptr(ws), _lib.cur_stream(dev)), "gcr_bpr_fwd_f32")
+        ctx.save_for_backward(table, j_idx, dldx)
+        ctx.graph, ctx.n_users, ctx.n_neg = graph, n_users, n_neg
+        ctx.mark_non_differentiable(j_idx)
+        return sums
+
+    @staticmethod
+    def backward(ctx, g_sums):
+        table, j_idx, dldx = ctx.saved_tensors
+        graph, n_users = ctx.graph, ctx.n_users
+        n_items = table.shape[0] - n_users
+        gs = g_sums.contiguous().to(torch.float32)
+        u_idx, i_idx = graph.user_major_edges(n_users)
+        batch = u_idx.numel()
+        # positive pairs: G = C_sym [U; I], C_sym = the graph's pattern with c_ui at (u, i) and (i, u)
+        val = torch.empty(2 * batch, dtype=torch.float32, device=table.device)
+        dropped = torch.zeros(n_items, dtype=torch.float32, device=table.device)   # samples the forward dropped, per positive item
+        _lib.check(_lib.lib().gcr_bpr_edge_values_f32(_lib.dptr(dldx), _lib.dptr(graph.mirror_perm()), _lib.dptr(graph.col),
+                                                      n_users, batch, _lib.dptr(gs), _lib.dptr(val), _lib.dptr(dropped),
+                                                      _lib.cur_stream(table.device)), "gcr_bpr_edge_values_f32")
+        gfull = torch.empty_like(table)
+        spmm_into(graph.with_values(val), table, y=gfull)
+        gu, gi = gfull[:n_users], gfull[n_users:]
+        # ... and the |I[i]|^2 term of the positives: 2 g_2 (number of live samples with item i) I[i]  (the users' |U[u]|^2
+        # term rides in the launch below, which walks the samples user by user)
+        live = graph.row_degrees()[n_users:] - dropped
+        gi.addcmul_(table[n_users:], (2.0 * gs[2] * live).unsqueeze(1))
+        # negatives (fresh every step: one sort) and the users' side of them
+        ku, pu, _ = _sorted_order(u_idx, n_users, cache=True)
+        kj, pj, _ = _sorted_order(j_idx.reshape(-1), n_items)
+        _lib.check(_lib.lib().gcr_bpr_bwd_sorted_f32(
+            _lib.dptr(table[:n_users]), _lib.dptr(table[n_users:]), table.shape[1], _lib.dptr(u_idx), None,
+            _lib.dptr(j_idx), batch, ctx.n_neg, n_users, n_items, _lib.dptr(dldx), _lib.dptr(gs), _lib.dptr(ku),
+            _lib.dptr(pu), None, None, _lib.dptr(kj), _lib.dptr(pj), _lib.dptr(gu), _lib.dptr(gi),
+            _lib.cur_stream(table.device)), "gcr_bpr_bwd_sorted_f32")
+        return gfull, None, None, None, None
+
+
+def bpr_edge_sums(graph, table, n_users, j_idx, variant=BPR_LOG_SIGMOID):
+    """`bpr_sums(table[:U], table[U:], u_idx, i_idx, j_idx, variant)` for (u_idx, i_idx) = the non-zeros of the user rows
+    of `graph` in CSR order (`graph.user_major_edges`), i.e. a full batch over the training edges the graph was built from
+    (lightgcn.py:91-118).  `table`: the stacked [U + I, d] encoder output; j_idx: [E] or [E, n_neg] negatives in that
+    order.  Same sums, same gradients (the sums in another order: ~1e-6 relative); the backward's positive-pair parts are
+    one SpMM launch.  The graph must be a symmetric bipartite operator with the users first."""
+    _lib.require_cuda(table)
+    if not graph.symmetric:
+        raise ValueError("bpr_edge_sums needs a symmetric bipartite operator (users first)")
+    if table.dtype != torch.float32 or table.dim() != 2 or table.shape[0] != graph.n_rows:
+        raise ValueError("table must be float32 [n_rows, d]")
+    j_idx = _as_index(j_idx, table.device)
+    e = graph.user_major_edges(n_users)[0].numel()
+    if j_idx.shape[0] != e or j_idx.dim() > 2:
+        raise ValueError("j_idx: [E] or [E, n_neg] with E = the number of training edges")
+    if e < BPR_SORTED_MIN_BATCH or e * (1 if j_idx.dim() == 1 else j_idx.shape[1]) >= 2 ** 31:
+        u_idx, i_idx = graph.user_major_edges(n_users)
+        ue, ie = split_rows(table, n_users)
+        return bpr_sums(ue, ie, u_idx, i_idx, j_idx, variant)
+    return _BprEdgeSums.apply(table, graph, int(n_users), j_idx, int(variant))
+
+
 def bpr_sums(user_tab, item_tab, u_idx, i_idx, j_idx, variant=BPR_NCL):
     """Fused gather + BPR + squared norms.  Returns a differentiable float32[5]:
     [sum_b loss_b, sum_b |U[u_b]|^2, sum_b |I[i_b]|^2, sum_bk |I[j_bk]|^2, #samples with a bad id].

@@ -133,6 +133,42 @@ class CsrGraph:
                                nnz_per_part=self.plan.nnz_per_part, validate=False, transpose=self)
         return self._t
 
+    def row_degrees(self):
+        """Non-zeros per row, float32 [n_rows] (cached)."""
+        dg = getattr(self, "_row_deg", None)
+        if dg is None:
+            dg = (self.rowptr[1:] - self.rowptr[:-1]).to(torch.float32)
+            self._row_deg = dg
+        return dg
+
+    def with_values(self, val):
+        """A view of this operator with other per-non-zero values (float32 [nnz], same order): structure, work plan and
+        workspace are shared, nothing is copied — e.g. the per-edge coefficients of `functional.bpr_edge_sums`."""
+        import copy
+        if val.shape != self.val.shape or val.dtype != torch.float32 or val.device != self.val.device:
+            raise ValueError("val must be float32 [nnz] on the graph's device")
+        g = copy.copy(self)
+        g.val = val.contiguous()
+        g._t = None
+        return g
+
+    def user_major_edges(self, n_users):
+        """Bipartite symmetric operators ([U + I] x [U + I], users first; `bipartite_sym_norm`, `from_edge_index_gcn_norm`
+        of lightgcn.py:36-39's edge_index): (u_idx, i_idx) int64 [E] of the non-zeros of the user rows in CSR order — the
+        training pairs when the graph was built from them — cached."""
+        c = getattr(self, "_um_edges", None)
+        if c is None or c[0] != int(n_users):
+            n_users = int(n_users)
+            rp = self.rowptr[: n_users + 1]
+            e = int(rp[-1])
+            if 2 * e != self.nnz:
+                raise ValueError("not a symmetric bipartite operator with the users first: nnz != 2 * nnz(user rows)")
+            u = torch.repeat_interleave(torch.arange(n_users, device=self.device), rp[1:] - rp[:-1])
+            i = self.col[:e].to(torch.int64) - n_users
+            c = (n_users, u, i)
+            self._um_edges = c
+        return c[1], c[2]
+
     def mirror_perm(self):
         """Symmetric operators only: int64 [nnz], mirror[e] = position of the non-zero (c, r) for the non-zero
         e = (r, c) — the nnz -> transpose-nnz map that lets a per-non-zero edge mask be handed to the

@@ -277,3 +277,40 @@ def test_bpr_on_split_table_writes_one_gradient_buffer():
     assert torch.equal(sums.detach(), ref.detach())
     want = torch.cat([ut.grad, it.grad])
     assert float((s1.grad - want).abs().max()) <= 1e-6 * float(want.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_neg,variant,d", [(1, 2, 64), (3, 2, 64), (1, 0, 32)])
+def test_full_batch_over_the_graphs_edges_equals_the_sampled_form(Fn, n_neg, variant, d):
+    """functional.bpr_edge_sums — the full batch of lightgcn.py:91-118 over the training graph's own edge list, backward's
+    positive-pair parts as ONE SpMM with per-edge coefficients — against bpr_sums on the same (u, i, j) triples: same
+    sums, gradients of both tables equal to 2e-5 of their largest entry.  Duplicate interactions (kept by the raw
+    multigraph), isolated users / items, n_neg = 1 / 3, a negative id out of range."""
+    import recommendation_amd as ra
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(17 + n_neg)
+    n_u, n_i, e = 20_000, 5_000, 300_000
+    u = torch.randint(0, n_u - 50, (e,), device=dev, generator=g)            # the last 50 users have no interaction
+    i = torch.randint(0, n_i - 20, (e,), device=dev, generator=g)
+    u[:100], i[:100] = u[100:200], i[100:200]                                # 100 duplicate pairs
+    rows = torch.cat([u, i + n_u])
+    cols = torch.cat([i + n_u, u])
+    graph = ra.CsrGraph.from_coo(rows, cols, torch.ones(2 * e, device=dev), n_u + n_i, n_u + n_i, dev, symmetric=True)
+    uu, ii = graph.user_major_edges(n_u)
+    assert uu.numel() == e
+    shape = (e,) if n_neg == 1 else (e, n_neg)
+    j = torch.randint(0, n_i, shape, device=dev, generator=g)
+    j.view(-1)[7] = n_i + 3                                                  # out of range: that sample drops out
+    tab_a = (torch.randn(n_u + n_i, d, device=dev, generator=g) * 0.3).requires_grad_()
+    tab_b = tab_a.detach().clone().requires_grad_()
+    w = torch.tensor([1.0 / e, 1e-4, 2e-4, 3e-4, 0.0], device=dev)
+    sa = Fn.bpr_edge_sums(graph, tab_a, n_u, j, variant)
+    ub, ib = Fn.split_rows(tab_b, n_u)
+    sb = Fn.bpr_sums(ub, ib, uu, ii, j, variant)
+    assert torch.equal(sa, sb)
+    (sa * w).sum().backward()
+    (sb * w).sum().backward()
+    ga, gb = tab_a.grad, tab_b.grad
+    assert float((ga[:n_u] - gb[:n_u]).abs().max()) <= 2e-5 * float(gb[:n_u].abs().max())
+    assert float((ga[n_u:] - gb[n_u:]).abs().max()) <= 2e-5 * float(gb[n_u:].abs().max())
+    assert float(ga[n_u - 50:n_u].abs().max()) == 0.0                        # users without an interaction

@@ -436,17 +436,18 @@ struct StagedRows {
 template <int D, int THREADS>
 __device__ __forceinline__ void stage_load_t(const float* __restrict__ b, const float* __restrict__ b_scale, int64_t n_rows,
                                              int64_t j0, int tid, StagedRows<(kTileJ * D / 4) / THREADS>& g) {
-  const float* __restrict__ sp = b_scale != nullptr ? b_scale : b;               // wave-uniform
-  const int64_t stride = b_scale != nullptr ? 1 : 0;
+  const float* __restrict__ sp = b_scale != nullptr ? b_scale + j0 : b;          // wave-uniform bases + small 32-bit lane offsets
+  const float* __restrict__ tb = b + j0 * D;
+  const unsigned stride = b_scale != nullptr ? 1u : 0u;
+  const int rem = (int)min((int64_t)kTileJ, n_rows - j0);  // rows of this tile that exist (>= 1)
 #pragma unroll
   for (int u = 0; u < (kTileJ * D / 4) / THREADS; ++u) {
     const int idx = tid + THREADS * u;
     const int row = idx / (D / 4), c4 = idx % (D / 4);
-    const int64_t j = j0 + row;
-    const int64_t jj = j < n_rows ? j : n_rows - 1;
-    g.v[u] = *reinterpret_cast<const float4*>(b + jj * D + 4 * c4);
-    g.s[u] = sp[jj * stride];
-    g.live[u] = j < n_rows;                                  // rows behind the end: scale 0, applied with the multiply
+    const unsigned rr = (unsigned)min(row, rem - 1) & (kTileJ - 1);   // rows behind the end repeat the last one ...
+    g.v[u] = *reinterpret_cast<const float4*>(tb + (rr * D + 4u * c4));
+    g.s[u] = sp[rr * stride];
+    g.live[u] = row < rem;                                   // ... with scale 0, applied with the multiply
   }
 }
 
@@ -1488,11 +1489,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
       for (int u = 0; u < NLDW; ++u) {
         const int idx = min(tid + THREADS * u, F4T - 1);     // (more threads than float4s: the surplus reloads the last one)
         const int row = idx / (D / 4), c4 = idx % (D / 4);
-        const int rr = min(row, rem - 1);
+        const unsigned rr = (unsigned)min(row, rem - 1) & (kTileJ - 1);   // (masked: a provably small offset folds into the load)
         // loads only: the scale is multiplied in where the row is staged, two steps from here (doing it on the spot put
         // a `s_waitcnt vmcnt(0)` behind the loads — a memory round trip in front of every step's first MFMA)
-        r.v[u] = *reinterpret_cast<const float4*>(tb + rr * D + 4 * c4);
-        r.s[u] = sp[rr * sstride];
+        r.v[u] = *reinterpret_cast<const float4*>(tb + (rr * D + 4u * c4));   // uniform base + 32-bit lane offset
+        r.s[u] = sp[rr * (unsigned)sstride];
         r.live[u] = row < rem;
       }
       if (MODE == 0 && tid < kTileJ) {

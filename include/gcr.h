@@ -335,6 +335,35 @@ int32_t gcr_normalize_bwd_f32(const float* x, const float* inv_norm, const float
                               float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * BCE-with-logits over the all-pairs score matrix — the `loss_type == "bce"` branch of LightGCN's training step:
+ *   scores = torch.matmul(user_vecs, item_emb.t()); labels = one-hot at pos_i;                 lightgcn.py:110-112
+ *   loss = F.binary_cross_entropy_with_logits(scores, labels)                                  lightgcn.py:113
+ *        = ( sum_ij softplus(s_ij) - sum_i s_{i, pos_i} ) / (M N),   s_ij = <a_i, b_j>  (no temperature, rows NOT normalised).
+ * The M x N part never reaches memory: row sums of softplus in the forward, sigmoid-weighted operand sums in the
+ * backward, on the InfoNCE tile engine (three bf16 planes for d <= 64; the f32 MFMA for d = 128 / 256 or with
+ * GCR_INFONCE_ENGINE_F32 in the flags).  d in {32, 64, 128, 256}.  The O(M d) positive-logit term is
+ * gcr_pos_logit_f32 / gcr_infonce_pos_bwd_f32 (or one SpMM when the batch is the graph's edge list).
+ * --------------------------------------------------------------------------------------------- */
+/* 1 when gcr_bce_fwd_f32 can also return o (d <= 64 on the split-operand engine) */
+int32_t gcr_bce_fwd_o_supported(int32_t d, uint32_t flags);
+int64_t gcr_bce_fwd_workspace_bytes(int64_t m, int64_t n, int32_t d);
+/*
+ * row_softplus[i] = sum_j softplus(<a_i, b_j>)                                   [m]
+ * o[i, :]         = sum_j sigmoid(<a_i, b_j>) * b_j      (optional, NULL to skip)  [m, d]
+ * — with o the gradient w.r.t. a_i of sum_i c_i row_softplus[i] is c_i * o[i, :]: no backward launch for that side.
+ */
+int32_t gcr_bce_fwd_f32(const float* a, int64_t m, const float* b, int64_t n, int32_t d, float* row_softplus,
+                        float* o, void* workspace, uint32_t flags, void* stream);
+int64_t gcr_bce_bwd_workspace_bytes(int64_t mx, int64_t ny, int32_t d);
+/*
+ * g[i, :] = sum_j (w_x[i] + w_y[j]) * sigmoid(<x_i, y_j>) * y_j — the gradient of sum over pairs of w * softplus(s)
+ * w.r.t. x_i, the weight sitting on the stationary rows (w_x, [mx]) or on the streamed rows (w_y, [ny]): exactly one
+ * of the two is given, the other NULL.  Scores are recomputed, never stored.
+ */
+int32_t gcr_bce_bwd_f32(const float* x, int64_t mx, const float* y, int64_t ny, int32_t d, const float* w_x,
+                        const float* w_y, float* g, void* workspace, uint32_t flags, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * k-means E-step of NCL's prototype contrast (ncl.py:340-356: faiss.Kmeans(d, k).train(x) +
  * index.search(x, 1); faiss itself is an un-vendored dependency, not installed: what is restated is its published
  * Clustering::train loop — Lloyd iterations + split_clusters for empty clusters; PARITY WITH FAISS UNPINNED).

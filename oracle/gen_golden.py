@@ -12,8 +12,10 @@ How each reference function is reached:
     ModuleNotFoundError; both packages stay absent).  Their loss functions do not use either
     package, so the named FunctionDef nodes are taken out of the reference file with `ast` at
     run time and executed unchanged against torch — no stand-in libraries, no source copied;
-  * lightgcn.py needs torch_geometric (absent): its loss block lightgcn.py:95-118 is a handful
-    of tensor expressions restated inline below; LGConv itself stays "parity unpinned".
+  * lightgcn.py needs torch_geometric (absent) and its loss block lives in the body of the epoch loop
+    (lightgcn.py:95-118), like gcl.py's (gcl.py:216-223): `load_stmts` takes that range of statements out of
+    the enclosing function's AST and executes them unchanged in a namespace holding the fixture's tensors
+    (nothing re-typed); LGConv itself stays "parity unpinned".
 
 Usage:  python oracle/gen_golden.py   (writes tests/golden/)
 """
@@ -47,6 +49,43 @@ def load_defs(path, names, methods=()):
     ns = {"torch": torch, "F": F, "nn": torch.nn, "np": np, "device": torch.device("cpu")}
     exec(compile(ast.Module(body=wanted, type_ignores=[]), path, "exec"), ns)
     return ns
+
+
+def load_stmts(path, func, first, last):
+    """Code object of the statements of top-level function (or `Class.method`) `func` in a reference file that lie in
+    the line range [first, last] — a slice of ONE statement list, however deeply nested in loops / try / with blocks
+    (the loss blocks of lightgcn.py / gcl.py are bodies of training loops).  Executed unchanged with `exec(code, ns)`."""
+    tree = ast.parse(open(path).read())
+    target = None
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name == func:
+            target = node
+        if isinstance(node, ast.ClassDef):
+            for sub in node.body:
+                if isinstance(sub, ast.FunctionDef) and f"{node.name}.{sub.name}" == func:
+                    target = sub
+    if target is None:
+        raise KeyError(f"{func} not found in {path}")
+
+    def find(body):
+        inside = [st for st in body if st.lineno >= first and st.end_lineno <= last]
+        if inside and inside[0].lineno == first and inside[-1].end_lineno == last:
+            return inside
+        for st in body:
+            if st.lineno <= first and st.end_lineno >= last:
+                for field in ("body", "orelse", "finalbody", "handlers"):
+                    sub = getattr(st, field, None)
+                    if sub:
+                        got = find([h for h in sub if isinstance(h, ast.stmt)] +
+                                   [x for h in sub if isinstance(h, ast.ExceptHandler) for x in h.body])
+                        if got:
+                            return got
+        return None
+
+    stmts = find(target.body)
+    if not stmts:
+        raise KeyError(f"{path}:{first}-{last} is not a run of whole statements of one block of {func}")
+    return compile(ast.Module(body=stmts, type_ignores=[]), f"{path}:{first}-{last}", "exec")
 
 
 def seeded_triples(rng, n_users, n_items, n_inter, n_dup):
@@ -225,27 +264,38 @@ def main():
     run(lambda a, b, nj: ncl["l2_reg_loss"](1e-4, a[ui], b[pi], b[nj]), "ncl_l2reg", ni1)  # ncl.py:122-123
     out["directau_l2reg_loss"] = directau.l2_reg_loss(1e-4, ut[ui], it[pi], it[ni1]).item()
 
-    def lightgcn_block(a, b, nj, reg_weight=1e-4):
-        # lightgcn.py:95-108,118 restated inline (module needs torch_geometric): bpr + reg
-        uv, pv = a[ui], b[pi]
-        nv = b[nj]
-        if nj.dim() == 1:
-            ns_ = (uv * nv).sum(dim=-1)
-        else:
-            ns_ = (uv.unsqueeze(1) * nv).sum(dim=-1).mean(dim=1)
-        ps_ = (uv * pv).sum(dim=-1)
-        loss = -torch.log(torch.sigmoid(ps_ - ns_)).mean()
-        return loss + reg_weight * (uv.norm(2).pow(2) + pv.norm(2).pow(2))
+    # lightgcn.py:95-118 (gathers, BPR / BCE branch, regulariser): the statements of train_model's epoch loop, lifted
+    lgcn_code = load_stmts(os.path.join(REF, "lightgcn.py"), "train_model", 95, 118)
 
-    run(lightgcn_block, "lgcn_block_n1", ni1)
-    run(lightgcn_block, "lgcn_block_n3", ni3)
+    def lightgcn_block(loss_type):
+        def fn(a, b, nj, reg_weight=1e-4):
+            ns_ = {"torch": torch, "F": F, "user_emb": a, "item_emb": b, "pos_u": ui, "pos_i": pi, "neg_i": nj,
+                   "config": {"n_neg": 1 if nj.dim() == 1 else nj.shape[1], "loss_type": loss_type, "reg_weight": reg_weight}}
+            exec(lgcn_code, ns_)
+            return ns_["loss"]
+        return fn
+
+    run(lightgcn_block("bpr"), "lgcn_block_n1", ni1)
+    run(lightgcn_block("bpr"), "lgcn_block_n3", ni3)
+    # loss_type == "bce" (lightgcn.py:109-113): all-pairs scores [B, I], one-hot labels, BCE-with-logits + the regulariser
+    run(lightgcn_block("bce"), "lgcn_bce", ni1)
+    # ... the same block at the magnitudes of TRAINED embeddings (scores of several units, both signs) and with
+    # repeated (user, item) pairs in the batch
+    ut_w, it_w = ut.clone(), it.clone()
+    ut, it = ut_w * 4.0, it_w * 3.0
+    out.update(user_tab_big=ut.numpy(), item_tab_big=it.numpy())
+    run(lightgcn_block("bce"), "lgcn_bce_big", ni1)
+    ut, it = ut_w, it_w
+
+    # gcl.py:216-223 (gathers, BPR, regulariser, total) lifted from the batch loop of GCLTuner.run; the contrast term
+    # of :223 enters as a zero (it has its own fixtures)
+    gcl_code = load_stmts(os.path.join(REF, "gcl.py"), "GCLTuner.run", 216, 223)
 
     def gcl_block(a, b, nj, reg_weight=1e-4):
-        # gcl.py:216-223 (bpr + reg part) restated inline: it lives inside the tuner loop body
-        u_e, p_e, n_e = a[ui], b[pi], b[nj]
-        bpr = -F.logsigmoid((u_e * p_e).sum(1) - (u_e * n_e).sum(1)).mean()
-        reg = (u_e.norm(2).pow(2) + p_e.norm(2).pow(2) + n_e.norm(2).pow(2)) / len(ui)
-        return bpr + reg_weight * reg
+        ns_ = {"torch": torch, "F": F, "device": torch.device("cpu"), "user_z1": a, "item_z1": b, "users": ui,
+               "pos_items": pi, "neg_items": nj, "ssl_loss": torch.zeros(()), "config": {"reg_weight": reg_weight}}
+        exec(gcl_code, ns_)
+        return ns_["total_loss"]
 
     run(gcl_block, "gcl_block", ni1)
     np.savez_compressed(os.path.join(OUT, "bpr.npz"), **out)
@@ -604,6 +654,9 @@ def gen_featmask():
 
 
 if __name__ == "__main__":
+    if "--out" in sys.argv:                        # write somewhere else (e.g. to diff a regeneration against tests/golden)
+        OUT = sys.argv[sys.argv.index("--out") + 1]
+        os.makedirs(OUT, exist_ok=True)
     if "--featmask" in sys.argv:
         gen_featmask()
     elif "--mhcn" in sys.argv:

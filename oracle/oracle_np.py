@@ -413,6 +413,33 @@ def bpr_grads(user_tab, item_tab, u_idx, i_idx, j_idx, variant=BPR_NCL):
     return gu, gi
 
 
+def bce_rows(a, b):
+    """(row sums of softplus(a b^T) [M], sigmoid(a b^T) [M, N]) in float64 — the all-pairs part of lightgcn.py:110-113."""
+    s = np.asarray(a, F64) @ np.asarray(b, F64).T
+    return np.logaddexp(0.0, s).sum(1), 0.5 * (1.0 + np.tanh(0.5 * s))
+
+
+def lightgcn_bce_loss(user_tab, item_tab, u_idx, i_idx, reg_weight=0.0):
+    """lightgcn.py:95-96,109-118 with loss_type == "bce": scores = user_emb[pos_u] @ item_emb.T ([B, I]), labels one-hot at
+    pos_i, F.binary_cross_entropy_with_logits (mean over B * I: softplus(s) - y s) + reg_weight (|u|^2 + |p|^2).
+    Returns (loss, d loss / d user_tab, d loss / d item_tab)."""
+    ut, it = np.asarray(user_tab, F64), np.asarray(item_tab, F64)
+    u, i = np.asarray(u_idx), np.asarray(i_idx)
+    bsz, n_items = u.size, it.shape[0]
+    loss = 0.0
+    gu, gi = np.zeros_like(ut), np.zeros_like(it)
+    for lo in range(0, bsz, 8192):                      # the [B, I] matrix of the reference, a slab of rows at a time
+        uc, ic = u[lo:lo + 8192], i[lo:lo + 8192]
+        uv = ut[uc]
+        rows, sig = bce_rows(uv, it)
+        loss += rows.sum() - (uv * it[ic]).sum() + reg_weight * bsz * n_items * ((uv ** 2).sum() + (it[ic] ** 2).sum())
+        sig[np.arange(uc.size), ic] -= 1.0
+        gi += sig.T @ uv / (bsz * n_items)
+        np.add.at(gu, uc, sig @ it / (bsz * n_items) + 2.0 * reg_weight * uv)
+        np.add.at(gi, ic, 2.0 * reg_weight * it[ic])
+    return loss / (bsz * n_items), gu, gi
+
+
 # --------------------------------------------------------------------------
 # counter-based RNG: negative sampler (N1) and edge masks (A1)
 # --------------------------------------------------------------------------

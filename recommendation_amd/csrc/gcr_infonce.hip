@@ -144,6 +144,36 @@ __device__ __forceinline__ void lse_update(const f32x16 (&acc)[NT], int rem, flo
   }
 }
 
+// log2-domain pieces of the BCE-with-logits element (lightgcn.py:109-113): for the log2-domain score s2 = s log2 e
+//   softplus(s) = ln2 * (max(s2, 0) + log2(1 + u)),  sigmoid(s) = s2 >= 0 ? 1 / (1 + u) : u / (1 + u),  u = 2^-|s2|.
+// log2(1 + u) is compensated for the rounding of v = 1 + u (e = u - (v - 1) exactly; + e log2e / v), so a strongly
+// negative score keeps its ~2^s2 instead of 0.  A masked score (-inf) gives softplus = 0 and sigmoid = 0.
+__device__ __forceinline__ void bce_terms(float s2, float& softplus2, float& sig) {
+  const float u = __builtin_amdgcn_exp2f(-fabsf(s2));
+  const float v = 1.0f + u;
+  const float rc = __builtin_amdgcn_rcpf(v);
+  const float e = u - (v - 1.0f);
+  softplus2 = fmaxf(s2, 0.f) + fmaf(e * rc, kLog2e, __builtin_amdgcn_logf(v));
+  sig = s2 >= 0.f ? rc : u * rc;
+}
+
+// BCE forward on the f32 engine: l_run += sum over the tile's live rows of softplus2
+template <int NT, bool MASK>
+__device__ __forceinline__ void bce_update(const f32x16 (&acc)[NT], int rem, float (&l_run)[NT]) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rc = (r & 3) + 8 * (r >> 2);
+      float sp, sg;
+      bce_terms((!MASK || rc < rem) ? acc[t][r] : -INFINITY, sp, sg);
+      sum += sp;
+    }
+    l_run[t] += sum;
+  }
+}
+
 // in-tile offset of table row `i` for lane half h of the tile starting at j0 (matches (r&3)+8(r>>2) of
 // the register that holds it), or -1 when the row is not one of this lane's 16
 __device__ __forceinline__ int diag_offset(int64_t i, int64_t j0, int h) {
@@ -177,7 +207,7 @@ __device__ __forceinline__ float half_wave_sum_to_last_lane(float v) {
   return v;
 }
 
-template <int D, bool COLSUM, bool EXD = false>
+template <int D, bool COLSUM, bool EXD = false, bool BCE = false>
 __global__ __launch_bounds__(256, (D <= 64 ? 3 : 2)) void infonce_fwd_kernel(const float* __restrict__ a,
                                                              const float* __restrict__ a_scale, int64_t m_rows,
                                                              const float* __restrict__ b,
@@ -221,7 +251,12 @@ __global__ __launch_bounds__(256, (D <= 64 ? 3 : 2)) void infonce_fwd_kernel(con
     stage_load<D>(b, b_scale, n_rows, nxt * kTileJ, tid, regs);
     f32x16 acc[S::NT];
     score_tile<D>(lds[cur], i32, h, bfrag, acc);
-    if (EXD) {                                      // diagonal pair (i, j = i) left out of the sums
+    if (BCE) {                                      // sum of softplus instead of the online logsumexp
+      if ((tt + 1) * kTileJ > n_rows)
+        bce_update<S::NT, true>(acc, rows_left(n_rows, tt * kTileJ, h), l_run);
+      else
+        bce_update<S::NT, false>(acc, 64, l_run);
+    } else if (EXD) {                               // diagonal pair (i, j = i) left out of the sums
       int xr[S::NT];
 #pragma unroll
       for (int t = 0; t < S::NT; ++t) xr[t] = diag_offset(i0 + 32 * t + i32, tt * kTileJ, h);
@@ -252,7 +287,7 @@ __global__ __launch_bounds__(256, (D <= 64 ? 3 : 2)) void infonce_fwd_kernel(con
     const float m = fmaxf(m_run[t], m_o);
     const float l = l_run[t] * __builtin_amdgcn_exp2f(m_run[t] - m) + l_o * __builtin_amdgcn_exp2f(m_o - m);
     const int64_t row = i0 + 32 * t + i32;
-    if (h == 0 && row < m_rows) part[(int64_t)split * m_rows + row] = make_float2(m, l);
+    if (h == 0 && row < m_rows) part[(int64_t)split * m_rows + row] = BCE ? make_float2(0.f, l_run[t] + l_o) : make_float2(m, l);
   }
 }
 
@@ -831,7 +866,7 @@ struct BwdShape {
   static constexpr int ROWS_PER_BLOCK = 4 * 32 * NT;
 };
 
-template <int D, bool EXD = false>
+template <int D, bool EXD = false, bool BCE = false>
 __global__ __launch_bounds__(256, 2) void infonce_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ x_scale, int64_t mx, const float* __restrict__ y,
     const float* __restrict__ y_scale, int64_t ny, float scale2, float out_scale, const float* __restrict__ lse_x,
@@ -856,7 +891,7 @@ __global__ __launch_bounds__(256, 2) void infonce_bwd_kernel(
     load_stationary<D>(x, x_scale, mx, row, h, scale2, bfrag[t]);
     const bool on = row < mx && w_x != nullptr;
     wl[t] = on ? w_x[row] : 0.f;
-    lse2l[t] = on ? lse_x[row] * kLog2e : 1.0e30f;  // disabled term: exp2(-huge) = 0, never 0 * inf
+    lse2l[t] = (on && !BCE) ? lse_x[row] * kLog2e : 1.0e30f;  // disabled term: exp2(-huge) = 0, never 0 * inf
   }
   f32x16 gacc[B::NT][B::CT];
 #pragma unroll
@@ -876,7 +911,7 @@ __global__ __launch_bounds__(256, 2) void infonce_bwd_kernel(
       const int64_t j = j0 + tid;
       const bool on = j < ny && w_y != nullptr;
       s_w = on ? w_y[j] : 0.f;
-      s_lse = on ? lse_y[j] * kLog2e : 1.0e30f;
+      s_lse = (on && !BCE) ? lse_y[j] * kLog2e : 1.0e30f;
     }
   };
   auto store_stats = [&](int buf) {
@@ -935,7 +970,12 @@ __global__ __launch_bounds__(256, 2) void infonce_bwd_kernel(
           // EXD: the diagonal pair (stationary row i, streamed row j = i) carries no probability
           const bool dead = dead_j || (EXD && diag_offset(i0 + 32 * t + i32, j0, h) == e + 8 * g);
           const float sc = dead ? -INFINITY : acc[t][r];
-          acc[t][r] = wl[t] * __builtin_amdgcn_exp2f(sc - lse2l[t]) + wre[e] * __builtin_amdgcn_exp2f(sc - lre[e]);
+          if (BCE) {                                // P = (w_x[i] + w_y[j]) sigmoid(s_ij)
+            float sp, sg;
+            bce_terms(sc, sp, sg);
+            acc[t][r] = (wl[t] + wre[e]) * sg;
+          } else
+            acc[t][r] = wl[t] * __builtin_amdgcn_exp2f(sc - lse2l[t]) + wre[e] * __builtin_amdgcn_exp2f(sc - lre[e]);
         }
       }
     }
@@ -1322,6 +1362,9 @@ __global__ __launch_bounds__(256, 2) void infonce_fwdo_b3_kernel(
 //   MODE 0  backward: P = w_x e^{s - lse_x} + w_y e^{s - lse_y}   (infonce_bwd_b3_kernel's arithmetic)
 //   MODE 1  forward with the weighted row sum (infonce_fwdo_b3_kernel's arithmetic): online reference point,
 //           the rare rescale of the accumulators happens between two B phases.
+//   MODE 2  BCE-with-logits forward (lightgcn.py:109-113): row sums of softplus(s) and o_i = sum_j sigmoid(s_ij) y_j
+//           (sigmoid <= 1: no reference point, no rescale); MODE 3 its backward, P = (w_x[i] + w_y[j]) sigmoid(s_ij)
+//           (SIDES 1 / 2: the weights sit on the stationary / the streamed rows).
 // ------------------------------------------------------------------------------------------
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint2 lds_read_tr16(const unsigned char* p) {      // ds_read_b64_tr_b16; EXEC must be all ones
@@ -1429,6 +1472,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
   // units, all padded to whole tiles; FOLD: the statistics are (e, c), the weights live in the exponent
   constexpr bool PRE = MODE == 0 && std::is_same<E, EngH2>::value;
   constexpr bool FOLD = PRE && SIDES == 2;
+  constexpr bool BWD = MODE == 0 || MODE == 3;               // per-row weights (MODE 0: and lse) ride with the tiles
+  constexpr bool FWD = MODE == 1 || MODE == 2;               // running row sums + the o accumulators
+  static_assert(MODE < 2 || (std::is_same<E, EngB3>::value && !EXD && NW == 4), "BCE modes: three planes, four waves");
+  static_assert(MODE != 3 || SIDES == 1 || SIDES == 2, "BCE backward: weights on one side");
   __shared__ __align__(16) unsigned char lds_rm[RING][RM];   // ring: tile t (B, transposed reads), t+1 (A), t+2 (staging)
   __shared__ __align__(16) float st_lse[RING][kTileJ];
   __shared__ __align__(16) float st_w[RING][kTileJ];
@@ -1440,16 +1487,16 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
 
   // MODE 0 on EngH2: weights pre-scaled into f16 range (h2_wscale_kernel); hw == nullptr otherwise
   const float w_mul = hw != nullptr ? hw[0] : 1.0f;
-  const bool on_x = MODE == 0 && row_i < mx && w_x != nullptr;
+  const bool on_x = BWD && row_i < mx && w_x != nullptr;
   const float wl = on_x ? w_x[row_i] * w_mul : 0.f;
-  const float lse2l = on_x ? lse_x[row_i] * kLog2e : 1.0e30f;
+  const float lse2l = (MODE == 0 && on_x) ? lse_x[row_i] * kLog2e : 1.0e30f;
   // FOLDX (statistics on the stationary rows only): the same move as FOLD inside the kernel — |w_i| into the exponent,
   // sgn w_i into the stationary operand (the scores flip with it, hence c_x) and back out of the gradient row at the end:
   //   P_ij = w_i e^{s_ij - lse_i} = sgn_i 2^(c_x s'_ij + e_x)
   constexpr bool FOLDX = MODE == 0 && SIDES == 1;
   const float sgn_x = FOLDX && wl < 0.f ? -1.0f : 1.0f;
   const float c_x = sgn_x * E::kSInv;
-  const float e_x = on_x ? fmaf(-lse_x[row_i], kLog2e, __log2f(fabsf(wl))) : -1.0e30f;
+  const float e_x = (MODE == 0 && on_x) ? fmaf(-lse_x[row_i], kLog2e, __log2f(fabsf(wl))) : -1.0e30f;
   u32x4 bq[1][NPL][S::KC];
   load_stationary_e<E, D>(x, x_scale, mx, row_i, h, scale2 * E::kSX * sgn_x, bq[0]);
   float m_run = kNegBig, l_run = 0.f;                   // MODE 1
@@ -1496,11 +1543,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
         r.s[u] = sp[rr * (unsigned)sstride];
         r.live[u] = row < rem;
       }
-      if (MODE == 0 && tid < kTileJ) {
+      if (BWD && tid < kTileJ) {
         const int64_t j = j0 + tid;
         const bool on = j < ny && w_y != nullptr;
         sw = on ? w_y[j] * w_mul : 0.f;
-        sl = on ? lse_y[j] * kLog2e : 1.0e30f;
+        sl = (MODE == 0 && on) ? lse_y[j] * kLog2e : 1.0e30f;
       }
     };
     // one third of the staging of one float4: split (x, y), split (z, w), row-major plane stores
@@ -1524,7 +1571,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
 #pragma unroll
           for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<uint2*>(p + pl * S::PLANE) = make_uint2(sa[u][pl], sb[u][pl]);
         }
-        if (MODE == 0 && u == 0 && tid < kTileJ) {
+        if (BWD && u == 0 && tid < kTileJ) {
           st_lse[sbuf][tid] = sl;
           st_w[sbuf][tid] = sw;
         }
@@ -1572,6 +1619,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
         psum = 0.f;
         p_off = E::kPExp - m_use;
       }
+      if (MODE == 2) psum = 0.f;
     };
     // streamed rows' statistics (MODE 0, SIDES != 1): accumulator register r = 4 g + e of lane half h is tile row
     // 8 g + 4 h + e, so ONE ds_read_b128 per array serves four consecutive P units; group g + 1 is fetched while group g
@@ -1579,7 +1627,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
     // (timing-only build with constants: 1.82 -> 1.66 ms).
     float4 sl4[2], sw4[2];
     auto stats_begin = [&](int sbuf) {
-      if (MODE == 0 && SIDES != 1) {
+      if (BWD && SIDES != 1) {
         sl4[0] = *reinterpret_cast<const float4*>(&st_lse[sbuf][4 * h]);
         sw4[0] = *reinterpret_cast<const float4*>(&st_w[sbuf][4 * h]);
       }
@@ -1590,6 +1638,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
         if (MODE == 1) {
           acc[r] = __builtin_amdgcn_exp2f(fmaf(acc[r], E::kSInv, p_off));
           psum += acc[r];
+        } else if (MODE == 2) {
+          float sp, sg;
+          bce_terms(acc[r] * E::kSInv, sp, sg);
+          psum += sp;
+          acc[r] = sg;
         } else {
           float lre = 0.f, wre = 0.f;
           if (SIDES != 1) {
@@ -1603,7 +1656,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
             wre = e == 0 ? w4.x : (e == 1 ? w4.y : (e == 2 ? w4.z : w4.w));
           }
           const float sc = acc[r];
-          if (SIDES == 1) acc[r] = __builtin_amdgcn_exp2f(fmaf(sc, c_x, e_x));
+          if (MODE == 3) {
+            float sp, sg;
+            bce_terms(sc * E::kSInv, sp, sg);
+            acc[r] = (SIDES == 1 ? wl : wre) * sg;
+          } else if (SIDES == 1) acc[r] = __builtin_amdgcn_exp2f(fmaf(sc, c_x, e_x));
           else if (FOLD) acc[r] = __builtin_amdgcn_exp2f(fmaf(sc, wre, lre));
           else if (SIDES == 2) acc[r] = wre * __builtin_amdgcn_exp2f(fmaf(sc, E::kSInv, -lre));
           else acc[r] = wl * __builtin_amdgcn_exp2f(fmaf(sc, E::kSInv, -lse2l)) + wre * __builtin_amdgcn_exp2f(fmaf(sc, E::kSInv, -lre));
@@ -1628,6 +1685,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
         }
         l_run += psum;
       }
+      if (MODE == 2) l_run += psum;
     };
     auto score_plain = [&](const unsigned char* rm, f32x16& acc) {
 #pragma unroll
@@ -1701,7 +1759,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
         }
       }
       if (NW == 8) __syncthreads();                      // interval boundary: the partner group moves on to its score phase
-      if (MODE == 0 || real_next) prepare(acc, t + 1);
+      if (BWD || real_next) prepare(acc, t + 1);
       stats_begin(slot1);
       __builtin_amdgcn_sched_barrier(0);
       // phase B: second product of tile t || P(t+1)
@@ -1734,14 +1792,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
         for (int term = 0; term < NTERM; ++term) {
           gacc[c] = E::mfma(ya[grp & 1][E::ta(term)], pp[E::tb(term)], gacc[c]);
           const int slot = grp * NTERM + term;
-          if (MODE == 0 || real_next) {
+          if (BWD || real_next) {
 #pragma unroll
             for (int m = slot * 24 / NG; m < (slot + 1) * 24 / NG; ++m) p_unit(m, acc, slot1, pn);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      if (MODE == 0 || real_next) finish_p();
+      if (BWD || real_next) finish_p();
       __syncthreads();
     };
     // NW = 8: waves 4..7 take one barrier more before the loop and waves 0..3 one more after it: the same number for
@@ -1768,11 +1826,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
   }
 
   float* gout = gpart + (int64_t)split * mx * D;
-  if (MODE == 1) {
+  if (FWD) {
     const float l_o = __shfl_xor(l_run, 32, 64);
-    // the sum carries the scale of P (2^kPExp), the rows P's and the streamed operand's
+    // the sum carries the scale of P (2^kPExp), the rows P's and the streamed operand's; MODE 2: plain log2-domain sum
     if (h == 0 && row_i < mx)
-      part[(int64_t)split * mx + row_i] = make_float2(m_run, (l_run + l_o) * __builtin_amdgcn_exp2f(-E::kPExp));
+      part[(int64_t)split * mx + row_i] =
+          MODE == 2 ? make_float2(0.f, l_run + l_o) : make_float2(m_run, (l_run + l_o) * __builtin_amdgcn_exp2f(-E::kPExp));
   }
   const float o_mul = out_scale * (hw != nullptr ? hw[1] : 1.0f) * sgn_x;
   if (row_i < mx) {
@@ -2108,6 +2167,107 @@ int32_t launch_fwd_o(const float* a, const float* a_scale, int64_t m, const floa
 }
 
 bool dim_supported(int d) { return d == 32 || d == 64 || d == 128 || d == 256; }
+
+// ------------------------------------------------------------------------------------------
+// BCE-with-logits over the all-pairs score matrix (lightgcn.py:109-113, loss_type == "bce"):
+//   scores = user_vecs @ item_emb.T;  labels one-hot at pos_i;  F.binary_cross_entropy_with_logits(scores, labels)
+//   = ( sum_ij softplus(s_ij) - sum_i s_{i, pos_i} ) / (M N).
+// The M x N part is the row sum of softplus (forward) and (sigmoid(s)) weighted row / column sums of the operands
+// (gradients) — the InfoNCE tile engine with another epilogue; rows are NOT normalised here, so the launches run on
+// three bf16 planes (d <= 64, the pipelined two-product loop, MODE 2 / 3) or the f32 MFMA (d = 128, 256, or forced).
+// The positive-logit term is O(M d) and lives in the host-side op (functional.bce_softplus_rowsum's callers).
+// ------------------------------------------------------------------------------------------
+// rowsum[i] = ln2 * sum_s part[s][i].y ;  o[i, :] = sum_s opart[s][i, :]   (fixed order)
+__global__ __launch_bounds__(256) void bce_merge_kernel(const float2* __restrict__ part, const float* __restrict__ opart,
+                                                        int nsplit, int64_t m_rows, int d, float* __restrict__ rowsum,
+                                                        float* __restrict__ o) {
+  const int d4 = o != nullptr ? d / 4 : 1;
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= m_rows * d4) return;
+  const int64_t i = k / d4;
+  const int c = (int)(k % d4);
+  if (c == 0) {
+    float l = 0.f;
+    for (int s = 0; s < nsplit; ++s) l += part[(int64_t)s * m_rows + i].y;
+    rowsum[i] = l * kLn2;
+  }
+  if (o != nullptr) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < nsplit; ++s) {
+      const float4 v = reinterpret_cast<const float4*>(opart)[((int64_t)s * m_rows + i) * d4 + c];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    reinterpret_cast<float4*>(o)[i * d4 + c] = acc;
+  }
+}
+
+bool bce_pipe(int d, bool force_f32) { return d <= 64 && use_b3(d, force_f32); }
+
+FwdPlan plan_bce_fwd(int64_t m, int64_t n, int d, bool force_f32) {
+  if (bce_pipe(d, force_f32)) return plan_bwd_rows(m, n, d, 128);
+  return plan_fwd(m, n, d <= 128 ? 256 : 128, d <= 64 ? 768 : 512);
+}
+
+template <int D>
+int32_t launch_bce_fwd(const float* a, int64_t m, const float* b, int64_t n, float* rowsum, float* o, void* workspace,
+                       bool force_f32, hipStream_t s) {
+  const FwdPlan p = plan_bce_fwd(m, n, D, force_f32);
+  float2* part = reinterpret_cast<float2*>(workspace);
+  float* opart = reinterpret_cast<float*>(part + (int64_t)p.nsplit * m);
+  const dim3 grid((unsigned)(p.m_blocks * p.nsplit));
+  const float* none = nullptr;
+  bool with_o = false;
+  if constexpr (D <= 64) {
+    if (bce_pipe(D, force_f32)) {
+      hipLaunchKernelGGL((infonce_pipe_kernel<EngB3, D, 2, false, 0, 4>), grid, dim3(256), 0, s, a, none, m, b, none, n,
+                         kLog2e, 1.0f, none, none, none, none, p.nsplit, p.tiles_per_split, opart, part, none);
+      with_o = true;
+    }
+  }
+  if (!with_o) {
+    if (o != nullptr) return GCR_EUNSUPPORTED;
+    hipLaunchKernelGGL((infonce_fwd_kernel<D, false, false, true>), grid, dim3(256), 0, s, a, none, m, b, none, n, kLog2e,
+                       p.nsplit, p.tiles_per_split, part, (float*)nullptr, 0.f);
+  }
+  int32_t st = GCR_LAUNCH_STATUS();
+  if (st != GCR_OK) return st;
+  const int64_t threads = m * (o != nullptr ? D / 4 : 1);
+  hipLaunchKernelGGL(bce_merge_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, part, opart, p.nsplit, m, D,
+                     rowsum, o);
+  return GCR_LAUNCH_STATUS();
+}
+
+template <int D>
+int32_t launch_bce_bwd(const float* x, int64_t mx, const float* y, int64_t ny, const float* w_x, const float* w_y, float* g,
+                       void* workspace, bool force_f32, hipStream_t s) {
+  const float* none = nullptr;
+  if constexpr (D <= 64) {
+    if (bce_pipe(D, force_f32)) {
+      const FwdPlan p = plan_bwd_rows(mx, ny, D, BwdB3<D>::ROWS_PER_BLOCK);
+      float* gpart = p.nsplit == 1 ? g : reinterpret_cast<float*>(workspace);
+      const dim3 grid((unsigned)(p.m_blocks * p.nsplit));
+      if (w_x != nullptr)
+        hipLaunchKernelGGL((infonce_pipe_kernel<EngB3, D, 3, false, 1, 4>), grid, dim3(256), 0, s, x, none, mx, y, none, ny,
+                           kLog2e, 1.0f, none, w_x, none, none, p.nsplit, p.tiles_per_split, gpart, (float2*)nullptr, none);
+      else
+        hipLaunchKernelGGL((infonce_pipe_kernel<EngB3, D, 3, false, 2, 4>), grid, dim3(256), 0, s, x, none, mx, y, none, ny,
+                           kLog2e, 1.0f, none, none, none, w_y, p.nsplit, p.tiles_per_split, gpart, (float2*)nullptr, none);
+      int32_t st = GCR_LAUNCH_STATUS();
+      if (st != GCR_OK) return st;
+      return reduce_splits(p, gpart, mx, D, g, s);
+    }
+  }
+  const FwdPlan p = plan_bwd<D>(mx, ny);
+  float* gpart = p.nsplit == 1 ? g : reinterpret_cast<float*>(workspace);
+  for (int pass = 0; pass < BwdShape<D>::PASSES; ++pass) {
+    hipLaunchKernelGGL((infonce_bwd_kernel<D, false, true>), dim3((unsigned)(p.m_blocks * p.nsplit)), dim3(256), 0, s, x,
+                       none, mx, y, none, ny, kLog2e, 1.0f, none, w_x, none, w_y, pass * BwdShape<D>::CT, p.nsplit,
+                       p.tiles_per_split, gpart);
+    int32_t st = GCR_LAUNCH_STATUS();
+    if (st != GCR_OK) return st;
+  }
+  return reduce_splits(p, gpart, mx, D, g, s);
+}
 
 // ------------------------------------------------------------------------------------------
 // Nearest-centroid assignment for the NCL prototype step (ncl.py:340-356: faiss.Kmeans.train +
@@ -2626,4 +2786,71 @@ extern "C" int32_t gcr_normalize_bwd_f32(const float* x, const float* inv_norm, 
   hipLaunchKernelGGL(normalize_bwd_kernel, dim3((unsigned)(want > 8192 ? 8192 : want)), dim3(256), 0,
                      (hipStream_t)stream, x, inv_norm, ghat, n, d, out);
   return GCR_LAUNCH_STATUS();
+}
+
+// ---- BCE-with-logits over all pairs (lightgcn.py:109-113) ----
+extern "C" int32_t gcr_bce_fwd_o_supported(int32_t d, uint32_t flags) {
+  return (d == 32 || d == 64) && bce_pipe(d, (flags & GCR_INFONCE_ENGINE_F32) != 0) ? 1 : 0;
+}
+
+extern "C" int64_t gcr_bce_fwd_workspace_bytes(int64_t m, int64_t n, int32_t d) {
+  if (m <= 0 || n <= 0 || !dim_supported(d)) return 0;
+  const FwdPlan p = plan_bce_fwd(m, n, d, false), q = plan_bce_fwd(m, n, d, true);   // either engine (chosen per call)
+  const int64_t nsplit = p.nsplit > q.nsplit ? p.nsplit : q.nsplit;
+  return nsplit * m * ((int64_t)sizeof(float2) + (d <= 64 ? (int64_t)d * (int64_t)sizeof(float) : 0));
+}
+
+extern "C" int32_t gcr_bce_fwd_f32(const float* a, int64_t m, const float* b, int64_t n, int32_t d, float* row_softplus,
+                                   float* o, void* workspace, uint32_t flags, void* stream) {
+  GCR_CHECK_ARG(m >= 0 && n >= 1);
+  GCR_CHECK_ARG((flags & ~(uint32_t)GCR_INFONCE_ENGINE_F32) == 0);
+  if (!dim_supported(d)) return GCR_EUNSUPPORTED;
+  if (o != nullptr && !gcr_bce_fwd_o_supported(d, flags)) return GCR_EUNSUPPORTED;
+  if (m == 0) return GCR_OK;
+  GCR_CHECK_ARG(a != nullptr && b != nullptr && row_softplus != nullptr && workspace != nullptr);
+  GCR_CHECK_ARG(m < (1ll << 40) && n < (1ll << 40));
+  const bool f32 = (flags & GCR_INFONCE_ENGINE_F32) != 0;
+  hipStream_t s = (hipStream_t)stream;
+  switch (d) {
+    case 32: return launch_bce_fwd<32>(a, m, b, n, row_softplus, o, workspace, f32, s);
+    case 64: return launch_bce_fwd<64>(a, m, b, n, row_softplus, o, workspace, f32, s);
+    case 128: return launch_bce_fwd<128>(a, m, b, n, row_softplus, o, workspace, f32, s);
+    default: return launch_bce_fwd<256>(a, m, b, n, row_softplus, o, workspace, f32, s);
+  }
+}
+
+extern "C" int64_t gcr_bce_bwd_workspace_bytes(int64_t mx, int64_t ny, int32_t d) {
+  if (mx <= 0 || ny <= 0 || !dim_supported(d)) return 0;
+  FwdPlan p;
+  switch (d) {
+    case 32: p = plan_bwd<32>(mx, ny); break;
+    case 64: p = plan_bwd<64>(mx, ny); break;
+    case 128: p = plan_bwd<128>(mx, ny); break;
+    default: p = plan_bwd<256>(mx, ny); break;
+  }
+  int64_t nsplit = p.nsplit;
+  if (d <= 64) {
+    const FwdPlan q = plan_bwd_rows(mx, ny, d, 128);
+    if (q.nsplit > nsplit) nsplit = q.nsplit;
+  }
+  return nsplit > 1 ? nsplit * mx * d * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int32_t gcr_bce_bwd_f32(const float* x, int64_t mx, const float* y, int64_t ny, int32_t d, const float* w_x,
+                                   const float* w_y, float* g, void* workspace, uint32_t flags, void* stream) {
+  GCR_CHECK_ARG(mx >= 0 && ny >= 1);
+  GCR_CHECK_ARG((flags & ~(uint32_t)GCR_INFONCE_ENGINE_F32) == 0);
+  if (!dim_supported(d)) return GCR_EUNSUPPORTED;
+  if (mx == 0) return GCR_OK;
+  GCR_CHECK_ARG(x != nullptr && y != nullptr && g != nullptr);
+  GCR_CHECK_ARG((w_x != nullptr) != (w_y != nullptr));     // the weights sit on exactly one side
+  GCR_CHECK_ARG(workspace != nullptr || gcr_bce_bwd_workspace_bytes(mx, ny, d) == 0);
+  const bool f32 = (flags & GCR_INFONCE_ENGINE_F32) != 0;
+  hipStream_t s = (hipStream_t)stream;
+  switch (d) {
+    case 32: return launch_bce_bwd<32>(x, mx, y, ny, w_x, w_y, g, workspace, f32, s);
+    case 64: return launch_bce_bwd<64>(x, mx, y, ny, w_x, w_y, g, workspace, f32, s);
+    case 128: return launch_bce_bwd<128>(x, mx, y, ny, w_x, w_y, g, workspace, f32, s);
+    default: return launch_bce_bwd<256>(x, mx, y, ny, w_x, w_y, g, workspace, f32, s);
+  }
 }

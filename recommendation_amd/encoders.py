@@ -269,6 +269,31 @@ class LightGCN(nn.Module):
         return Fn.split_rows(x, nu)
 
 
+    def loss(self, edge_index, neg_i=None, loss_type="bpr", reg_weight=0.0):
+        """One training step's loss as lightgcn.py:85-118 computes it on the FULL batch of training edges
+        (pos_u / pos_i = the edge list the graph was built from, in the graph's user-major order):
+        loss_type "bpr": -log(sigmoid(pos - neg)).mean() with `neg_i` [E] or [E, n_neg] (lightgcn.py:98-108);
+        loss_type "bce": BCE-with-logits of the [E, I] scores against one-hot labels (lightgcn.py:109-113; neg_i unused);
+        plus reg_weight * (|user_vecs|^2 + |pos_item_vecs|^2) (lightgcn.py:118)."""
+        graph = edge_index if isinstance(edge_index, CsrGraph) else self.prepare(edge_index)
+        nu = self.user_embedding.num_embeddings
+        x = torch.cat([self.user_embedding.weight, self.item_embedding.weight], dim=0)
+        final = Fn.lightgcn_propagate(graph, x, self.num_layers, combine="sum")
+        n_edges = graph.user_major_edges(nu)[0].numel()
+        if loss_type == "bpr":
+            if neg_i is None:
+                raise ValueError("loss_type 'bpr' needs neg_i")
+            s = Fn.bpr_edge_sums(graph, final, nu, neg_i, Fn.BPR_LOG_SIGMOID)
+            return s[0] / n_edges + reg_weight * (s[1] + s[2])
+        if loss_type != "bce":
+            raise ValueError("Unsupported loss_type")              # lightgcn.py:115
+        loss = Fn.bce_edge_loss(graph, final, nu)
+        if reg_weight:
+            # |user_vecs|^2 + |pos_item_vecs|^2 over the edge list = sum over rows of (#edges of the row) |row|^2
+            loss = loss + reg_weight * torch.dot(graph.row_degrees(), final.square().sum(1))
+        return loss
+
+
 def sept_encoder(emb, adj: CsrGraph, n_layers: int, combine: str = "mean"):
     """emb_k = normalize(A emb_{k-1}) per layer (the NORMALISED rows feed the next layer), then
     combine='mean': univariate/sept.py:220-226; combine='sum': univariate/sept_social.py:370-385

@@ -809,6 +809,138 @@ def infonce_stats(a, b, pos=None, temperature=0.2, normalize=True, want_col=Fals
                                grad_a)
 
 
+# ---------------------------------------------------------------------------------------------
+# BCE-with-logits over all pairs (lightgcn.py:109-113, `loss_type == "bce"`)
+# ---------------------------------------------------------------------------------------------
+def _bce_flags(engine=None):
+    return _resolve_engine(engine) & INFONCE_ENGINE_F32        # rows are not unit rows: three bf16 planes or the f32 MFMA
+
+
+def bce_fwd_raw(a, b, want_o=False, engine_flag=0):
+    """(rowsum [M], o [M, d] or None): rowsum[i] = sum_j softplus(<a_i, b_j>), o[i] = sum_j sigmoid(<a_i, b_j>) b_j (no autograd)."""
+    L = _lib.lib()
+    m, d = a.shape
+    n = b.shape[0]
+    rows = torch.empty(m, dtype=torch.float32, device=a.device)
+    o = torch.empty(m, d, dtype=torch.float32, device=a.device) if want_o else None
+    ws = torch.empty(max(int(L.gcr_bce_fwd_workspace_bytes(m, n, d)), 8) // 4, dtype=torch.float32, device=a.device)
+    _lib.check(L.gcr_bce_fwd_f32(_lib.dptr(a), m, _lib.dptr(b), n, d, _lib.dptr(rows), _lib.dptr(o), _lib.dptr(ws),
+                                 int(engine_flag), _lib.cur_stream(a.device)), "gcr_bce_fwd_f32")
+    return rows, o
+
+
+def bce_bwd_raw(x, y, w_x=None, w_y=None, engine_flag=0, out=None):
+    """g[i] = sum_j (w_x[i] | w_y[j]) sigmoid(<x_i, y_j>) y_j (exactly one of the weight vectors; gcr_bce_bwd_f32)."""
+    L = _lib.lib()
+    mx, d = x.shape
+    g = torch.empty_like(x) if out is None else out
+    nbytes = int(L.gcr_bce_bwd_workspace_bytes(mx, y.shape[0], d))
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device) if nbytes else None
+    _lib.check(L.gcr_bce_bwd_f32(_lib.dptr(x), mx, _lib.dptr(y), y.shape[0], d, _lib.dptr(w_x), _lib.dptr(w_y), _lib.dptr(g),
+                                 _lib.dptr(ws), int(engine_flag), _lib.cur_stream(x.device)), "gcr_bce_bwd_f32")
+    return g
+
+
+class _BceRows(torch.autograd.Function):
+    """(a, b) -> rowsum [M] of softplus(a b^T); the backward is sigmoid-weighted operand sums (no M x N matrix)."""
+
+    @staticmethod
+    def forward(ctx, a, b, eng, grad_a):
+        a_p, b_p = _pad_dim(a).contiguous(), _pad_dim(b).contiguous()
+        want_o = bool(grad_a and a_p.shape[0] > 0 and _lib.lib().gcr_bce_fwd_o_supported(a_p.shape[1], eng))
+        rows, o = bce_fwd_raw(a_p, b_p, want_o, eng)
+        ctx.save_for_backward(a_p, b_p, o)
+        ctx.eng, ctx.d = eng, a.shape[1]
+        return rows
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, o = ctx.saved_tensors
+        g = g.contiguous().float()
+        ga = gb = None
+        if ctx.needs_input_grad[0]:
+            ga = o * g.unsqueeze(1) if o is not None else bce_bwd_raw(a, b, w_x=g, engine_flag=ctx.eng)
+        if ctx.needs_input_grad[1]:
+            gb = bce_bwd_raw(b, a, w_y=g, engine_flag=ctx.eng)
+        d = ctx.d
+        if ga is not None and ga.shape[1] != d:
+            ga = ga[:, :d].contiguous()
+        if gb is not None and gb.shape[1] != d:
+            gb = gb[:, :d].contiguous()
+        return ga, gb, None, None
+
+
+def bce_softplus_rowsum(a, b, engine=None):
+    """rowsum[i] = sum_j softplus(<a_i, b_j>) = sum_j BCE-with-logits(s_ij, label 0) without materialising the [M, N]
+    scores of lightgcn.py:110; differentiable w.r.t. a and b.  With a one-hot label per row the loss of lightgcn.py:113
+    is (rowsum.sum() - sum_i s_{i, pos_i}) / (M N)  (`losses.lightgcn_bce_loss`)."""
+    _lib.require_cuda(a, b)
+    if a.dim() != 2 or b.dim() != 2 or a.shape[1] != b.shape[1] or a.dtype != torch.float32 or b.dtype != torch.float32:
+        raise ValueError("a [M, d] and b [N, d] must be float32 with the same d")
+    if b.shape[0] == 0:
+        raise ValueError("empty item table")
+    return _BceRows.apply(a, b, _bce_flags(engine), torch.is_grad_enabled() and a.requires_grad)
+
+
+class _BceEdgeLoss(torch.autograd.Function):
+    """lightgcn.py:109-113 for the batch that IS the training graph's edge list (the full batch of lightgcn.py:86-87):
+        loss = ( sum_u deg(u) rowsum_u  -  sum_{(u,i) in E} <U_u, I_i> ) / (E * I)
+    * rows of the [E, I] score matrix that belong to the same user are equal: the softplus part runs over the U distinct
+      users, weighted by their number of training edges (E / U times fewer pairs than the reference's matmul);
+    * the positive-logit sum is 1/2 <T, A1 T> with A1 the graph's pattern with unit values (duplicate edges counted), and
+      its gradient w.r.t. the stacked table T is A1 T itself: ONE SpMM launch gives the value and both gradients."""
+
+    @staticmethod
+    def forward(ctx, table, graph, n_users, eng):
+        table = table.contiguous()
+        ue, ie = table[:n_users], table[n_users:]
+        n_edges = graph.user_major_edges(n_users)[0].numel()
+        deg = graph.row_degrees()[:n_users].contiguous()
+        want_o = bool(_lib.lib().gcr_bce_fwd_o_supported(table.shape[1], eng))
+        rows, o = bce_fwd_raw(ue, ie, want_o, eng)
+        ones = getattr(graph, "_unit_values", None)
+        if ones is None:
+            ones = graph if graph.val is None else \
+                graph.with_values(torch.ones(graph.nnz, dtype=torch.float32, device=table.device))
+            graph._unit_values = ones
+        y = torch.empty_like(table)
+        spmm_into(ones, table, y=y)
+        scale = 1.0 / (float(n_edges) * float(ie.shape[0]))
+        ctx.save_for_backward(table, o, y, deg)
+        ctx.n_users, ctx.eng, ctx.scale = n_users, eng, scale
+        return (torch.dot(deg, rows) - 0.5 * torch.dot(table.reshape(-1), y.reshape(-1))) * scale
+
+    @staticmethod
+    def backward(ctx, g):
+        table, o, y, deg = ctx.saved_tensors
+        n_users = ctx.n_users
+        ue, ie = table[:n_users], table[n_users:]
+        c = g * ctx.scale
+        gt = torch.empty_like(table)
+        w = (deg * c).contiguous()
+        if o is not None:
+            torch.mul(o, w.unsqueeze(1), out=gt[:n_users])
+        else:
+            bce_bwd_raw(ue, ie, w_x=w, engine_flag=ctx.eng, out=gt[:n_users])
+        bce_bwd_raw(ie, ue, w_y=w, engine_flag=ctx.eng, out=gt[n_users:])
+        torch.addcmul(gt, y, (-c).reshape(1, 1), out=gt)          # (c stays on the device: no host read-back)
+        return gt, None, None, None
+
+
+def bce_edge_loss(graph, table, n_users, engine=None):
+    """`F.binary_cross_entropy_with_logits(user_emb[pos_u] @ item_emb.T, one_hot(pos_i))` (lightgcn.py:109-113) for
+    (pos_u, pos_i) = the training edges `graph` was built from (`graph.user_major_edges`); `table` = the stacked [U + I, d]
+    encoder output.  d must be one of the MFMA widths (32 / 64 / 128 / 256)."""
+    _lib.require_cuda(table)
+    if not graph.symmetric:
+        raise ValueError("bce_edge_loss needs a symmetric bipartite operator (users first)")
+    if table.dtype != torch.float32 or table.dim() != 2 or table.shape[0] != graph.n_rows:
+        raise ValueError("table must be float32 [n_rows, d]")
+    if table.shape[1] not in _MFMA_DIMS:
+        raise ValueError("bce_edge_loss: embedding dim must be 32, 64, 128 or 256 (use losses.lightgcn_bce_loss otherwise)")
+    return _BceEdgeLoss.apply(table, graph, int(n_users), _bce_flags(engine))
+
+
 def edge_mask_exact_bits(nnz, n_keep, seed, device):
     """Keep bitmap with exactly n_keep of nnz bits set, a uniformly random subset without replacement
     (univariate/sept.py:55-61: `np.random.choice(idx, int(len(idx) * (1 - drop_rate)), replace=False)`)."""

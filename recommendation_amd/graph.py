@@ -145,7 +145,7 @@ class CsrGraph:
         """A view of this operator with other per-non-zero values (float32 [nnz], same order): structure, work plan and
         workspace are shared, nothing is copied — e.g. the per-edge coefficients of `functional.bpr_edge_sums`."""
         import copy
-        if val.shape != self.val.shape or val.dtype != torch.float32 or val.device != self.val.device:
+        if tuple(val.shape) != (self.nnz,) or val.dtype != torch.float32 or val.device != self.col.device:
             raise ValueError("val must be float32 [nnz] on the graph's device")
         g = copy.copy(self)
         g.val = val.contiguous()

@@ -6,6 +6,7 @@ HIP kernels of libgcr (no M x N score matrix is ever materialised).
   batch_softmax_loss                      ssl4rec.py:25-30
   ssl_layer_loss, ProtoNCE_loss           ncl.py:358-375 (NCLModel methods; here plain functions
                                           taking what the methods read from `self`)
+  lightgcn_bce_loss                       lightgcn.py:109-113 (the `loss_type == "bce"` branch of train_model)
 """
 from __future__ import annotations
 
@@ -84,6 +85,25 @@ def bpr_loss_logsigmoid(user_emb, pos_emb, neg_emb):
 def l2_reg_loss(reg, *args):
     """ncl.py:122-123: reg * sum_x ||x||_F / rows(x) (tiny reductions; stays in torch)."""
     return reg * sum(torch.norm(x, p=2) / x.shape[0] for x in args)
+
+
+def lightgcn_bce_loss(user_emb, item_emb, pos_u, pos_i, engine=None):
+    """lightgcn.py:95-96,109-113 (`loss_type == "bce"`): scores = user_emb[pos_u] @ item_emb.T  [B, I], labels one-hot at
+    pos_i, `F.binary_cross_entropy_with_logits(scores, labels)` = mean over B * I of softplus(s) - y s.  The [B, I]
+    matrix is never formed: the softplus part is the fused row sum (rows of one user are equal, so a batch with at least
+    as many samples as users runs over the distinct users weighted by their sample counts), the positive logits are a
+    gathered dot product.  For the full batch over a graph's own edge list use `Fn.bce_edge_loss` (LightGCN.loss)."""
+    dev = user_emb.device
+    pos_u = torch.as_tensor(pos_u, device=dev, dtype=torch.int64).reshape(-1)
+    pos_i = torch.as_tensor(pos_i, device=dev, dtype=torch.int64).reshape(-1)
+    bsz, n_users, n_items = pos_u.numel(), user_emb.shape[0], item_emb.shape[0]
+    if bsz >= n_users:
+        cnt = torch.bincount(pos_u, minlength=n_users).to(torch.float32)
+        soft = torch.dot(Fn.bce_softplus_rowsum(user_emb, item_emb, engine), cnt)
+    else:
+        soft = Fn.bce_softplus_rowsum(Fn.gather_rows(user_emb, pos_u), item_emb, engine).sum()
+    pos = (Fn.gather_rows(user_emb, pos_u) * Fn.gather_rows(item_emb, pos_i)).sum()
+    return (soft - pos) / (float(bsz) * float(n_items))
 
 
 def bpr_gather_loss(user_tab, item_tab, u_idx, i_idx, j_idx, variant=Fn.BPR_NCL):

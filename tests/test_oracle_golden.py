@@ -171,6 +171,17 @@ def test_bpr_and_regularisers(golden):
     assert val == pytest.approx(float(b["gcl_block_loss"]), rel=RT)
 
 
+def test_lightgcn_bce_block(golden):
+    # lightgcn.py:95-118 with loss_type == "bce", lifted from the epoch loop's statements by the generator
+    b = golden("bpr.npz")
+    u, i = b["u_idx"], b["i_idx"]
+    for name, ut, it in (("lgcn_bce", b["user_tab"], b["item_tab"]), ("lgcn_bce_big", b["user_tab_big"], b["item_tab_big"])):
+        loss, gu, gi = O.lightgcn_bce_loss(ut, it, u, i, reg_weight=1e-4)
+        assert loss == pytest.approx(float(b[f"{name}_loss"]), rel=RT)
+        np.testing.assert_allclose(gu, b[f"{name}_gu"], rtol=1e-4, atol=1e-5 * np.abs(b[f"{name}_gu"]).max())
+        np.testing.assert_allclose(gi, b[f"{name}_gi"], rtol=1e-4, atol=1e-5 * np.abs(b[f"{name}_gi"]).max())
+
+
 def test_augmentation_contract(golden):
     a = golden("augment.npz")
     # gcl.py:22-25 Bernoulli keep: rate ~ 1 - pe ; sept.py:55-61 keeps exactly floor(nnz*(1-p)) with value 1

@@ -451,6 +451,37 @@ def infonce_roofline(Fn, x0, n_u, dev):
     return out
 
 
+def self_launch(n_ranks):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` as a child process (one rank per GPU, the
+    contract's own launch line) and exit with its code.  Called before anything initialises the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:                     # a free rendezvous port on the loopback interface
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    sys.stdout.flush()
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+def init_only(rank, world):
+    """GCR_BENCH_INIT_ONLY=1: every rank joins the process group (gloo, CPU), meets at a barrier and rank 0 prints one line
+    — the launch path of `--gpus N` exercised without a GPU (tests/test_host_logic_cpu.py)."""
+    import torch.distributed as dist
+    dist.init_process_group(backend="gloo")
+    seen = torch.ones(1)
+    dist.all_reduce(seen)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"init_only": True, "dist_backend": dist.get_backend(), "dist_world": dist.get_world_size(),
+                          "ranks_seen": int(seen.item())}))
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -471,9 +502,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            # plain `python bench.py --gpus N`: start the N ranks ourselves.  Nothing in this process has touched the GPU
+            # (importing torch does not), and it never will: the ranks are children, their output is relayed, their exit
+            # code is ours.
+            return self_launch(args.gpus)
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("GCR_BENCH_INIT_ONLY") == "1":
+        return init_only(rank, world)
     if os.environ.get("GCR_BENCH_REHEARSE_ONE_GPU") == "1":
         local_rank = 0      # rehearsal of the N-rank code path on a one-GPU box: ranks share cuda:0 over gloo
     torch.cuda.set_device(local_rank)
@@ -548,6 +584,28 @@ def main():
             except Exception as e:      # noqa: BLE001
                 extra["community_graph"][wl_name] = {"error": repr(e)[:200]}
             torch.cuda.empty_cache()
+
+    # BASELINE configs[3] and [4] at one GPU (their N-rank forms run under --gpus N): the GCL two-view step of gcl.py:205-227
+    # through the single-rank sharded path, and MHCN's 2-layer multi-channel pass forward and forward + backward
+    if not args.no_extra and d == 64:
+        try:
+            c5 = cfg5_measure(d, 5, 2, 0, 1, dev, ra)
+            extra["cfg5"] = {"workload": c5["config"]["workload"], "edges_per_s": c5["value"], "fwd_ms": c5["ms_per_step"],
+                             "fwd_bwd_ms": c5["extra"]["fwd_bwd_ms"], "fwd_bwd_over_fwd": c5["extra"]["fwd_bwd_over_fwd"],
+                             "frac_alg": c5["roofline"]["frac"]}
+        except Exception as e:      # noqa: BLE001
+            extra["cfg5"] = {"error": repr(e)[:300]}
+        torch.cuda.empty_cache()
+        try:
+            from recommendation_amd import distributed as gdist
+            dist = _init_dist(dev)                                  # one rank: RCCL group of size 1 (no collective moves data)
+            try:
+                extra["gcl_step"] = gcl_step_leg(ra, gdist, dist, dev, 0, 1, d, None)
+            finally:
+                dist.destroy_process_group()
+        except Exception as e:      # noqa: BLE001
+            extra["gcl_step"] = {"error": repr(e)[:300]}
+        torch.cuda.empty_cache()
 
     line = {
         "metric": "edges propagated/sec (LightGCN d=%d, %d-layer fwd message pass)" % (d, k_layers),
@@ -787,6 +845,15 @@ CFG5 = dict(users=250_000, items=50_000, deg=(24, 16, 8), deg_r=10, layers=2)   
 
 
 def main_cfg5(args, rank, world, dev, ra):
+    line = cfg5_measure(args.dim, args.steps, args.warmup, rank, world, dev, ra)
+    if rank == 0:
+        print(json.dumps(line))
+    import torch.distributed as dist
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def cfg5_measure(d, steps, warmup, rank, world, dev, ra):
     """BASELINE config 5: MHCN's layer loop (univariate/mhcn.py:422-466) with the three U x U channel operators
     row-sharded by user: per layer three all-gathers of [U, d] channel operands, each overlapped with the
     previous channel's dual-output SpMM on its own stream, plus the R^T / R item side (all-reduce of the partial
@@ -798,7 +865,7 @@ def main_cfg5(args, rank, world, dev, ra):
     if world > 1 or os.environ.get("GCR_BENCH_FORCE_COLLECTIVES") == "1":
         dist = _init_dist(dev)
         gdist.FORCE_COLLECTIVES = os.environ.get("GCR_BENCH_FORCE_COLLECTIVES") == "1"
-    per_u, n_i, d, k_layers = CFG5["users"], CFG5["items"], args.dim, CFG5["layers"]
+    per_u, n_i, k_layers = CFG5["users"], CFG5["items"], CFG5["layers"]
     u_pad = per_u * world
     gen = torch.Generator(device=dev).manual_seed(SEED + rank)
     rows = torch.arange(per_u, device=dev)
@@ -826,17 +893,17 @@ def main_cfg5(args, rank, world, dev, ra):
         enc.allreduce_grads()
 
     if world > 1:
-        elapsed = _timed_ranks(dist, dev, step, args.warmup, args.steps)
+        elapsed = _timed_ranks(dist, dev, step, warmup, steps)
         t_fb = _timed_ranks(dist, dev, step_fb, 1, 3) / 3
         nnz_all = torch.tensor([nnz_local], device=dev, dtype=torch.int64)
         dist.all_reduce(nnz_all)
         nnz_all = int(nnz_all.item())
     else:
-        for _ in range(args.warmup):
+        for _ in range(warmup):
             step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             step()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
@@ -848,14 +915,15 @@ def main_cfg5(args, rank, world, dev, ra):
         torch.cuda.synchronize()
         t_fb = (time.perf_counter() - t0) / 3
         nnz_all = nnz_local
+    line = None
     if rank == 0:
         n_rows = u_pad * 4 + n_i                                       # output rows of the five operators
         bytes_alg = nnz_all * (8 + 4 * d) + n_rows * (2 * 4 * d + 4)   # dual epilogue: two output rows
-        achieved = bytes_alg * k_layers * args.steps / elapsed / 1e9
+        achieved = bytes_alg * k_layers * steps / elapsed / 1e9
         line = {
             "metric": "edges propagated/sec (MHCN d=%d, %d-layer multi-channel message pass)" % (d, k_layers),
-            "value": nnz_all * k_layers * args.steps / elapsed, "unit": "edges/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "value": nnz_all * k_layers * steps / elapsed, "unit": "edges/s", "n_gpus": world,
+            "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"cfg5 x{world}: MHCN {k_layers}-layer d={d}, {u_pad} users ({per_u}/GPU) x {n_i} items; "
                                    f"H_s/H_j/H_p with {CFG5['deg']} nnz per row, R with {CFG5['deg_r']} (nnz={nnz_all}); "
@@ -867,11 +935,9 @@ def main_cfg5(args, rank, world, dev, ra):
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                          "frac": round(achieved / (HBM_PEAK_GBS * world), 4), "traffic": None},
             "cpu_baseline": None, "dist_backend": dist.get_backend() if dist.is_initialized() else None, "dist_world": world,
-            "extra": {"fwd_bwd_ms": 1e3 * t_fb},
+            "extra": {"fwd_bwd_ms": 1e3 * t_fb, "fwd_bwd_over_fwd": round(t_fb * steps / elapsed, 3)},
         }
-        print(json.dumps(line))
-    if world > 1 or dist.is_initialized():
-        dist.destroy_process_group()
+    return line
 
 
 def bench_extra(ra, Fn, graph, x0, k_layers, nnz, dev, n_u, n_i):
@@ -979,6 +1045,10 @@ def bench_extra(ra, Fn, graph, x0, k_layers, nnz, dev, n_u, n_i):
     out["lightgcn_full_batch_step_ms"] = 1e3 * timeit(lightgcn_step, 5)
     out["lightgcn_full_batch_edges"] = int(eu.numel())
     del xp, opt
+    try:
+        out["lightgcn_bce"] = bce_legs(ra, Fn, graph, x0, k_layers, n_u, n_i, dev, timeit)
+    except Exception as e:      # noqa: BLE001
+        out["lightgcn_bce"] = {"error": repr(e)[:300]}
 
     # the stages either side of the path: NCL's k-means E-step and full-ranking eval
     from recommendation_amd.evaluate import rank_topk
@@ -989,6 +1059,60 @@ def bench_extra(ra, Fn, graph, x0, k_layers, nnz, dev, n_u, n_i):
         q = torch.arange(0, min(n_u, 100000), device=dev)
         t_r = timeit(lambda: rank_topk(ut, it, q, rowptr_u, items_u, 50), 2)
         out["full_ranking_users_per_s"] = q.numel() / t_r
+    return out
+
+
+def bce_legs(ra, Fn, graph, x0, k_layers, n_u, n_i, dev, timeit):
+    """The `loss_type == "bce"` branch of lightgcn.py's step (lightgcn.py:109-113): BCE-with-logits of the all-pairs scores
+    [E, I] against one-hot labels.  (i) the bare all-pairs part at 2^18 user rows x all items (fused softplus row sums,
+    forward, and forward + both gradients); (ii) the whole cfg1-sized training step (943 x 1682, 80 000 edges: the
+    reference's own feasible size, its [E, I] matrix is 135 M logits); (iii) the whole step on the benchmark graph — the
+    reference would materialise E x I = 10^12 logits; here the softplus part runs over the U distinct users weighted by
+    their edge counts (U x I = 10^11 pairs), the positive logits are one SpMM."""
+    from recommendation_amd.encoders import LightGCN
+    from recommendation_amd.optim import FusedAdam
+    out = {}
+    d = x0.shape[1]
+    m = min(1 << 18, n_u)
+    a, b = (x0[:m] * 8).contiguous(), (x0[n_u:] * 8).contiguous()       # trained-scale rows (scores of a few tenths .. units)
+    with torch.no_grad():
+        t_f = _event_ms(lambda: Fn.bce_softplus_rowsum(a, b), 3)
+    ag, bg = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+
+    def fb():
+        ag.grad = bg.grad = None
+        Fn.bce_softplus_rowsum(ag, bg).sum().backward()
+
+    t_fb = _event_ms(fb, 3)
+    pairs = m * n_i
+    out["all_pairs"] = {"shape": f"{m} x {n_i} x {d}", "pairs": pairs, "fwd_ms": round(t_f, 3), "fwd_bwd_ms": round(t_fb, 3),
+                        "pairs_per_s_fwd": pairs / t_f * 1e3, "pairs_per_s_fwd_bwd": pairs / t_fb * 1e3,
+                        "mfma_issued_frac_fwd_bwd": round(6 * 4 * 2.0 * pairs * d / t_fb / 1e9 / BF16_MFMA_PEAK_TF, 4),
+                        "note": "three bf16 planes (rows are not unit rows): 6 MFMA products per f32 product; fwd = softplus row "
+                                "sums only (1 tile product), fwd_bwd = flash-style forward (2) + item-side backward (2)"}
+    del a, b, ag, bg
+
+    def step_leg(model, g, reps):
+        opt = FusedAdam(model.parameters(), lr=1e-3)
+
+        def step():
+            opt.zero_grad()
+            model.loss(g, loss_type="bce", reg_weight=1e-4).backward()
+            opt.step()
+        return 1e3 * timeit(step, reps)
+
+    w1 = WORKLOADS["cfg1"]
+    u1, i1 = synth_interactions_device(w1["users"], w1["items"], w1["edges"], SEED, dev)
+    ei1 = torch.stack([torch.cat([u1, i1 + w1["users"]]), torch.cat([i1 + w1["users"], u1])])    # lightgcn.py:36-39
+    m1 = LightGCN(943, 1682, d, 2).to(dev)
+    g1 = m1.prepare(ei1)
+    out["cfg1_step_ms"] = round(step_leg(m1, g1, 10), 4)
+    out["cfg1_step_logits"] = 80000 * 1682
+    mb = LightGCN(n_u, n_i, d, k_layers).to(dev)
+    out["full_batch_step_ms"] = round(step_leg(mb, graph, 2), 3)
+    out["full_batch_step_logits_reference"] = (graph.nnz // 2) * n_i
+    out["full_batch_step_pairs_computed"] = n_u * n_i
+    out["note"] = "full_batch_step: propagate + BCE(all E x I logits, by distinct user) + reg + backward + Adam on the benchmark graph"
     return out
 
 

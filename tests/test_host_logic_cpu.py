@@ -105,3 +105,22 @@ def test_split_clusters_restatement_properties():
     cent3 = np.arange(20, dtype=np.float64).reshape(5, 4) + 1
     cnt3 = np.array([1, 1, 1, 2, 0], dtype=np.float64)
     assert O.kmeans_split_clusters(cent3, cnt3, 5, 1234, 0) == 1 and cnt3.tolist() == [1, 1, 1, 1, 1]
+
+
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2` from a plain invocation (no launcher, WORLD_SIZE unset) starts two ranks itself, relays
+    rank 0's line and exits with the children's code; GCR_BENCH_INIT_ONLY stops each rank after the rendezvous (no GPU)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["GCR_BENCH_INIT_ONLY"] = "1"
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    rec = json.loads(lines[0])
+    assert rec["dist_world"] == 2 and rec["ranks_seen"] == 2

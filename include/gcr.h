@@ -334,6 +334,29 @@ int32_t gcr_infonce_pos_bwd_f32(const float* x, const float* x_scale, const floa
 int32_t gcr_normalize_bwd_f32(const float* x, const float* inv_norm, const float* ghat, int64_t n, int32_t d,
                               float* out, void* stream);
 
+/* Backward through `F.normalize(A x, p=2, dim=1)` from the SAVED NORMALISED rows n = normalize(z) and inv = 1 / max(|z|, eps)
+ * (what gcr_spmm_csr_f32 / _dual_f32 write with GCR_SPMM_ROW_L2NORM; sept.py:223-224, mhcn.py:440-457):
+ *   out = (g_n - n <n, g_n>) * inv + g_raw          g_raw optional (the gradient of the raw product, mhcn.py:440-442)
+ * one pass; out may alias g_n or g_raw.  d a multiple of 4, <= 256. */
+int32_t gcr_normalize_bwd_n_f32(const float* n_rows_normalised, const float* inv_norm, const float* g_n,
+                                const float* g_raw, int64_t rows, int32_t d, float* out, void* stream);
+
+/* out[dx, dg] = X^T G for tall row-major X [n, dx], G [n, dg]: the weight gradient of `em @ W` in MHCN's gating /
+ * attention (mhcn.py:404-420; W is d x d, n = #users), rows split over the chip on the f32 MFMA, partials summed in a
+ * fixed order (bitwise reproducible).  dx, dg in {32, 64, 96, 128} (GCR_EUNSUPPORTED otherwise). */
+int64_t gcr_gram_tn_workspace_bytes(int64_t n, int32_t dx, int32_t dg);
+int32_t gcr_gram_tn_f32(const float* x, const float* g, int64_t n, int32_t dx, int32_t dg, float* out, void* workspace,
+                        void* stream);
+
+/* out[r] = <x[r, :], v> for row-major x [n, d], v [d] — the channel-attention logits of mhcn.py:414 as one product per channel. */
+int32_t gcr_rows_dot_vec_f32(const float* x, const float* v, int64_t n, int32_t d, float* out, void* stream);
+
+/* out[c] = sum_r w[r] * x[r][c] for tall x [n, d], w [n] (d <= 256): the gradient of v in the channel-attention logits
+ * `em @ v` (mhcn.py:414 with v = attention_mat attention^T); fixed-order partial sums. */
+int64_t gcr_weighted_colsum_workspace_bytes(int64_t n, int32_t d);
+int32_t gcr_weighted_colsum_f32(const float* x, const float* w, int64_t n, int32_t d, float* out, void* workspace,
+                                void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * BCE-with-logits over the all-pairs score matrix — the `loss_type == "bce"` branch of LightGCN's training step:
  *   scores = torch.matmul(user_vecs, item_emb.t()); labels = one-hot at pos_i;                 lightgcn.py:110-112

@@ -56,6 +56,12 @@ SIGNATURES = {
     "gcr_infonce_bwd_ex_f32": (c_int32, [_P, _P, c_int64, _P, _P, c_int64, c_int32, c_float, _P, _P, _P, _P, _P, _P, c_uint32, _P]),
     "gcr_infonce_pos_bwd_f32": (c_int32, [_P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int32, c_float, _P, _P, _P]),
     "gcr_normalize_bwd_f32": (c_int32, [_P, _P, _P, c_int64, c_int32, _P, _P]),
+    "gcr_normalize_bwd_n_f32": (c_int32, [_P, _P, _P, _P, c_int64, c_int32, _P, _P]),
+    "gcr_gram_tn_workspace_bytes": (c_int64, [c_int64, c_int32, c_int32]),
+    "gcr_gram_tn_f32": (c_int32, [_P, _P, c_int64, c_int32, c_int32, _P, _P, _P]),
+    "gcr_rows_dot_vec_f32": (c_int32, [_P, _P, c_int64, c_int32, _P, _P]),
+    "gcr_weighted_colsum_workspace_bytes": (c_int64, [c_int64, c_int32]),
+    "gcr_weighted_colsum_f32": (c_int32, [_P, _P, c_int64, c_int32, _P, _P, _P]),
     "gcr_bce_fwd_o_supported": (c_int32, [c_int32, c_uint32]),
     "gcr_bce_fwd_workspace_bytes": (c_int64, [c_int64, c_int64, c_int32]),
     "gcr_bce_fwd_f32": (c_int32, [_P, c_int64, _P, c_int64, c_int32, _P, _P, _P, c_uint32, _P]),

@@ -457,10 +457,13 @@ class _ShardedChannelLayer(torch.autograd.Function):
             g_raw, g_nrm = gs[2 * c], gs[2 * c + 1]
             nrm, inv = saved[2 * c], saved[2 * c + 1]
             dz = None
-            if g_nrm is not None:
+            if g_nrm is not None and nrm.is_cuda:
+                dz = Fn.normalize_bwd_n(nrm, inv, g_nrm, g_raw)        # one pass (gcr_normalize_bwd_n_f32)
+            elif g_nrm is not None:       # CPU stand-ins of the gloo choreography tests only
                 dz = (g_nrm - nrm * (nrm * g_nrm).sum(1, keepdim=True)) * inv.unsqueeze(1)
-            if g_raw is not None:
-                dz = g_raw if dz is None else dz + g_raw
+                dz = dz if g_raw is None else dz + g_raw
+            elif g_raw is not None:
+                dz = g_raw
             if dz is None:
                 dxs.append(None)
                 handles.append(None)

@@ -402,12 +402,8 @@ class _MultiStreamSpMM(torch.autograd.Function):
             dx = torch.empty(gt.n_rows, ref.shape[1], dtype=torch.float32, device=dev)
             s.wait_event(start)
             with torch.cuda.stream(s):
-                dz = None
-                if g_y is not None:       # through the row normalise: (g - y <y, g>) / max(||A x||, eps)
-                    dz = (g_y - y * (y * g_y).sum(1, keepdim=True)) * inv.unsqueeze(1)
-                if g_raw is not None:
-                    dz = g_raw if dz is None else dz + g_raw
-                dz = dz.contiguous()
+                # through the row normalise, one pass: (g - y <y, g>) / max(||A x||, eps) + g_raw
+                dz = Fn.normalize_bwd_n(y, inv, g_y, g_raw) if g_y is not None else g_raw.contiguous()
                 Fn.spmm_into(gt, dz, y=dx)
                 dz.record_stream(s)
             used.append(s)

@@ -208,6 +208,104 @@ def lightgcn_propagate(graph: CsrGraph, x0, n_layers: int, combine: str = "mean"
     return out
 
 
+def normalize_bwd_n(nrm, inv, g_n, g_raw=None, out=None):
+    """d(A x) of `F.normalize(A x)` from the saved normalised rows: (g_n - nrm <nrm, g_n>) * inv (+ g_raw) in ONE pass
+    (gcr_normalize_bwd_n_f32; sept.py:223-224, mhcn.py:440-457).  Rows clamped by eps have inv = 1e12 and nrm = 0.
+    `out` may be g_n or g_raw themselves (in place)."""
+    _lib.require_cuda(nrm, inv, g_n, g_raw, out)
+    g_n = g_n.contiguous()
+    g_raw = None if g_raw is None else g_raw.contiguous()
+    if out is None:
+        out = torch.empty_like(g_n)
+    rows, d = nrm.shape
+    if g_n.shape != nrm.shape or out.shape != nrm.shape or (g_raw is not None and g_raw.shape != nrm.shape) or d % 4 or d > 256:
+        raise ValueError("normalize_bwd_n: [rows, d] float32 tensors of one shape, d a multiple of 4 and <= 256")
+    _lib.check(_lib.lib().gcr_normalize_bwd_n_f32(_lib.dptr(nrm), _lib.dptr(inv), _lib.dptr(g_n), _lib.dptr(g_raw), rows, d,
+                                                  _lib.dptr(out), _lib.cur_stream(nrm.device)), "gcr_normalize_bwd_n_f32")
+    return out
+
+
+_GRAM_DIMS = (32, 64, 96, 128)
+
+
+def gram_tn(x, g):
+    """x^T g ([dx, dg]) for tall x [n, dx], g [n, dg] with the rows split over the whole chip (gcr_gram_tn_f32): the weight
+    gradient of `em @ W` (mhcn.py:404-420).  Widths outside {32, 64, 96, 128} go to the library GEMM."""
+    _lib.require_cuda(x, g)
+    x, g = x.contiguous(), g.contiguous()
+    n, dx = x.shape
+    dg = g.shape[1]
+    if dx not in _GRAM_DIMS or dg not in _GRAM_DIMS or g.shape[0] != n:
+        return x.t() @ g
+    L = _lib.lib()
+    out = torch.empty(dx, dg, dtype=torch.float32, device=x.device)
+    ws = torch.empty(max(int(L.gcr_gram_tn_workspace_bytes(n, dx, dg)), 4) // 4, dtype=torch.float32, device=x.device)
+    _lib.check(L.gcr_gram_tn_f32(_lib.dptr(x), _lib.dptr(g), n, dx, dg, _lib.dptr(out), _lib.dptr(ws), _lib.cur_stream(x.device)),
+               "gcr_gram_tn_f32")
+    return out
+
+
+class _DenseProj(torch.autograd.Function):
+    """em @ W for a tall em [n, d] and a small square-ish W (MHCN's gating / attention, mhcn.py:404-420): forward and
+    d em stay library GEMMs (n is the large dimension: they tile well); dW = em^T g is `gram_tn`."""
+
+    @staticmethod
+    def forward(ctx, em, w):
+        ctx.save_for_backward(em, w)
+        return em @ w
+
+    @staticmethod
+    def backward(ctx, g):
+        em, w = ctx.saved_tensors
+        g = g.contiguous()
+        gem = g @ w.t() if ctx.needs_input_grad[0] else None
+        gw = gram_tn(em, g) if ctx.needs_input_grad[1] else None
+        return gem, gw
+
+
+def dense_proj(em, w):
+    """`torch.matmul(em, W)` of mhcn.py:405,409,414 with the weight gradient computed by a row-split kernel."""
+    if not em.is_cuda or em.dim() != 2 or w.dim() != 2 or em.dtype != torch.float32:
+        return em @ w
+    return _DenseProj.apply(em, w)
+
+
+class _RowsDotVec(torch.autograd.Function):
+    """em @ v for tall em [n, d] and v [d]: d em = g v^T (one write pass), d v = sum_r g_r em_r (gcr_weighted_colsum_f32:
+    the library's transposed GEMV of this shape ran 1.1 ms at n = 250K)."""
+
+    @staticmethod
+    def forward(ctx, em, v):
+        ctx.save_for_backward(em, v)
+        v = v.contiguous()
+        out = torch.empty(em.shape[0], dtype=torch.float32, device=em.device)
+        _lib.check(_lib.lib().gcr_rows_dot_vec_f32(_lib.dptr(em), _lib.dptr(v), em.shape[0], em.shape[1], _lib.dptr(out),
+                                                   _lib.cur_stream(em.device)), "gcr_rows_dot_vec_f32")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        em, v = ctx.saved_tensors
+        g = g.contiguous()
+        gem = torch.outer(g, v) if ctx.needs_input_grad[0] else None
+        gv = None
+        if ctx.needs_input_grad[1]:
+            L = _lib.lib()
+            n, d = em.shape
+            gv = torch.empty(d, dtype=torch.float32, device=em.device)
+            ws = torch.empty(max(int(L.gcr_weighted_colsum_workspace_bytes(n, d)), 4) // 4, dtype=torch.float32, device=em.device)
+            _lib.check(L.gcr_weighted_colsum_f32(_lib.dptr(em), _lib.dptr(g), n, d, _lib.dptr(gv), _lib.dptr(ws),
+                                                 _lib.cur_stream(em.device)), "gcr_weighted_colsum_f32")
+        return gem, gv
+
+
+def rows_dot_vec(em, v):
+    """`em @ v` ([n, d] x [d] -> [n]) with the row-split weighted column sum as the gradient of v."""
+    if not em.is_cuda or em.dim() != 2 or v.dim() != 1 or em.dtype != torch.float32 or em.shape[1] > 256:
+        return em @ v
+    return _RowsDotVec.apply(em.contiguous(), v)
+
+
 class _NormProp(torch.autograd.Function):
     """One SEPT layer: y = normalize(A x) row-wise (sept.py:223-224); saves y and 1/||Ax||."""
 
@@ -224,10 +322,10 @@ class _NormProp(torch.autograd.Function):
     def backward(ctx, dy):
         y, inv = ctx.saved_tensors
         # d(Ax) = (dy - y <y, dy>) / max(||Ax||, eps); rows clamped by eps have inv = 1e12 and y = 0
-        dz = (dy - y * (y * dy).sum(1, keepdim=True)) * inv.unsqueeze(1)
+        dz = normalize_bwd_n(y, inv, dy)
         gt = ctx.graph.t
         dx = torch.empty(gt.n_rows, dy.shape[1], dtype=torch.float32, device=dy.device)
-        spmm_into(gt, dz.contiguous(), y=dx)
+        spmm_into(gt, dz, y=dx)
         return dx, None
 
 
@@ -287,11 +385,7 @@ class _NormPropDual(torch.autograd.Function):
         if gz is None and gn is None:
             return None, None
         # dz = gz + (gn - n <n, gn>) / max(||z||, eps); rows clamped by eps have inv = 1e12 and n = 0
-        dz = None
-        if gn is not None:
-            dz = (gn - n * (n * gn).sum(1, keepdim=True)) * inv.unsqueeze(1)
-        if gz is not None:
-            dz = gz if dz is None else dz + gz
+        dz = normalize_bwd_n(n, inv, gn, gz) if gn is not None else gz
         gt = ctx.graph.t
         dx = torch.empty(gt.n_rows, dz.shape[1], dtype=torch.float32, device=dz.device)
         spmm_into(gt, dz.contiguous(), y=dx)

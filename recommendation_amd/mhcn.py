@@ -49,13 +49,16 @@ class MHCNEncoder(nn.Module):
 
     # -- dense pieces (mhcn.py:404-420) ---------------------------------------------------------
     def self_gating(self, em, channel):
-        return em * torch.sigmoid(em @ self.gating_weights[str(channel)] + self.gating_bias[str(channel)])
+        return em * torch.sigmoid(Fn.dense_proj(em, self.gating_weights[str(channel)]) + self.gating_bias[str(channel)])
 
     def self_supervised_gating(self, em, channel):
-        return em * torch.sigmoid(em @ self.sgating_weights[str(channel)] + self.sgating_bias[str(channel)])
+        return em * torch.sigmoid(Fn.dense_proj(em, self.sgating_weights[str(channel)]) + self.sgating_bias[str(channel)])
 
     def channel_attention(self, *channel_embeddings):
-        logits = torch.stack([(self.attention * (e @ self.attention_mat)).sum(1) for e in channel_embeddings])
+        # mhcn.py:414: sum(attention * (e @ attention_mat), 1) = e @ (attention_mat @ attention^T): one [U, d] x [d] product
+        # per channel instead of a [U, d] x [d, d] GEMM, a multiply and a row reduction (and their three backward passes)
+        v = (self.attention_mat @ self.attention.t()).squeeze(1)
+        logits = torch.stack([Fn.rows_dot_vec(e, v) for e in channel_embeddings])
         score = torch.softmax(logits, dim=0)
         mixed = sum(score[k].unsqueeze(1) * e for k, e in enumerate(channel_embeddings))
         return mixed, score

@@ -112,3 +112,76 @@ def test_gather_rows_forward_and_scatter_backward(n, d, b):
     (yb * w).sum().backward()
     tol = 1e-6 * max(float(ta.grad.abs().max()), 1.0) if b else 0.0
     assert float((ta.grad - tb.grad).abs().max()) <= tol
+
+
+@pytest.mark.parametrize("d", [64, 32, 128, 100])
+@pytest.mark.parametrize("with_raw", [False, True])
+def test_normalize_bwd_n_one_pass(d, with_raw):
+    """gcr_normalize_bwd_n_f32 = (g - n <n, g>) * inv (+ g_raw) against float64, incl. an eps-clamped (all-zero) row and
+    in-place output."""
+    from recommendation_amd import functional as Fn
+    rng = np.random.default_rng(d)
+    z = rng.standard_normal((1003, d)).astype(np.float32)
+    z[17] = 0.0
+    norm = np.maximum(np.linalg.norm(z.astype(np.float64), axis=1, keepdims=True), 1e-12)
+    n, inv = (z / norm).astype(np.float32), (1.0 / norm[:, 0]).astype(np.float32)
+    g = rng.standard_normal((1003, d)).astype(np.float32)
+    graw = rng.standard_normal((1003, d)).astype(np.float32) if with_raw else None
+    n64, g64 = n.astype(np.float64), g.astype(np.float64)
+    ref = (g64 - n64 * (n64 * g64).sum(1, keepdims=True)) * inv.astype(np.float64)[:, None]
+    if with_raw:
+        ref = ref + graw
+    tn, ti, tg = (torch.from_numpy(a).cuda() for a in (n, inv, g))
+    tr = torch.from_numpy(graw).cuda() if with_raw else None
+    out = Fn.normalize_bwd_n(tn, ti, tg, tr)
+    live = np.arange(1003) != 17                              # (row 17: inv = 1e12 times a rounding residue: not compared)
+    np.testing.assert_allclose(out.cpu().numpy()[live], ref[live], rtol=1e-5, atol=1e-5 * np.abs(ref[live]).max())
+    assert torch.equal(Fn.normalize_bwd_n(tn, ti, tg.clone(), tr, out=tg), out)
+
+
+@pytest.mark.parametrize("n", [1, 255, 1000, 70001])
+@pytest.mark.parametrize("dx,dg", [(64, 64), (32, 128), (96, 32), (128, 128)])
+def test_gram_tn(n, dx, dg):
+    """x^T g with the rows split over the chip (gcr_gram_tn_f32: the weight gradient of MHCN's `em @ W`) vs float64."""
+    from recommendation_amd import functional as Fn
+    rng = np.random.default_rng(n + dx)
+    x = rng.standard_normal((n, dx)).astype(np.float32)
+    g = rng.standard_normal((n, dg)).astype(np.float32)
+    out = Fn.gram_tn(torch.from_numpy(x).cuda(), torch.from_numpy(g).cuda())
+    ref = x.astype(np.float64).T @ g.astype(np.float64)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=2e-6 * np.sqrt(n) * 4)
+    again = Fn.gram_tn(torch.from_numpy(x).cuda(), torch.from_numpy(g).cuda())
+    assert torch.equal(out, again)                            # fixed-order partial sums: bitwise reproducible
+
+
+def test_dense_proj_gradients():
+    from recommendation_amd import functional as Fn
+    torch.manual_seed(0)
+    em = torch.randn(5000, 64, device="cuda", requires_grad=True)
+    w = torch.randn(64, 64, device="cuda", requires_grad=True)
+    up = torch.randn(5000, 64, device="cuda")
+    (Fn.dense_proj(em, w) * up).sum().backward()
+    ge, gw = em.grad.clone(), w.grad.clone()
+    em.grad = w.grad = None
+    ((em.double() @ w.double()) * up.double()).sum().backward()
+    np.testing.assert_allclose(ge.cpu().numpy(), em.grad.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(em.grad.abs().max()))
+    np.testing.assert_allclose(gw.cpu().numpy(), w.grad.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(w.grad.abs().max()))
+
+
+@pytest.mark.parametrize("n,d", [(1, 64), (1000, 64), (70001, 64), (5000, 48), (3000, 128), (777, 3)])
+def test_rows_dot_vec_gradients(n, d):
+    """`em @ v` with gcr_weighted_colsum_f32 as the gradient of v, vs float64."""
+    from recommendation_amd import functional as Fn
+    torch.manual_seed(n)
+    em = torch.randn(n, d, device="cuda", requires_grad=True)
+    v = torch.randn(d, device="cuda", requires_grad=True)
+    up = torch.randn(n, device="cuda")
+    out = Fn.rows_dot_vec(em, v)
+    (out * up).sum().backward()
+    ge, gv = em.grad.clone(), v.grad.clone()
+    em.grad = v.grad = None
+    ref = em.double() @ v.double()
+    (ref * up.double()).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(ge.cpu().numpy(), em.grad.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(gv.cpu().numpy(), v.grad.cpu().numpy(), rtol=1e-4, atol=2e-6 * np.sqrt(n) * 4)

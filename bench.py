@@ -1159,8 +1159,12 @@ def ncl_step_legs(Fn, graph, x0, k_layers, n_u, n_i, uidx, iidx, jn, timeit):
     out["ncl_train_step_full_ms"] = leg(300, True, True)
     out["ncl_train_step_full"] = {
         "what": "NCLModel.train_step = the loop body ncl.py:311-329 INCLUDING the per-batch e_step (ncl.py:324,340-356: k-means "
-                "of all users and of all items, faiss defaults niter 25 / 256 points per centroid / seed 1234, + assignment of "
-                "every row), B = 2048, 3 layers, d = 64, 1M users x 100K items / 10M interactions, sym-normalised operator",
+                "of all users and of all items, faiss defaults niter 25 / 256 points per centroid / seed 1234), B = 2048, 3 "
+                "layers, d = 64, 1M users x 100K items / 10M interactions, sym-normalised operator.  Assignment: the fused legs "
+                "(k*_graph_ms, k*_eager_ms) search only the step's own 2 x B batch rows — the only assignments the iteration "
+                "reads (ncl.py:370-373); the reference's full-table index.search (ncl.py:355) is computed lazily when "
+                "user_2cluster / item_2cluster is read.  The autograd leg (k300_autograd_ms) runs the full N x k search every "
+                "step, as the reference does: the legs time the same training step, not the same assignment work",
         "k300_graph_ms": out["ncl_train_step_full_ms"],
         "k300_eager_ms": leg(300, True, False),
         "k300_autograd_ms": leg(300, False, False, reps=3),

@@ -26,12 +26,22 @@ def encode_raw_ids(values):
     the order Python's `sorted()` gives the ids (ncl.py:60-61): integers by value, strings by code point (= by UTF-8
     byte, packed big-endian eight bytes per word, NUL-padded: a prefix sorts first).  None: ids of another type (the
     caller then keeps the host dict path)."""
-    if not all(isinstance(v, (str, int, np.integer, np.str_)) and not isinstance(v, bool) for v in values[:64]):
-        return None
+    if not (isinstance(values, np.ndarray) and values.dtype.kind in "iuUS"):
+        # decided from the WHOLE column: np.asarray would silently turn a mixed int / str column into strings (ints then
+        # sort as text), where the reference's sorted() raises a TypeError — such a column keeps the host dict path
+        kinds = set(map(type, values))
+        if not kinds or any(issubclass(k, bool) or isinstance(k, type(None)) for k in kinds):
+            return None
+        is_int = all(issubclass(k, (int, np.integer)) for k in kinds)
+        is_str = all(issubclass(k, (str, np.str_)) for k in kinds)
+        if not (is_int or is_str):
+            return None
     arr = np.asarray(values)
     if arr.ndim != 1 or arr.shape[0] != len(values):
         return None
     if arr.dtype.kind in "iu":
+        if arr.dtype.kind == "u" and arr.size and int(arr.max()) >= 1 << 63:
+            return None                                     # would wrap in int64: host dict path
         return (arr.astype(np.int64).view(np.uint64) ^ np.uint64(1 << 63)).reshape(-1, 1)
     if arr.dtype.kind == "U":
         arr = np.char.encode(arr, "utf-8")
@@ -110,10 +120,12 @@ class Interaction(_LazyMaps):
     On a GPU device the id maps are built there (gcr_dense_ids_u64: radix sort + head flags + scan over the encoded id
     columns) — the Python dicts of the reference become lazily built views.
     reorder="spectral": the dense ids are additionally re-numbered for gather locality (reorder.py); `perm_user` /
-    `perm_item` hold reference id -> id used here, and every id this object hands out is the re-numbered one."""
+    `perm_item` hold reference id -> id used here, and every id this object hands out is the re-numbered one.  With
+    `reorder_guard` (default) the renumbering skips itself — `perm_user` stays None, `reorder_decision` says why — when
+    the graph fits the caches, its spectrum shows no community direction, or the renumbered operator measures no faster."""
 
     def __init__(self, conf, train, test, device=None, normalised=False, id_order="sorted", reorder=None,
-                 rows_per_cluster=None):
+                 rows_per_cluster=None, reorder_guard=True):
         self.train, self.test = train, test
         self.device = _device(device)
         if id_order not in ("sorted", "first_seen"):
@@ -142,13 +154,24 @@ class Interaction(_LazyMaps):
         if reorder is not None:
             if reorder != "spectral" or self.device.type != "cuda":
                 raise ValueError("reorder must be None or 'spectral' (GPU device)")
-            from .reorder import DEFAULT_ROWS_PER_CLUSTER, locality_permutation
-            pu, pi, row_group = locality_permutation(uid, iid, self.user_num, self.item_num, self.device,
-                                                     rows_per_cluster or DEFAULT_ROWS_PER_CLUSTER)
-            uid, iid = pu[uid], pi[iid]
-            self.perm_user, self.perm_item = pu.cpu().numpy(), pi.cpu().numpy()
-            self._users_raw = [u for _, u in sorted(zip(self.perm_user.tolist(), self._users_raw))]
-            self._items_raw = [i for _, i in sorted(zip(self.perm_item.tolist(), self._items_raw))]
+            from .reorder import DEFAULT_ROWS_PER_CLUSTER, guarded_locality_permutation, locality_permutation
+            rpc = rows_per_cluster or DEFAULT_ROWS_PER_CLUSTER
+            if reorder_guard:
+                # the renumbering must never slow a graph down: it skips itself (reason in `reorder_decision`, logged) on
+                # a graph that fits the caches, whose spectrum shows no community direction, or that measures no faster
+                pu, pi, row_group, self.reorder_decision = guarded_locality_permutation(
+                    uid, iid, self.user_num, self.item_num, self.device, rpc)
+                import logging
+                logging.getLogger("recommendation_amd").info("reorder='spectral': %s (%s)", "applied" if pu is not None
+                                                             else "skipped", self.reorder_decision["reason"])
+            else:
+                pu, pi, row_group = locality_permutation(uid, iid, self.user_num, self.item_num, self.device, rpc)
+                self.reorder_decision = {"applied": True, "reason": "reorder_guard=False"}
+            if pu is not None:
+                uid, iid = pu[uid], pi[iid]
+                self.perm_user, self.perm_item = pu.cpu().numpy(), pi.cpu().numpy()
+                self._users_raw = [u for _, u in sorted(zip(self.perm_user.tolist(), self._users_raw))]
+                self._items_raw = [i for _, i in sorted(zip(self.perm_item.tolist(), self._items_raw))]
         self.test_set = {}
         for t in test:
             self.test_set.setdefault(t[0], {})[t[1]] = 1
@@ -213,18 +236,50 @@ class LGCNEncoder(nn.Module):
             "item_emb": nn.Parameter(self.table[n_u:]),
         })
 
+    def _aliased(self):
+        u, i = self.embedding_dict["user_emb"], self.embedding_dict["item_emb"]
+        t = self.table
+        return t.device == u.device and t.dtype == u.dtype and t.shape[0] == u.shape[0] + i.shape[0] and \
+            u.data_ptr() == t.data_ptr() and i.data_ptr() == t.data_ptr() + u.numel() * t.element_size() and \
+            u.is_contiguous() and i.is_contiguous()
+
+    def restack(self):
+        """Re-establishes `table` as the storage of the two parameters when something replaced theirs — `.to()` / `.cuda()`,
+        `copy.deepcopy` (a target-encoder copy, bgrl_g2l.py:548-style), `load_state_dict(assign=True)`, a bare
+        `param.data = ...`: the parameters win (they are what the optimiser and the state dict see), the table is rebuilt
+        from them and they become views of it again.  Cheap when nothing changed (two pointer comparisons)."""
+        if not self._aliased():
+            u, i = self.embedding_dict["user_emb"], self.embedding_dict["item_emb"]
+            with torch.no_grad():
+                self.table = torch.cat([u.data, i.data], 0)
+                u.data, i.data = self.table[: u.shape[0]], self.table[u.shape[0]:]
+        return self.table
+
     def _apply(self, fn, *args, **kwargs):
         # .to() / .cuda() / .float() re-create the parameters one by one: re-establish the stacked buffer afterwards
         super()._apply(fn, *args, **kwargs)
-        u, i = self.embedding_dict["user_emb"], self.embedding_dict["item_emb"]
-        if self.table.device != u.device or self.table.dtype != u.dtype or u.data_ptr() != self.table.data_ptr():
-            self.table = torch.cat([u.data, i.data], 0)
-            u.data, i.data = self.table[: u.shape[0]], self.table[u.shape[0]:]
+        self.restack()
         return self
 
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            # graph handles are shared, not copied (device-resident CSR + plan; immutable for the encoder)
+            new.__dict__[k] = v if k in ("data", "norm_adj") else copy.deepcopy(v, memo)
+        new.restack()
+        return new
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.restack()
+        return out
+
     def stacked(self):
-        """The [U + I, d] embedding table as an autograd alias of the two parameters."""
-        return _StackedTable.apply(self.embedding_dict["user_emb"], self.embedding_dict["item_emb"], self.table)
+        """The [U + I, d] embedding table as an autograd alias of the two parameters (re-stacked first if the parameters'
+        storage was replaced behind the table's back: a stale table would train nothing, silently)."""
+        return _StackedTable.apply(self.embedding_dict["user_emb"], self.embedding_dict["item_emb"], self.restack())
 
     def forward(self):
         emb = self.stacked()

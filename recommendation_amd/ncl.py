@@ -36,13 +36,14 @@ _CONF_DEFAULTS = {"batch_size": ("batch.size", 2048), "emb_size": ("embedding.si
 
 class NCLModel:
     def __init__(self, conf, train_set, test_set, device=None, seed=0, kmeans_niter=FAISS_NITER, kmeans_seed=FAISS_SEED,
-                 fused_step=True, graph_capture=False, reorder=None):
+                 fused_step=True, graph_capture=False, reorder=None, reorder_guard=True):
         """kmeans_niter / kmeans_seed: the two parameters of `faiss.Kmeans(d, k, gpu=False)` that ncl.py:352 leaves at
         faiss' defaults (ClusteringParameters: niter = 25, seed = 1234; see kmeans.py for provenance — faiss is absent,
         parity with it unpinned), explicit here.  fused_step: run the loop body as the hand-derived launch sequence of
         ncl_step.FusedNCLStep when the configuration allows it (same arithmetic as the autograd path);
         graph_capture: replay that sequence from a hipGraph.  reorder="spectral": locality renumbering of users / items
-        (reorder.py; ids stay consistent everywhere because every id comes from `self.data`)."""
+        (reorder.py; ids stay consistent everywhere because every id comes from `self.data`; with reorder_guard it skips
+        itself on graphs it cannot speed up, `self.data.reorder_decision`)."""
         self.config, self.seed = conf, seed
         self.kmeans_niter, self.kmeans_seed = int(kmeans_niter), int(kmeans_seed)
         self.fused_step, self.graph_capture = bool(fused_step), bool(graph_capture)
@@ -57,7 +58,7 @@ class NCLModel:
         # `train_set` may be a prepared data object (user_num, item_num, norm_adj, device, ...) instead of the triple list:
         # NCLModel.from_graph builds one around a device-resident operator (graphs too large for Python id maps)
         self.data = train_set if hasattr(train_set, "norm_adj") else Interaction(conf, train_set, test_set, device=device,
-                                                                                  reorder=reorder)
+                                                                                  reorder=reorder, reorder_guard=reorder_guard)
         self.model = LGCNEncoder(self.data, self.emb_size, self.n_layers)
         self.user_centroids = self.item_centroids = None
         self._user_2cluster = self._item_2cluster = self._e_inputs = None

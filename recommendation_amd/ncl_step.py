@@ -87,7 +87,10 @@ class FusedNCLStep:
         o_ = self.owner
         enc, graph, n_u, n_i = self.enc, self.graph, self.n_u, self.n_i
         L = _lib.lib()
-        x0 = enc.table
+        if self._cuda_graph is not None and not enc._aliased():
+            raise RuntimeError("the encoder's parameters were re-bound (deepcopy / load_state_dict(assign=True) / .data = ...) "
+                               "after this step was captured: call capture() again")
+        x0 = enc.restack()                 # the parameters' storage IS the table (re-stacked if something replaced it)
         dev = x0.device
         n, d = x0.shape
         K = enc.layers
@@ -313,6 +316,10 @@ class FusedNCLStep:
         dev = self.enc.table.device
         if not all(g.get("capturable") for g in self.opt.param_groups):
             raise ValueError("capture() needs FusedAdam(capturable=True)")
+        if int(warmup) < 1:
+            # the first step allocates optimiser state, cached k-means index vectors and the allocator's pools: captured,
+            # those allocations would become graph nodes that every replay repeats
+            raise ValueError("capture() needs at least one eager warm-up step")
         z = torch.zeros(int(batch_size), dtype=torch.int64, device=dev)
         self._static = [z.clone(), z.clone(), z.clone()]
         self._cuda_graph, self._warm, self._warmup, self._out = None, 0, int(warmup), None
@@ -326,6 +333,8 @@ class FusedNCLStep:
         st = self._static
         if st is None:
             raise RuntimeError("call capture(batch_size) first")
+        if self._cuda_graph is not None and not self.enc._aliased():
+            raise RuntimeError("the encoder's parameters were re-bound after this step was captured: call capture() again")
         dev = st[0].device
         for dst, src in zip(st, (user_idx, pos_idx, neg_idx)):
             dst.copy_(torch.as_tensor(src, device=dev), non_blocking=True)

@@ -36,9 +36,14 @@ class FusedAdam(torch.optim.Optimizer):
                     raise ValueError("FusedAdam needs contiguous float32 parameters")
                 st = self.state[p]
                 if not st:
+                    if torch.cuda.is_current_stream_capturing():
+                        raise RuntimeError("FusedAdam: the first step() must run eagerly (it allocates the state; inside a "
+                                           "stream capture the allocation and the zero count would be replayed every time)")
                     st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p)
                     st["exp_avg_sq"] = torch.zeros_like(p)
+                    if group.get("capturable"):            # device-side step count, allocated with the rest of the state
+                        st["step_dev"] = torch.zeros(1, dtype=torch.int64, device=p.device)
                 st["step"] += 1
                 extra = list((extra_grads or {}).get(p, []))
                 if len(extra) > 2:
@@ -46,7 +51,9 @@ class FusedAdam(torch.optim.Optimizer):
                 g = p.grad.contiguous()
                 ex = [e.contiguous() for e in extra] + [None, None]
                 if group.get("capturable"):
-                    if "step_dev" not in st:
+                    if "step_dev" not in st:               # state loaded from a non-capturable run
+                        if torch.cuda.is_current_stream_capturing():
+                            raise RuntimeError("FusedAdam: no device step count yet; run one eager step() before capturing")
                         st["step_dev"] = torch.full((1,), st["step"] - 1, dtype=torch.int64, device=p.device)
                     st["step_dev"].add_(1)
                     _lib.check(L.gcr_adam_step_dev_f32(_lib.dptr(p), _lib.dptr(g), _lib.dptr(ex[0]), _lib.dptr(ex[1]),
@@ -61,3 +68,14 @@ class FusedAdam(torch.optim.Optimizer):
                                                float(group["weight_decay"]), int(st["step"]), 1.0, _lib.cur_stream(p.device)),
                            "gcr_adam_step_f32")
         return loss
+
+    def sync_step_counts(self):
+        """Host step counts <- device step counts (one read-back per capturable parameter): graph replays advance only the
+        device counter.  `state_dict()` calls it, so that a checkpoint resumed on either path gets the right bias corrections."""
+        for st in self.state.values():
+            if "step_dev" in st:
+                st["step"] = int(st["step_dev"].item())
+
+    def state_dict(self):
+        self.sync_step_counts()
+        return super().state_dict()

@@ -33,8 +33,11 @@ DEFAULT_ROWS_PER_CLUSTER = 8192       # 8192 x 256 B = 2 MB of user rows: half o
 
 
 def spectral_labels(uid, iid, n_users, n_items, device, n_clusters, dim=64, iters=14, reortho_every=4, seed=0,
-                    graph=None):
-    """int64 [n_users + n_items] co-cluster label of every user and item (device tensor)."""
+                    graph=None, min_structure=None, info=None):
+    """int64 [n_users + n_items] co-cluster label of every user and item (device tensor).
+    min_structure: give up BEFORE the k-means (return (None, deg)) when the largest Ritz value of the iterated subspace is
+    below `min_structure` x the noise bulk edge of a structureless graph with these mean degrees (`noise_bulk_edge`): no
+    community direction stands out of the bulk, no numbering can help.  info: a dict that receives the evidence."""
     dev = torch.device(device)
     n = n_users + n_items
     g = graph if graph is not None else CsrGraph.bipartite_sym_norm(uid, iid, n_users, n_items, dev)
@@ -62,6 +65,12 @@ def spectral_labels(uid, iid, n_users, n_items, device, n_clusters, dim=64, iter
     Fn.spmm_into(g, x, y=ax)
     m = (x.t() @ ax).double().cpu()
     evals, evecs = torch.linalg.eigh((m + m.t()) / 2)                    # Rayleigh-Ritz on the iterated subspace
+    bulk = noise_bulk_edge(n_users, n_items, g.nnz // 2)
+    if info is not None:
+        info.update(ritz_top=round(float(evals.max()), 4), ritz_median=round(float(evals.median()), 4),
+                    noise_bulk_edge=round(bulk, 4))
+    if min_structure is not None and float(evals.max()) < float(min_structure) * bulk:
+        return None, deg
     keep = evecs[:, evals > max(0.05, float(evals.max()) * 0.25)]        # drop directions that are still noise
     if keep.shape[1] < 2:
         keep = evecs[:, -min(dim, 8):]
@@ -71,6 +80,15 @@ def spectral_labels(uid, iid, n_users, n_items, device, n_clusters, dim=64, iter
     z = z / z.norm(dim=1, keepdim=True).clamp_min(1e-20)
     _, labels = run_kmeans(z.contiguous(), int(n_clusters), niter=15, seed=int(seed) + 1)
     return labels, deg
+
+
+def noise_bulk_edge(n_users, n_items, n_edges):
+    """Edge of the singular-value bulk of D_u^-1/2 R D_i^-1/2 for a bipartite graph WITHOUT structure (edges independent
+    given the degrees): 1 / sqrt(mean user degree) + 1 / sqrt(mean item degree) (Marchenko-Pastur scaling of a random
+    rectangular matrix with these row / column sums).  Community directions of a planted partition with in-community
+    probability p sit near p, far above it when p is large."""
+    du, di = max(n_edges / max(n_users, 1), 1e-9), max(n_edges / max(n_items, 1), 1e-9)
+    return du ** -0.5 + di ** -0.5
 
 
 def order_from_labels(labels, deg, n_users):
@@ -127,3 +145,55 @@ def xcd_grouped_order(desc_host, row_group_host, n_xcd=8, waves_per_block=4):
         padded[: l.size] = l
         order[:, x, :] = padded.reshape(blocks, waves_per_block)
     return order.reshape(-1)
+
+
+def _layer_ms(graph, x, reps=3):
+    y = torch.empty_like(x)
+    Fn.spmm_into(graph, x, y=y)
+    torch.cuda.synchronize(x.device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        Fn.spmm_into(graph, x, y=y)
+    e1.record()
+    torch.cuda.synchronize(x.device)
+    return e0.elapsed_time(e1) / reps
+
+
+def guarded_locality_permutation(uid, iid, n_users, n_items, device, rows_per_cluster=DEFAULT_ROWS_PER_CLUSTER, seed=0,
+                                 min_structure=0.9, min_gain=0.03, d=64, graph=None):
+    """`locality_permutation` that can say no: returns (perm_user, perm_item, group, decision) with the three tensors None
+    when the renumbering is NOT to be applied.  It must never slow a graph down, so it is kept only if
+      1. the graph is larger than the caches a numbering could help with (>= 4 clusters of `rows_per_cluster` rows),
+      2. the Ritz spectrum of the subspace iteration reaches the noise bulk of a structureless graph (`min_structure` x
+         `noise_bulk_edge`, checked before the k-means is paid for; measured at cfg2 sizes, scripts/perf_reorder.py --sweep:
+         uniform 0.86 x the edge, planted communities with p_in = 0.5 / 0.7 / 0.85 at 1.03 / 1.67 / 2.06 x — the threshold
+         only weeds out the clearly structureless, the measurement below decides the rest), and
+      3. MEASURED: one SpMM layer (d columns) on the renumbered operator with its XCD-grouped plan is at least `min_gain`
+         faster than on the operator as it came.
+    decision: {"applied": bool, "reason": str, ...evidence} — logged by the caller."""
+    dev = torch.device(device)
+    decision = {"applied": False}
+    n_clusters = max(2, -(-int(n_users) // int(rows_per_cluster)))
+    if n_clusters < 4:
+        decision["reason"] = f"{n_users} user rows are {n_clusters} cluster(s) of {rows_per_cluster}: the tables fit the caches"
+        return None, None, None, decision
+    g0 = graph if graph is not None else CsrGraph.bipartite_sym_norm(uid, iid, n_users, n_items, dev)
+    labels, deg = spectral_labels(uid, iid, n_users, n_items, dev, n_clusters, seed=seed, graph=g0,
+                                  min_structure=min_structure, info=decision)
+    if labels is None:
+        decision["reason"] = ("largest Ritz value %.3f is below %.2f x the noise bulk edge %.3f of a structureless graph with "
+                              "these degrees: no community direction to number by" %
+                              (decision["ritz_top"], min_structure, decision["noise_bulk_edge"]))
+        return None, None, None, decision
+    pu, pi, group = order_from_labels(labels, deg, n_users)
+    u, i = torch.as_tensor(uid, device=dev), torch.as_tensor(iid, device=dev)
+    g1 = CsrGraph.bipartite_sym_norm(pu[u], pi[i], n_users, n_items, dev, row_group=group)
+    x = torch.randn(n_users + n_items, d, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+    t0, t1 = _layer_ms(g0, x), _layer_ms(g1, x)
+    decision.update(ms_per_layer_before=round(t0, 4), ms_per_layer_after=round(t1, 4))
+    if t1 > (1.0 - min_gain) * t0:
+        decision["reason"] = "measured: %.3f -> %.3f ms per layer is not a gain of %.0f %%" % (t0, t1, 100 * min_gain)
+        return None, None, None, decision
+    decision.update(applied=True, reason="measured: %.3f -> %.3f ms per layer" % (t0, t1))
+    return pu, pi, group, decision

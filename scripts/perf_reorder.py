@@ -14,7 +14,7 @@ import bench  # noqa: E402
 import recommendation_amd as ra  # noqa: E402
 from recommendation_amd import functional as Fn, reorder as R  # noqa: E402
 
-a = [float(x) for x in sys.argv[1:]]
+a = [float(x) for x in sys.argv[1:] if not x.startswith("--")]
 n_u, n_i, n_e = (int(a[0]), int(a[1]), int(a[2])) if len(a) >= 3 else (1_000_000, 100_000, 10_000_000)
 n_comm = int(a[3]) if len(a) > 3 else 128
 p_in = a[4] if len(a) > 4 else 0.85
@@ -69,3 +69,25 @@ g3 = build(pu3, pi3, group3)
 print("hidden labels + grouped: %.3f ms / layer" % layer_ms(g3))
 g4 = build(pu3, pi3, None)
 print("hidden labels, plain:    %.3f ms / layer" % layer_ms(g4))
+
+# --- robustness sweep: weaker structure and none at all, guard decisions included --------------
+if "--sweep" in sys.argv:
+    import json
+    rows = []
+    for tag, pin in (("uniform", None), ("p_in=0.5", 0.5), ("p_in=0.7", 0.7), ("p_in=0.85", 0.85)):
+        if pin is None:
+            uu, ii = bench.synth_interactions_device(n_u, n_i, n_e, bench.SEED, dev)
+        else:
+            uu, ii, _, _ = bench.synth_community_interactions_device(n_u, n_i, n_e, bench.SEED, dev, max(2, n_u // 8192), pin)
+        gg = ra.CsrGraph.bipartite_sym_norm(uu, ii, n_u, n_i, dev)
+        t_b = layer_ms(gg)
+        ppu, ppi, grp = R.locality_permutation(uu, ii, n_u, n_i, dev, graph=gg)          # forced
+        gf = ra.CsrGraph.bipartite_sym_norm(ppu[uu], ppi[ii], n_u, n_i, dev, row_group=grp)
+        t_f = layer_ms(gf)
+        del gf
+        _, _, _, dec = R.guarded_locality_permutation(uu, ii, n_u, n_i, dev, graph=gg)
+        rows.append({"graph": tag, "ms_per_layer_as_is": round(t_b, 4), "ms_per_layer_forced_renumbering": round(t_f, 4),
+                     "guard": dec})
+        print(json.dumps(rows[-1]))
+        del gg
+        torch.cuda.empty_cache()

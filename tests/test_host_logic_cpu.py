@@ -124,3 +124,42 @@ def test_bench_gpus_n_starts_its_own_ranks():
     assert len(lines) == 1, res.stdout
     rec = json.loads(lines[0])
     assert rec["dist_world"] == 2 and rec["ranks_seen"] == 2
+
+
+def test_lgcn_encoder_table_follows_rebound_parameters():
+    """`LGCNEncoder.table` is what the propagation reads and the two Parameters are views of it — by construction
+    only.  deepcopy, load_state_dict(assign=True) and a bare `.data = ...` re-bind the parameters' storage; the encoder
+    must re-stack (never read a stale table)."""
+    import copy
+    import types
+    import torch
+    from recommendation_amd.encoders import LGCNEncoder
+    data = types.SimpleNamespace(user_num=5, item_num=3, device=torch.device("cpu"), norm_adj=None)
+    enc = LGCNEncoder(data, 8, 2)
+
+    def aliased(e):
+        u, i = e.embedding_dict["user_emb"], e.embedding_dict["item_emb"]
+        return u.data_ptr() == e.table.data_ptr() and i.data_ptr() == e.table[5:].data_ptr()
+
+    assert aliased(enc)
+    twin = copy.deepcopy(enc)
+    assert aliased(twin) and twin.table.data_ptr() != enc.table.data_ptr()
+    assert torch.equal(twin.table, enc.table) and twin.norm_adj is enc.norm_adj
+    with torch.no_grad():
+        twin.embedding_dict["user_emb"].add_(1.0)              # what an optimiser does to the copy's parameter
+    assert torch.equal(twin.table[:5], twin.embedding_dict["user_emb"].data) and not torch.equal(twin.table, enc.table)
+    sd = {k: v.clone() + 2.0 for k, v in enc.state_dict().items()}
+    enc.load_state_dict(sd, assign=True)
+    assert aliased(enc) and torch.equal(enc.table[5:], sd["embedding_dict.item_emb"])
+    enc.embedding_dict["user_emb"].data = torch.zeros(5, 8)
+    assert not enc._aliased()
+    assert torch.equal(enc.restack()[:5], torch.zeros(5, 8)) and aliased(enc)
+
+
+def test_encode_raw_ids_decides_from_the_whole_column():
+    import numpy as np
+    from recommendation_amd.encoders import encode_raw_ids
+    assert encode_raw_ids([3, 1, 2] * 40) is not None and encode_raw_ids(["b", "a"] * 70) is not None
+    assert encode_raw_ids([1] * 100 + ["7"]) is None           # mixed after position 64: sorted() would raise
+    assert encode_raw_ids(np.array([1, 2 ** 63 + 5], dtype=np.uint64)) is None
+    assert encode_raw_ids([True, False]) is None

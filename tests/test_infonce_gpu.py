@@ -3,6 +3,7 @@ reference-generated goldens.  Tolerance 1e-5 relative fp32 on the loss values (n
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from oracle import oracle_c as C
 from oracle import oracle_np as O
@@ -95,7 +96,7 @@ def _t(x, grad=False):
     return torch.from_numpy(np.ascontiguousarray(x)).cuda().requires_grad_(grad)
 
 
-def _gclose(t, ref, rel=1e-4, floor=1e-8):
+def _gclose(t, ref, rel=2e-5, floor=1e-8):
     got = t.detach().cpu().numpy().astype(np.float64)
     np.testing.assert_allclose(got, ref, rtol=rel, atol=max(1e-5 * np.abs(ref).max(), floor))
 
@@ -146,7 +147,30 @@ def test_golden_ncl_structure_and_prototype(Ls, golden, engine):
     assert float(ssl) == pytest.approx(float(c["ncl_ssl"]), rel=rel)
     ssl.backward()
     _gclose(ctx.grad, c["ncl_ssl_gctx"], floor=1e-12)
-    _gclose(x0.grad, c["ncl_ssl_gx0"], floor=1e-12)
+    # d / d x0 at the default 2e-5 does NOT hold against this golden on any engine, the exact f32 MFMA included (2-8 of
+    # 5120 elements off by up to 2.3e-4 of their value, 4e-5 of the largest element): the golden is the reference's own
+    # fp32 autograd result, whose softmax-minus-one-hot cancellation carries that much noise.  So: the golden at 2.5e-4,
+    # and the same expression (ncl.py:358-367) in float64 at the default.
+    _gclose(x0.grad, c["ncl_ssl_gx0"], rel=2.5e-4, floor=1e-12)
+    c64, x64 = _t(c["ncl_ctx"]).double().requires_grad_(True), _t(c["ncl_x0"]).double().requires_grad_(True)
+    ui, ii = _t(c["ncl_uidx"]), _t(c["ncl_iidx"])
+    tau = float(c["ncl_ssl_temp"])
+
+    def side(cur, init, idx):
+        nc, ni_all = F.normalize(cur[idx], dim=1), F.normalize(init, dim=1)
+        pos = (nc * ni_all[idx]).sum(1) / tau
+        return -(pos - torch.logsumexp(nc @ ni_all.T / tau, dim=1)).sum()
+
+    ref64 = float(c["ncl_ssl_reg"]) * (side(c64[:nu], x64[:nu], ui) + float(c["ncl_alpha"]) * side(c64[nu:], x64[nu:], ii))
+    ref64.backward()
+    assert float(ssl) == pytest.approx(float(ref64), rel=rel)
+    _gclose(ctx.grad, c64.grad.cpu().numpy(), floor=1e-12)
+    # ... where it holds to 1e-5 of the largest element for the context rows and to 5e-5 for d / d x0: the layer-0 rows'
+    # gradient goes through F.normalize's projection g - xhat <xhat, g>, and in this fixture the context rows are the
+    # layer-0 rows plus 10 % noise, so g is nearly parallel to xhat and the projection cancels an order of magnitude — f32
+    # rounding of g (1e-6) shows up at ~1.6e-5 of the result on every engine (three bf16 planes: 7 of 5120 elements)
+    gx = x64.grad.cpu().numpy()
+    _gclose(x0.grad, gx, floor=5e-5 * np.abs(gx).max())
     x0p = _t(c["ncl_x0"], True)
     proto = Ls.ProtoNCE_loss(x0p, c["ncl_uidx"], c["ncl_iidx"], nu, _t(c["ncl_ucent"]), _t(c["ncl_u2c"]),
                              _t(c["ncl_icent"]), _t(c["ncl_i2c"]), float(c["ncl_ssl_temp"]), float(c["ncl_proto_reg"]),
@@ -188,8 +212,8 @@ def test_stats_grads_match_oracle(Fn, m, n, d, normalize, sym):
             nrm = np.maximum(np.sqrt((x.astype(np.float64) ** 2).sum(1, keepdims=True)), 1e-12)
             return (g - xn * (xn * g).sum(1, keepdims=True)) / nrm
         d_an, d_bn = thr(a, an, d_an), thr(b, bn, d_bn)
-    _gclose(at.grad, g1 + d_an, rel=2e-4)
-    _gclose(bt.grad, g2 + d_bn, rel=2e-4)
+    _gclose(at.grad, g1 + d_an)
+    _gclose(bt.grad, g2 + d_bn)
 
 
 @pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 63, 64, 65, 95, 96, 97, 127, 129, 161, 1023, 1025])
@@ -213,8 +237,8 @@ def test_every_tile_count_parity_forward_and_backward(Fn, n):
     # n = 1: the exact gradient is 0 (softmax over one row), what is left is f32 cancellation noise of
     # terms of size |w| / tau * |xhat| ~ 1 summed over the 45 anchors
     floor = 1e-5 if n == 1 else 1e-8
-    _gclose(at.grad, g1, rel=2e-4, floor=floor)
-    _gclose(bt.grad, g2, rel=2e-4, floor=floor)
+    _gclose(at.grad, g1, floor=floor)
+    _gclose(bt.grad, g2, floor=floor)
 
 
 @pytest.mark.parametrize("m,n", [(70, 20), (70, 33), (70, 64), (70, 96), (70, 2049), (70, 40000), (600, 5000)])
@@ -233,8 +257,8 @@ def test_short_and_many_column_splits(Fn, m, n):
     np.testing.assert_allclose(lse.detach().cpu().numpy(), ref_lse, rtol=1e-5, atol=1e-5)
     ((lse - pl) * _t(w.astype(np.float32))).sum().backward()
     g1, g2 = O.infonce_grads(a, b, pos, 10.0, True, w)
-    _gclose(at.grad, g1, rel=2e-4)
-    _gclose(bt.grad, g2, rel=2e-4)
+    _gclose(at.grad, g1)
+    _gclose(bt.grad, g2)
 
 
 @pytest.mark.parametrize("m,n,d,temp", [(300, 300, 64, 0.2), (1000, 257, 64, 0.05), (97, 4100, 128, 0.5), (64, 64, 32, 0.1)])
@@ -361,8 +385,8 @@ def test_flash_forward_path_gives_the_same_gradients(Fn, engine, monkeypatch, m,
         grads[flag] = (at.grad.clone(), bt.grad.clone())
     g1, g2 = O.infonce_grads(a, b, pos, 10.0, True, w.astype(np.float64))
     for flag in (True, False):
-        _gclose(grads[flag][0], g1, rel=2e-4)
-        _gclose(grads[flag][1], g2, rel=2e-4)
+        _gclose(grads[flag][0], g1)
+        _gclose(grads[flag][1], g2)
     # table side: the same launch, fed an lse that differs in the last bits (online merge vs two-stage merge)
     assert float((grads[True][1] - grads[False][1]).abs().max()) <= 1e-5 * float(grads[False][1].abs().max())
 

@@ -107,8 +107,19 @@ def test_graph_replay_equals_eager_sequence():
     assert graphed._fused._cuda_graph is not None                       # the graph path really ran
     assert int(og.state[graphed.model.embedding_dict["user_emb"]]["step_dev"]) == 6
     diff = (graphed.model.table - eager.model.table).abs()
-    # Adam's normalised update amplifies round-off on elements with tiny gradients: compare in units of lr
-    assert float(diff.mean()) < 0.005 * 0.02 and float(diff.max()) < 6 * 0.005
+    # Adam's normalised update amplifies round-off on elements with tiny gradients, so the comparison that binds is on
+    # the elements whose gradient is RESOLVED (second moment within 20x of the largest): there the two tables agree to a
+    # hundredth of ONE step of size lr — a frozen bias correction or a dropped gradient branch moves them by ~lr per step
+    assert float(diff.mean()) < 0.005 * 0.02
+    for name in ("user_emb", "item_emb"):
+        pe, pg = eager.model.embedding_dict[name], graphed.model.embedding_dict[name]
+        rms = oe.state[pe]["exp_avg_sq"].sqrt()
+        resolved = rms > 0.05 * rms.max()
+        assert int(resolved.sum()) > 100
+        assert float((pg - pe).abs()[resolved].max()) < 0.01 * 0.005
+        assert float((og.state[pg]["exp_avg"] - oe.state[pe]["exp_avg"]).abs().max()) <= 2e-5 * float(oe.state[pe]["exp_avg"].abs().max())
+    # a checkpoint taken after replays carries the device-side step count
+    assert all(st["step"] == 6 for st in og.state_dict()["state"].values())
 
 
 def test_capturable_adam_matches_host_step_count():

@@ -75,7 +75,8 @@ def test_renumbering_is_a_permutation_of_the_reference_graph(golden):
     g = golden("graph_build.npz")
     train = _triples(g)
     ref = Interaction({}, train, train[:10], device="cuda", normalised=True)
-    d = Interaction({}, train, train[:10], device="cuda", normalised=True, reorder="spectral", rows_per_cluster=8)
+    d = Interaction({}, train, train[:10], device="cuda", normalised=True, reorder="spectral", rows_per_cluster=8,
+                    reorder_guard=False)                                  # (forced: the guard would skip a toy graph)
     pu, pi = d.perm_user, d.perm_item
     assert sorted(pu.tolist()) == list(range(ref.user_num)) and sorted(pi.tolist()) == list(range(ref.item_num))
     for raw, k in ref.user.items():
@@ -159,7 +160,7 @@ def test_renumbered_model_ranks_like_the_reference_numbering():
             "NCL": {"n_layers": 2, "tau": 0.1, "ssl_reg": 1e-4, "proto_reg": 1e-4, "alpha": 1.0, "num_clusters": 8,
                     "hyper_layers": 1}}
     ref = NCLModel(conf, train, test, device="cuda", seed=1)
-    new = NCLModel(conf, train, test, device="cuda", seed=1, reorder="spectral")
+    new = NCLModel(conf, train, test, device="cuda", seed=1, reorder="spectral", reorder_guard=False)
     assert new.data.perm_user is not None
     pu = torch.from_numpy(new.data.perm_user).cuda()
     pi = torch.from_numpy(new.data.perm_item).cuda()
@@ -208,3 +209,26 @@ def test_bitmap_set_ignores_out_of_range_ids():
     idx = torch.tensor([0, 31, 32, 95, 95, -1, 96, 10 ** 9], device="cuda")
     bits = Fn.active_rows_bitmap(idx, 96).cpu().numpy().view(np.uint32)
     assert bits.tolist() == [0x80000001, 0x00000001, 0x80000000]
+
+
+def test_renumbering_guard_skips_what_it_cannot_speed_up(golden):
+    """`Interaction(reorder="spectral")` must never slow a graph down: a toy graph (fits the caches) and a graph WITHOUT
+    community structure (uniform users x Zipf items, the headline benchmark's law) keep the reference numbering, with the
+    reason recorded; a planted-community graph of the same size is renumbered and measures faster."""
+    import bench
+    from recommendation_amd import reorder as R
+    from recommendation_amd.encoders import Interaction
+    g = golden("graph_build.npz")
+    toy = Interaction({}, _triples(g), [], device="cuda", normalised=True, reorder="spectral")
+    assert toy.perm_user is None and "fit the caches" in toy.reorder_decision["reason"]
+    dev = torch.device("cuda", 0)
+    n_u, n_i, n_e = 1_000_000, 100_000, 10_000_000           # BASELINE configs[1] sizes (smaller tables live in the caches anyway)
+    users, items = bench.synth_interactions_device(n_u, n_i, n_e, 7, dev)
+    pu, pi, group, dec = R.guarded_locality_permutation(users, items, n_u, n_i, dev, rows_per_cluster=8192)
+    assert pu is None and not dec["applied"], dec
+    assert dec["ritz_top"] < 0.9 * dec["noise_bulk_edge"] or dec["ms_per_layer_after"] > 0.97 * dec["ms_per_layer_before"], dec
+    del users, items
+    users, items, _, _ = bench.synth_community_interactions_device(n_u, n_i, n_e, 7, dev, n_u // 8192, 0.85)
+    pu, pi, group, dec = R.guarded_locality_permutation(users, items, n_u, n_i, dev, rows_per_cluster=8192)
+    assert pu is not None and dec["applied"] and dec["ritz_top"] > 0.9 * dec["noise_bulk_edge"], dec
+    assert dec["ms_per_layer_after"] < 0.97 * dec["ms_per_layer_before"], dec

@@ -304,12 +304,11 @@ constexpr float kDefer = 8.0f;
 //          v_cvt_pk_f16_f32) leaves <= 2^-22 |x|; hi*hi + hi*lo + lo*hi drops lo*lo (2^-22): half the matrix-core work of
 //          EngB3 at an error of a few f32 roundings per product.  f16 has a 5-bit exponent, so the format is only used for
 //          operands whose range is known — rows of at most unit norm (the caller's promise GCR_INFONCE_UNIT_ROWS; every
-//          contrast loss of the reference normalises) and probabilities — each pre-scaled by a power of two that puts its
-//          largest value just under 2^15..2^16:
-//            stationary rows (<= inv_tau log2 e, inv_tau <= kH2MaxInvTau)   x 2^4      (|.| <= 462)
-//            streamed rows   (<= 1)                                          x 2^8
-//            scores                                                          accumulator x 2^-12 (folded into the FMA in
-//                                                                            front of exp2)
+//          contrast loss of the reference normalises) and probabilities — each pre-scaled by a power of two that keeps its
+//          largest value inside the f16 range and its typical values' residuals in the normal range:
+//            stationary rows (<= inv_tau log2 e, inv_tau <= kH2MaxInvTau)   x 2^-2     (|.| <= 7.3)
+//            streamed rows   (<= 1)                                          x 2^2
+//            scores                                                          = the accumulator (product of the pre-scales 1)
 //            P, MODE 1 (<= 2^kDefer = 2 relative to the lagging reference)   x 2^14
 //            P, MODE 0 (w e^{s - lse} <= 2 max|w|)                           x 2^14 / 2^ceil(log2 max|w|) (max|w| from a
 //                                                                            one-block pre-pass, h2_wscale_kernel)
@@ -347,8 +346,16 @@ struct EngB3 {
 struct EngH2 {
   static constexpr int NPL = 2, NTERM = 3;
   static constexpr int kMinBlocks = 2;          // 3 would cap the kernel at 168 VGPRs: 11-52 spilled dwords, 4-12 % slower
-  static constexpr float kSX = 16.0f, kSY = 256.0f;
-  static constexpr float kSInv = 1.0f / 4096.0f;
+  // Operand pre-scales whose PRODUCT is 1 (round 4; rounds 2-3 used 2^4 and 2^8 with an accumulator scale of 2^-12): the
+  // accumulator then IS the log2-domain score and the `acc * 2^-12 - m` fma in front of every exp2 disappears — one vector
+  // instruction per probability less in loops whose time is their count of vector instructions.  Emulated in
+  // numpy over 20 000 row pairs per case (unit rows, near-duplicates, rows with a few large and many tiny elements; d = 32 /
+  // 64; 1/tau = 2 / 10 / 20): worst |score error| 0.91e-6 / 1.90e-6 / 1.04e-6 at 1/tau = 10, against 0.89e-6 / 1.84e-6 /
+  // 1.01e-6 with the old pre-scales — what matters for the f16 residual planes is that typical elements stay above 2^-3
+  // (stationary rows carry the 1/tau log2 e factor: ~0.45-0.9 after x 2^-2; streamed unit rows ~0.5 after x 2^2), below it
+  // a residual goes sub-normal with ABSOLUTE error <= 2^-25, which the dot product tolerates (tests/test_h2_format_cpu.py).
+  static constexpr float kSX = 0.25f, kSY = 4.0f;
+  static constexpr float kSInv = 1.0f;
   static constexpr float kPExp = 14.0f;
   static constexpr float kDeferE = 1.0f;
   static __host__ __device__ constexpr int ta(int t) { constexpr int v[3] = {1, 0, 0}; return v[t]; }
@@ -531,7 +538,10 @@ __global__ __launch_bounds__(64 * NW, 2) void infonce_fwd_e_kernel(const float* 
   // running sums take that bound as a FIXED reference point (terms >= 2^(-2 scale2) >= 2^-58 at 1/tau <= 20): no row
   // maximum, no rescale — 14 of ~100 vector instructions per 32 x 32 tile less
   constexpr bool FIXREF = E::NPL == 2;
-  const float m_fix = scale2 * 1.00001f;
+  // ... and that fixed point is ZERO: a term is 2^s with |s| <= scale2 <= 29, the sum over up to 2^40 rows stays below 2^70
+  // — no reference needed for range, none for precision (f32 is scale-invariant) — so with E::kSInv == 1 a probability is
+  // exp2 of the accumulator register itself
+  const float m_fix = 0.f;
   float m_run[S::NT], l_run[S::NT], a_valid[S::NT];
 #pragma unroll
   for (int t = 0; t < S::NT; ++t) {
@@ -647,7 +657,8 @@ __global__ __launch_bounds__(64 * NW, 2) void infonce_fwd_e_kernel(const float* 
           m_new[t] = FIXREF ? m_fix : fmaxf(m_run[t], tmax[t] * E::kSInv);
           sum[t] = 0.f;
         } else if (u < 21) {
-          sum[t] += __builtin_amdgcn_exp2f(fmaf(cur[t][u - 5], E::kSInv, -m_new[t]));
+          if (FIXREF && E::kSInv == 1.0f) sum[t] += __builtin_amdgcn_exp2f(cur[t][u - 5]);
+          else sum[t] += __builtin_amdgcn_exp2f(fmaf(cur[t][u - 5], E::kSInv, -m_new[t]));
         } else if (FIXREF) {
           l_run[t] += sum[t];
         } else {
@@ -1392,7 +1403,7 @@ __global__ __launch_bounds__(1024) void h2_wscale_kernel(const float* __restrict
     if (m > 0.f && m < INFINITY) (void)frexpf(m, &e);                 // m = f * 2^e, f in [0.5, 1): |w| 2^-e < 1
     e = min(max(e, -100), 100);
     hw[0] = ldexpf(1.0f, 14 - e);
-    hw[1] = ldexpf(1.0f, e - 22);
+    hw[1] = 1.0f / (hw[0] * EngH2::kSY);
   }
 }
 

@@ -22,7 +22,7 @@ def test_residual_of_the_two_planes():
 
 
 def test_three_term_dot_product_of_unit_rows():
-    """Scores of unit-norm rows with the kernels' pre-scales (stationary x 2^4 after the 1/tau log2 e factor,
+    """Scores of unit-norm rows with the pre-scales of rounds 2-3 (stationary x 2^4 after the 1/tau log2 e factor,
     streamed x 2^8): |three-term product - exact| <= 3 * 2^-22 * sum |x_k y_k|, typically ~10x less."""
     rng = np.random.default_rng(1)
     d, n = 64, 4000
@@ -54,3 +54,35 @@ def test_probability_plane_range():
     assert (err[big] <= 2.0 ** -22 * p[big]).all()
     assert (err[~big] <= 2.0 ** -39).all()
     assert np.isfinite(hi).all() and hi.max() <= 32768.0
+
+
+def test_unit_product_prescales_cost_no_accuracy():
+    """Round 4: stationary x 2^-2, streamed x 2^2 — product 1, so the accumulator is the log2-domain score itself (EngH2::kSX /
+    kSY / kSInv in csrc/gcr_infonce.hip).  Elements under 2^-3 after scaling have a sub-normal residual plane (absolute error
+    <= 2^-25), which a dot product of unit rows tolerates: the worst score error over dense rows, near-duplicate pairs and
+    rows with a few large and many tiny elements stays within 10 % of the old pre-scales' and under 3e-6 at 1/tau = 20."""
+    rng = np.random.default_rng(2)
+    n = 6000
+
+    def unit(x):
+        return x / np.linalg.norm(x, axis=1, keepdims=True)
+
+    for d in (64, 32):
+        a, b = unit(rng.standard_normal((n, d))), unit(rng.standard_normal((n, d)))
+        b[:600] = unit(a[:600] + 1e-3 * rng.standard_normal((600, d)))
+        c = unit(rng.standard_normal((n, d)) * np.exp(rng.uniform(-6, 0, (n, d))))
+        for inv_tau in (2.0, 10.0, 20.0):
+            scale2 = inv_tau * 1.4426950408889634
+            worst = {}
+            for name, (sx, sy) in (("old", (16.0, 256.0)), ("new", (0.25, 4.0))):
+                errs = []
+                for x, y in ((a, b), (c, c[::-1]), (a, c)):
+                    xs, ys = (x * scale2 * sx).astype(np.float32), (y * sy).astype(np.float32)
+                    xh, xl = split2(xs)
+                    yh, yl = split2(ys)
+                    got = ((xh * yh).sum(1) + (xh * yl).sum(1) + (xl * yh).sum(1)) / (sx * sy)
+                    ref = (xs.astype(np.float64) * ys.astype(np.float64)).sum(1) / (sx * sy)
+                    errs.append(np.abs(got - ref).max())
+                worst[name] = max(errs)
+            assert worst["new"] <= 1.1 * worst["old"] + 2e-7, (d, inv_tau, worst)
+            assert worst["new"] < 3e-6 * inv_tau / 10.0 + 3e-7

@@ -404,6 +404,39 @@ int32_t gcr_kmeans_assign_f32(const float* x, int64_t n, const float* centroids,
 int32_t gcr_kmeans_assign_accumulate_f32(const float* x, int64_t n, const float* centroids, const float* half_sqnorm,
                                          int64_t k, int32_t d, int64_t* assign, float* sums, float* counts,
                                          int32_t n_copies, void* stream);
+#define GCR_KMEANS_SEARCH_LOW_REGISTERS 1u
+/* INCREMENTAL centroid update in 64-bit fixed point (exact, order-independent, run-to-run reproducible): the search of
+ * gcr_kmeans_search_image_f32 followed, for every point whose nearest centroid CHANGED since prev_assign (int32 [n], -1 =
+ * none yet; updated in place), by  sums_q[new] += q, sums_q[old] -= q, counts[new] += 1, counts[old] -= 1  with
+ * q = round(x * qscale[0]) (qscale = {2^e, 2^-e}, device floats, |x| * 2^e < 2^30).  sums_q int64 [n_copies, k, d] / counts
+ * int32 [n_copies, k] persist across the iterations of one k-means (zero before the first); a workgroup adds into private copy
+ * (its index % n_copies) and the copies are summed — exactly — by the update.  gcr_kmeans_lloyd_update_q_f32 then sets
+ * centroid = sums_q / (2^e * count) (an empty cluster keeps its centroid), 0.5 |c|^2, and runs the split step of
+ * gcr_kmeans_lloyd_update_f32 on a float copy of the counts (counts_scratch [k], left zeroed); `image` (optional): the
+ * operand image of the search (gcr_kmeans_centroid_image_f32 built it once) is kept up to date in the same two launches —
+ * every row by the finalize kernel, the rows a split rewrote by the split kernel — so an iteration needs no image launch. */
+int32_t gcr_kmeans_search_image_incr_f32(const float* x, int64_t n, const void* image, int64_t k, int32_t d,
+                                         int32_t* prev_assign, const float* qscale, int64_t* sums_q, int32_t* counts,
+                                         int32_t n_copies, uint32_t flags, void* stream);
+int32_t gcr_kmeans_lloyd_update_q_f32(const int64_t* sums_q, const int32_t* counts, const float* qscale, int64_t k, int32_t d,
+                                      float* centroids, float* half_sqnorm, float* counts_scratch, int64_t n_points,
+                                      uint64_t seed, int32_t iter, int32_t* n_split, void* image, int32_t n_copies, void* stream);
+
+/* The search of a Lloyd iteration for small problems (NCL's e_step: 76.8 K sampled points x a few hundred centroids, 25
+ * iterations per table and training step — a latency problem, not a throughput one): the centroids are split into their
+ * three bf16 planes ONCE per iteration into an image in MFMA-fragment order (gcr_kmeans_centroid_image_f32;
+ * gcr_kmeans_image_bytes bytes), and gcr_kmeans_search_image_f32 runs every wave on its own — 32 points stationary in
+ * registers, fragments as coalesced loads from L2, no LDS, no barrier.  assign (optional) as gcr_kmeans_assign_f32; sums /
+ * counts (optional, n_copies private copies) as gcr_kmeans_assign_accumulate_f32.  d in {32, 64}; same arithmetic, same
+ * tie rule (smaller centroid id) as the tiled kernels: identical assignments. */
+int64_t gcr_kmeans_image_bytes(int64_t k, int32_t d);
+int32_t gcr_kmeans_centroid_image_f32(const float* centroids, const float* half_sqnorm, int64_t k, int32_t d, void* image,
+                                      void* stream);
+/* GCR_KMEANS_SEARCH_LOW_REGISTERS: the <= 128-register form (four waves per SIMD, fragments fetched one k-chunk ahead): its
+ * waves fit beside the InfoNCE loops of the same training step on a SIMD, so the e_step overlaps them instead of queueing. */
+int32_t gcr_kmeans_search_image_f32(const float* x, int64_t n, const void* image, int64_t k, int32_t d, int64_t* assign,
+                                    float* sums, float* counts, int32_t n_copies, uint32_t flags, void* stream);
+
 /* centroids_c <- mean of the rows assigned to c (empty clusters keep their centroid), and
  * half_sqnorm refreshed.  n == 0 only refreshes half_sqnorm (initialisation).
  * sums [k, d] / counts [k] are fp32 scratch. */

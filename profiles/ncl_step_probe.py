@@ -37,6 +37,9 @@ rowptr_u = graph.rowptr[: n_u + 1].contiguous()
 items_u = (graph.col[: int(rowptr_u[-1])] - n_u).contiguous()
 jn = Fn.neg_sample(rowptr_u, items_u, uidx, 1, n_i, 3, 0, 101)
 model.e_step()
+if len(sys.argv) > 3:                              # e_step issue point of the fused step: late (default) | early
+    model.train_step((uidx, iidx, jn), opt, check_negatives=False, fused=fused)
+    model._fused.e_step_issue = sys.argv[3]
 for _ in range(9 if capture else 6):              # graph: 2 eager warm-ups + the capture, then 6 replays
     model.train_step((uidx, iidx, jn), opt, check_negatives=False, fused=fused)
 torch.cuda.synchronize()

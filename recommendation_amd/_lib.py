@@ -69,6 +69,12 @@ SIGNATURES = {
     "gcr_bce_bwd_f32": (c_int32, [_P, c_int64, _P, c_int64, c_int32, _P, _P, _P, _P, c_uint32, _P]),
     "gcr_kmeans_assign_f32": (c_int32, [_P, c_int64, _P, _P, c_int64, c_int32, _P, _P, _P]),
     "gcr_kmeans_assign_accumulate_f32": (c_int32, [_P, c_int64, _P, _P, c_int64, c_int32, _P, _P, _P, c_int32, _P]),
+    "gcr_kmeans_image_bytes": (c_int64, [c_int64, c_int32]),
+    "gcr_kmeans_centroid_image_f32": (c_int32, [_P, _P, c_int64, c_int32, _P, _P]),
+    "gcr_kmeans_search_image_f32": (c_int32, [_P, c_int64, _P, c_int64, c_int32, _P, _P, _P, c_int32, c_uint32, _P]),
+    "gcr_kmeans_search_image_incr_f32": (c_int32, [_P, c_int64, _P, c_int64, c_int32, _P, _P, _P, _P, c_int32, c_uint32, _P]),
+    "gcr_kmeans_lloyd_update_q_f32": (c_int32, [_P, _P, _P, c_int64, c_int32, _P, _P, _P, c_int64, c_uint64, c_int32, _P, _P, c_int32,
+                                                _P]),
     "gcr_kmeans_update_f32": (c_int32, [_P, c_int64, c_int32, _P, c_int64, _P, _P, _P, _P, _P]),
     "gcr_kmeans_update_sorted_f32": (c_int32, [_P, c_int64, c_int32, _P, _P, c_int64, _P, _P, _P, _P, _P]),
     "gcr_kmeans_lloyd_update_f32": (c_int32, [_P, c_int64, c_int32, _P, _P, _P, c_int64, _P, _P, _P, _P, c_int32, c_uint64,

@@ -2576,7 +2576,299 @@ __global__ __launch_bounds__(256, 2) void kmeans_assign_b3_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// The e_step's search at NCL's sizes (76.8 K sampled points x 300 centroids, 25 times per table and step) is a LATENCY
+// problem: the launch above puts ~1 wave on every SIMD, and each of its ten centroid tiles costs a wave the tile's
+// staging (split + LDS stores), a workgroup barrier and the first operand reads, none of it hidden — 19 us of search
+// for 7 us of matrix work.  Here the centroids are split into their three bf16 planes ONCE per Lloyd iteration, by
+// kmeans_image_kernel, into an image in MFMA-fragment order: for tile T, k-chunk c, plane p the 64 lanes' operand
+// registers are 1 KB of consecutive memory — one coalesced global_load_dwordx4 per fragment, served by L2 (120 KB for
+// k = 300).  A wave then needs no LDS, no barrier and no partner: 32 points stationary in registers (NT = 1: twice the
+// waves of the tiled kernel, so that the 1024 SIMDs hold 2-3 each), the next tile's twelve fragments in flight while
+// this tile's 24 MFMAs run, the running arg-max of the previous tile in their shadow.
+// ------------------------------------------------------------------------------------------
+// image[((T * KC + c) * 3 + p) * 64 + lane] = the 8 bf16 of plane p, features [h * KH + 8 c, + 8) of centroid 32 T + i32
+// (lane = 32 h + i32); bias[32 T + r] = -0.5 |c|^2, -inf past k (such a row never wins).
+template <int D>
+__global__ __launch_bounds__(256) void kmeans_image_kernel(const float* __restrict__ cent, const float* __restrict__ half_sq,
+                                                           int64_t k, u32x4* __restrict__ image, float* __restrict__ bias) {
+  using S = ShapeB3<D>;
+  const int64_t tiles = (k + kTileJ - 1) / kTileJ;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;          // one thread per (tile, chunk, lane)
+  if (idx < tiles * kTileJ) bias[idx] = idx < k ? -half_sq[idx] : -INFINITY;
+  if (idx >= tiles * S::KC * 64) return;
+  const int lane = (int)(idx & 63);
+  const int c = (int)((idx >> 6) % S::KC);
+  const int64_t T = (idx >> 6) / S::KC;
+  const int i32 = lane & 31, h = lane >> 5;
+  const int64_t row = T * kTileJ + i32;
+  float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+  if (row < k) {
+    const float* p = cent + row * D + h * S::KH + 8 * c;
+    v0 = *reinterpret_cast<const float4*>(p);
+    v1 = *reinterpret_cast<const float4*>(p + 4);
+  }
+  unsigned q[3][4];
+  split3(v0.x, v0.y, q[0][0], q[1][0], q[2][0]);
+  split3(v0.z, v0.w, q[0][1], q[1][1], q[2][1]);
+  split3(v1.x, v1.y, q[0][2], q[1][2], q[2][2]);
+  split3(v1.z, v1.w, q[0][3], q[1][3], q[2][3]);
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl)
+    image[((T * S::KC + c) * 3 + pl) * 64 + lane] = (u32x4){q[pl][0], q[pl][1], q[pl][2], q[pl][3]};
+}
+
+// LOWREG: the same search at <= 128 registers per lane (four waves per SIMD): fragments are fetched one k-chunk ahead
+// (three 16-B loads in flight per lane instead of two tiles' worth), one accumulator, the arg-max right behind its tile —
+// each wave now stalls on L2 latency, and the other three waves of the SIMD cover it.  What it buys is CO-RESIDENCE: a
+// wave of this kernel fits into the registers the InfoNCE loops of the same training step leave free on a SIMD (2 x 176-192
+// of 512), so the e_step's chain of small launches no longer waits for those grids to drain.
+// INCR (gcr_kmeans_search_image_incr_f32): the cluster sums are kept in 64-bit FIXED POINT across the Lloyd iterations and
+// only the points whose assignment CHANGED touch them — the row leaves its old cluster's sum and joins the new one's.
+// Integer adds are exact and commute, so the incremental sums equal a fresh accumulation bit for bit, in any order: no
+// drift over the 25 iterations, and the e_step becomes run-to-run reproducible (float row atomics are not).  After the first
+// iterations a few per cent of the points move, and the accumulation — 15-19 of an iteration's ~46 us as float row atomics
+// at the memory-side unit's rate — all but disappears (3-4 full passes' worth over 25 iterations instead of 25).
+// q = round(x * qscale[0]), qscale[0] a power of two with |q| < 2^30 (set from max |x| by the caller).
+template <int D, bool LOWREG = false, bool INCR = false>
+__global__ __launch_bounds__(256, LOWREG ? 4 : 2) void kmeans_search_img_kernel(
+    const float* __restrict__ x, int64_t n, const u32x4* __restrict__ image, const float* __restrict__ bias, int64_t k,
+    int64_t* __restrict__ assign, float* __restrict__ acc_sums, float* __restrict__ acc_counts, int n_copies,
+    int32_t* __restrict__ prev_assign = nullptr, const float* __restrict__ qscale = nullptr,
+    long long* __restrict__ sums_q = nullptr, int32_t* __restrict__ counts_i = nullptr) {
+  using S = ShapeB3<D>;
+  constexpr int KC = S::KC, NF = 3 * KC;                   // fragments per centroid tile
+  constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};     // (streamed plane, stationary plane), smallest terms first
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i32 = lane & 31, h = lane >> 5;
+  const int64_t i0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
+  if (i0 >= n) return;                                      // (whole waves only: nothing below synchronises across waves)
+  u32x4 bq[3][KC];
+  load_stationary_b3<D>(x, nullptr, n, i0 + i32, h, 1.0f, bq);
+  const int64_t tiles = (k + kTileJ - 1) / kTileJ;
+  float best = -INFINITY;
+  int btile = 0, breg = 0;
+  u32x4 fa[NF], fb[NF];
+  float4 ba[4], bb[4];
+  auto load_tile = [&](int64_t t, u32x4 (&f)[NF], float4 (&b4)[4]) {
+    const int64_t tt = min(t, tiles - 1);
+    const u32x4* base = image + tt * (NF * 64) + lane;
+#pragma unroll
+    for (int q = 0; q < NF; ++q) f[q] = base[q * 64];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) b4[g] = *reinterpret_cast<const float4*>(bias + tt * kTileJ + 8 * g + 4 * h);
+  };
+  auto scores = [&](const u32x4 (&f)[NF], const float4 (&b4)[4], f32x16& acc) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      acc[4 * g + 0] = b4[g].x; acc[4 * g + 1] = b4[g].y; acc[4 * g + 2] = b4[g].z; acc[4 * g + 3] = b4[g].w;
+    }
+#pragma unroll
+    for (int c = 0; c < KC; ++c)
+#pragma unroll
+      for (int term = 0; term < 6; ++term) acc = mfma_bf16(f[c * 3 + TA[term]], bq[TB[term]][c], acc);
+  };
+  auto argmax = [&](const f32x16& acc, int64_t t) {
+    const float bp = best;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      breg = acc[r] > best ? r : breg;
+      best = fmaxf(best, acc[r]);
+    }
+    btile = best > bp ? (int)t : btile;                     // a lane walks its rows in increasing centroid id: strict > keeps the smallest
+  };
+  if constexpr (LOWREG) {
+    const u32x4* fp = image + lane;
+    u32x4 cur[3], nxt[3];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) cur[pl] = fp[pl * 64];
+    for (int64_t t = 0; t < tiles; ++t) {
+      f32x16 acc;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b4 = *reinterpret_cast<const float4*>(bias + t * kTileJ + 8 * g + 4 * h);
+        acc[4 * g + 0] = b4.x; acc[4 * g + 1] = b4.y; acc[4 * g + 2] = b4.z; acc[4 * g + 3] = b4.w;
+      }
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        // the next chunk's three fragments (the next tile's first ones behind the last chunk; the image is read once past
+        // its end by the last tile: clamped)
+        const int64_t nq = min((t * KC + c + 1) * 3, (tiles * KC - 1) * 3);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) nxt[pl] = fp[(nq + pl) * 64];
+#pragma unroll
+        for (int term = 0; term < 6; ++term) acc = mfma_bf16(cur[TA[term]], bq[TB[term]][c], acc);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) cur[pl] = nxt[pl];
+      }
+      argmax(acc, t);
+    }
+  } else {
+  f32x16 acc_a, acc_b;
+  load_tile(0, fa, ba);
+  load_tile(1, fb, bb);
+  scores(fa, ba, acc_a);
+  int64_t t = 0;
+  for (; t + 2 < tiles; t += 2) {                           // tile t's scores are in acc_a, tile t + 1's fragments in fb
+    load_tile(t + 2, fa, ba);
+    scores(fb, bb, acc_b);
+    argmax(acc_a, t);
+    load_tile(t + 3, fb, bb);
+    scores(fa, ba, acc_a);
+    argmax(acc_b, t + 1);
+  }
+  argmax(acc_a, t);
+  if (t + 1 < tiles) {
+    scores(fb, bb, acc_b);
+    argmax(acc_b, t + 1);
+  }
+  }
+  const int jl = best > -INFINITY ? btile * kTileJ + (breg & 3) + 8 * (breg >> 2) + 4 * h : 0x7fffffff;
+  const float v_o = __shfl_xor(best, 32, 64);
+  const int j_o = __shfl_xor(jl, 32, 64);
+  const bool other = v_o > best || (v_o == best && j_o < jl);
+  const int j = other ? j_o : jl;
+  const int64_t row = i0 + i32;
+  if (h == 0 && row < n && assign != nullptr) assign[row] = j;
+  if constexpr (INCR) {
+    const float qs = qscale[0];
+    // private copy = workgroup % n_copies (the first iterations move every point: 76.8 K 512-B rows onto a few hundred
+    // rows of ONE copy serialise in the memory-side atomic unit: 144 us for the first launch); integer sums of the copies
+    // add up exactly, whichever copy a row joined and whichever it leaves
+    sums_q += (int64_t)(blockIdx.x % n_copies) * k * D;
+    counts_i += (int64_t)(blockIdx.x % n_copies) * k;
+    const int old_l = (h == 0 && row < n) ? prev_assign[row] : -1;
+    const bool moved_l = h == 0 && row < n && old_l != j;
+    if (moved_l) prev_assign[row] = j;
+    unsigned long long moved = __ballot(moved_l);           // bit q: point q of the wave changed cluster
+    while (moved != 0ull) {                                 // wave-uniform walk over the moved points only
+      const int q = __builtin_ctzll(moved);
+      moved &= moved - 1ull;
+      const int cn = __builtin_amdgcn_readlane(j, q), co = __builtin_amdgcn_readlane(old_l, q);
+      const float* xp = x + (i0 + q) * D;
+#pragma unroll
+      for (int c = 0; c < (D + 63) / 64; ++c) {
+        if (lane + 64 * c < D) {
+          const long long v = __float2ll_rn(xp[lane + 64 * c] * qs);
+          if (cn >= 0 && cn < k) atomicAdd(reinterpret_cast<unsigned long long*>(sums_q + (int64_t)cn * D + lane + 64 * c), (unsigned long long)v);
+          if (co >= 0) atomicAdd(reinterpret_cast<unsigned long long*>(sums_q + (int64_t)co * D + lane + 64 * c), (unsigned long long)(-v));
+        }
+      }
+      if (lane == 0) {
+        if (cn >= 0 && cn < k) atomicAdd(counts_i + cn, 1);
+        if (co >= 0) atomicAdd(counts_i + co, -1);
+      }
+    }
+    return;
+  }
+  if (acc_sums == nullptr) return;
+  // Lloyd update fused in, as in kmeans_assign_b3_kernel: every point's row goes to its cluster's sum as one 256-B
+  // float-atomic row (private copy = workgroup % n_copies), all 32 rows of the wave loaded before the first atomic
+  float* __restrict__ sb = acc_sums + (int64_t)(blockIdx.x % n_copies) * k * D;
+  float* __restrict__ cb = acc_counts + (int64_t)(blockIdx.x % n_copies) * k;
+  constexpr int NVX = (D + 63) / 64;
+  constexpr int PB = 32;                                    // rows in flight (the point planes are dead by now)
+#pragma unroll
+  for (int p0 = 0; p0 < 32; p0 += PB) {
+    float xv[PB][NVX];
+    int cj[PB];
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+      const int64_t r = i0 + p0 + q;
+      cj[q] = __builtin_amdgcn_readlane(j, p0 + q);
+      if (r >= n || cj[q] < 0 || cj[q] >= k) cj[q] = -1;
+      const float* xp = x + (r < n ? r : 0) * D;
+#pragma unroll
+      for (int c = 0; c < NVX; ++c) xv[q][c] = (lane + 64 * c < D) ? xp[lane + 64 * c] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+      if (cj[q] < 0) continue;                              // wave-uniform
+#pragma unroll
+      for (int c = 0; c < NVX; ++c)
+        if (lane + 64 * c < D) atomicAdd(sb + (int64_t)cj[q] * D + lane + 64 * c, xv[q][c]);
+      if (lane == 0) atomicAdd(cb + cj[q], 1.0f);
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int64_t gcr_kmeans_image_bytes(int64_t k, int32_t d) {
+  if (k < 1 || !(d == 32 || d == 64 || d == 128)) return 0;
+  const int64_t tiles = (k + kTileJ - 1) / kTileJ;
+  return tiles * (3 * (d / 16) * 64 * 16 + kTileJ * (int64_t)sizeof(float));      // fragments, then the bias rows
+}
+
+extern "C" int32_t gcr_kmeans_centroid_image_f32(const float* centroids, const float* half_sqnorm, int64_t k, int32_t d,
+                                                 void* image, void* stream) {
+  GCR_CHECK_ARG(k >= 1 && k < (1ll << 31));
+  if (!(d == 32 || d == 64 || d == 128)) return GCR_EUNSUPPORTED;
+  GCR_CHECK_ARG(centroids && half_sqnorm && image);
+  const int64_t tiles = (k + kTileJ - 1) / kTileJ;
+  u32x4* img = reinterpret_cast<u32x4*>(image);
+  float* bias = reinterpret_cast<float*>(img + tiles * 3 * (d / 16) * 64);
+  const int64_t threads = tiles * (d / 16) * 64;           // >= tiles * 32: covers the bias rows too
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((unsigned)((threads + 255) / 256));
+  switch (d) {
+    case 32: hipLaunchKernelGGL((kmeans_image_kernel<32>), grid, dim3(256), 0, s, centroids, half_sqnorm, k, img, bias); break;
+    case 64: hipLaunchKernelGGL((kmeans_image_kernel<64>), grid, dim3(256), 0, s, centroids, half_sqnorm, k, img, bias); break;
+    default: hipLaunchKernelGGL((kmeans_image_kernel<128>), grid, dim3(256), 0, s, centroids, half_sqnorm, k, img, bias); break;
+  }
+  return GCR_LAUNCH_STATUS();
+}
+
+extern "C" int32_t gcr_kmeans_search_image_f32(const float* x, int64_t n, const void* image, int64_t k, int32_t d,
+                                               int64_t* assign, float* sums, float* counts, int32_t n_copies, uint32_t flags,
+                                               void* stream) {
+  GCR_CHECK_ARG(n >= 0 && k >= 1 && k < (1ll << 31) && (flags & ~(uint32_t)GCR_KMEANS_SEARCH_LOW_REGISTERS) == 0);
+  if (!(d == 32 || d == 64)) return GCR_EUNSUPPORTED;      // (d = 128: the point planes + two tiles of fragments exceed 256 registers)
+  if (n == 0) return GCR_OK;
+  GCR_CHECK_ARG(x && image && (assign || sums));
+  GCR_CHECK_ARG((sums == nullptr) == (counts == nullptr) && (sums == nullptr || (n_copies >= 1 && n_copies <= 64)));
+  const int64_t tiles = (k + kTileJ - 1) / kTileJ;
+  const u32x4* img = reinterpret_cast<const u32x4*>(image);
+  const float* bias = reinterpret_cast<const float*>(img + tiles * 3 * (d / 16) * 64);
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((unsigned)((n + 127) / 128));
+  const bool low = (flags & GCR_KMEANS_SEARCH_LOW_REGISTERS) != 0;
+  if (d == 32) {
+    if (low) hipLaunchKernelGGL((kmeans_search_img_kernel<32, true>), grid, dim3(256), 0, s, x, n, img, bias, k, assign, sums, counts, (int)n_copies);
+    else hipLaunchKernelGGL((kmeans_search_img_kernel<32, false>), grid, dim3(256), 0, s, x, n, img, bias, k, assign, sums, counts, (int)n_copies);
+  } else {
+    if (low) hipLaunchKernelGGL((kmeans_search_img_kernel<64, true>), grid, dim3(256), 0, s, x, n, img, bias, k, assign, sums, counts, (int)n_copies);
+    else hipLaunchKernelGGL((kmeans_search_img_kernel<64, false>), grid, dim3(256), 0, s, x, n, img, bias, k, assign, sums, counts, (int)n_copies);
+  }
+  return GCR_LAUNCH_STATUS();
+}
+
+extern "C" int32_t gcr_kmeans_search_image_incr_f32(const float* x, int64_t n, const void* image, int64_t k, int32_t d,
+                                                    int32_t* prev_assign, const float* qscale, int64_t* sums_q,
+                                                    int32_t* counts, int32_t n_copies, uint32_t flags, void* stream) {
+  GCR_CHECK_ARG(n >= 0 && k >= 1 && k < (1ll << 31) && (flags & ~(uint32_t)GCR_KMEANS_SEARCH_LOW_REGISTERS) == 0);
+  GCR_CHECK_ARG(n_copies >= 1 && n_copies <= 64);
+  if (!(d == 32 || d == 64)) return GCR_EUNSUPPORTED;
+  if (n == 0) return GCR_OK;
+  GCR_CHECK_ARG(x && image && prev_assign && qscale && sums_q && counts);
+  const int64_t tiles = (k + kTileJ - 1) / kTileJ;
+  const u32x4* img = reinterpret_cast<const u32x4*>(image);
+  const float* bias = reinterpret_cast<const float*>(img + tiles * 3 * (d / 16) * 64);
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((unsigned)((n + 127) / 128));
+  const bool low = (flags & GCR_KMEANS_SEARCH_LOW_REGISTERS) != 0;
+  long long* sq = reinterpret_cast<long long*>(sums_q);
+#define GCR_KMI(DD, LOW)                                                                                                \
+  hipLaunchKernelGGL((kmeans_search_img_kernel<DD, LOW, true>), grid, dim3(256), 0, s, x, n, img, bias, k, (int64_t*)nullptr, \
+                     (float*)nullptr, (float*)nullptr, (int)n_copies, prev_assign, qscale, sq, counts)
+  if (d == 32) {
+    if (low) GCR_KMI(32, true); else GCR_KMI(32, false);
+  } else {
+    if (low) GCR_KMI(64, true); else GCR_KMI(64, false);
+  }
+#undef GCR_KMI
+  return GCR_LAUNCH_STATUS();
+}
 
 extern "C" int32_t gcr_kmeans_assign_f32(const float* x, int64_t n, const float* centroids, const float* half_sqnorm,
                                          int64_t k, int32_t d, int64_t* assign, float* best_score, void* stream) {

@@ -11,6 +11,28 @@
 
 namespace {
 
+// the three-bf16-plane operand split of the search kernels (gcr_b3.h wants these three names first)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kTileJ = 32;
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+#include "gcr_b3.h"
+
+// One fragment of the pre-split centroid image of gcr_kmeans_search_image_f32 (layout: kmeans_image_kernel in
+// gcr_infonce.hip): the 8 features [8 * col8, + 8) of centroid `row`, three planes.
+__device__ __forceinline__ void image_store_fragment(u32x4* __restrict__ image, int d, int64_t row, int col8, const float (&v)[8]) {
+  const int kh = d / 2, kc = d / 16;
+  const int feat = 8 * col8, h = feat / kh, c = (feat % kh) / 8;
+  const int64_t T = row / kTileJ;
+  const int lane = 32 * h + (int)(row % kTileJ);
+  unsigned q[3][4];
+  split3(v[0], v[1], q[0][0], q[1][0], q[2][0]);
+  split3(v[2], v[3], q[0][1], q[1][1], q[2][1]);
+  split3(v[4], v[5], q[0][2], q[1][2], q[2][2]);
+  split3(v[6], v[7], q[0][3], q[1][3], q[2][3]);
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) image[((T * kc + c) * 3 + pl) * 64 + lane] = (u32x4){q[pl][0], q[pl][1], q[pl][2], q[pl][3]};
+}
+
 constexpr uint32_t kStreamSplit = 0x4B4D5350u;  // 'KMSP'
 
 __device__ __forceinline__ float group16_sum(float v) {
@@ -181,6 +203,63 @@ __global__ __launch_bounds__(256) void kmeans_finalize_clear_kernel(float* __res
   }
 }
 
+// centroid = fixed-point sum / (scale * count) from the INCREMENTAL sums of gcr_kmeans_search_image_incr_f32 (nothing is
+// cleared: the sums persist across the iterations); an empty cluster keeps its centroid; half_sq = 0.5 |c|^2; the float
+// copy of the counts is what the split step reads (and clears).  One thread per centroid element, d divides 256.
+__global__ __launch_bounds__(256) void kmeans_finalize_q_kernel(const long long* __restrict__ sums_q,
+                                                                const int32_t* __restrict__ counts_i, const float* __restrict__ qscale,
+                                                                int64_t k, int d, float* __restrict__ cent, float* __restrict__ half_sq,
+                                                                float* __restrict__ counts_f, u32x4* __restrict__ image,
+                                                                float* __restrict__ bias, int n_copies) {
+  __shared__ float red[4];
+  __shared__ float rowbuf[256];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + tid;
+  const int64_t c = idx / d;
+  const int col = (int)(idx % d);
+  const bool valid = c < k;
+  float v = 0.f;
+  int cnt = 0;
+  if (valid) {
+    long long sum = 0;
+    for (int g = 0; g < n_copies; ++g) {                     // integer sums: exact in any order
+      cnt += counts_i[(int64_t)g * k + c];
+      sum += sums_q[((int64_t)g * k + c) * d + col];
+    }
+    v = cent[c * d + col];
+    if (cnt > 0) {
+      v = (float)((double)sum * (double)qscale[1] / (double)cnt);
+      cent[c * d + col] = v;
+    }
+  }
+  float ss = v * v;
+  if (d <= 64) {
+    for (int off = d >> 1; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
+  } else {
+    ss = gcr_wave_sum(ss);
+    if (lane == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    const int w0 = (tid >> 6) / (d >> 6) * (d >> 6);
+    ss = 0.f;
+    for (int w = 0; w < (d >> 6); ++w) ss += red[w0 + w];
+  }
+  if (valid && col == 0) {
+    half_sq[c] = 0.5f * ss;
+    counts_f[c] = (float)cnt;
+    if (bias != nullptr) bias[c] = -0.5f * ss;
+  }
+  if (image != nullptr) {                                  // this row's fragments of the search kernel's operand image
+    rowbuf[tid] = v;
+    __syncthreads();
+    if (valid && (col & 7) == 0) {
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = rowbuf[tid + e];
+      image_store_fragment(image, d, c, col >> 3, f);
+    }
+  }
+}
+
 constexpr int kSplitThreads = 256;    // (1024 at first: beside the backward of the NCL step a sixteen-wave workgroup waited up to 0.6 ms for a CU)
 
 template <typename T, typename Op>
@@ -209,7 +288,9 @@ __device__ __forceinline__ T block_reduce(T v, T* sh, Op op) {
 __global__ __launch_bounds__(kSplitThreads) void kmeans_split_kernel(float* __restrict__ counts, int64_t k, int d,
                                                                      float* __restrict__ cent, float* __restrict__ half_sq,
                                                                      int64_t n_points, uint64_t seed, uint32_t iter,
-                                                                     int32_t* __restrict__ n_split_out) {
+                                                                     int32_t* __restrict__ n_split_out,
+                                                                     u32x4* __restrict__ image = nullptr,
+                                                                     float* __restrict__ bias = nullptr) {
   __shared__ long long sh_ll[kSplitThreads / 64];
   __shared__ float sh_f[kSplitThreads / 64];
   const int tid = threadIdx.x;
@@ -267,6 +348,21 @@ __global__ __launch_bounds__(kSplitThreads) void kmeans_split_kernel(float* __re
       auto add_f = [](float a, float b) { return a + b; };
       ss_i = block_reduce<float>(ss_i, sh_f, add_f);
       ss_j = block_reduce<float>(ss_j, sh_f, add_f);
+      if (image != nullptr) {                                // the two rewritten rows in the search kernel's operand image
+        __syncthreads();                                     // (this block's own stores to cent above)
+        if (tid < 2 * (d / 8)) {
+          const long long row = tid < d / 8 ? ci : cj;
+          const int col8 = tid % (d / 8);
+          float f[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] = cent[row * d + 8 * col8 + e];
+          image_store_fragment(image, d, row, col8, f);
+        }
+        if (tid == 0) {
+          bias[ci] = -0.5f * ss_i;
+          bias[cj] = -0.5f * ss_j;
+        }
+      }
       if (tid == 0) {
         half_sq[ci] = 0.5f * ss_i;
         half_sq[cj] = 0.5f * ss_j;
@@ -351,5 +447,25 @@ extern "C" int32_t gcr_kmeans_lloyd_update_f32(const float* x, int64_t n, int32_
                      counts, k, d, centroids, half_sqnorm, keys_sorted != nullptr ? 1 : (int)n_copies);
   hipLaunchKernelGGL(kmeans_split_kernel, dim3(1), dim3(kSplitThreads), 0, s, counts, k, d, centroids, half_sqnorm, n, seed,
                      (uint32_t)iter, n_split);
+  return GCR_LAUNCH_STATUS();
+}
+
+extern "C" int32_t gcr_kmeans_lloyd_update_q_f32(const int64_t* sums_q, const int32_t* counts, const float* qscale, int64_t k,
+                                                 int32_t d, float* centroids, float* half_sqnorm, float* counts_scratch,
+                                                 int64_t n_points, uint64_t seed, int32_t iter, int32_t* n_split, void* image,
+                                                 int32_t n_copies, void* stream) {
+  GCR_CHECK_ARG(k >= 1 && k < (1ll << 31) && d >= 1 && d <= 256 && 256 % d == 0 && iter >= 0 && n_points >= 1);
+  GCR_CHECK_ARG(n_copies >= 1 && n_copies <= 64);
+  GCR_CHECK_ARG(sums_q && counts && qscale && centroids && half_sqnorm && counts_scratch);
+  GCR_CHECK_ARG(image == nullptr || d == 32 || d == 64 || d == 128);
+  hipStream_t s = (hipStream_t)stream;
+  u32x4* img = reinterpret_cast<u32x4*>(image);
+  const int64_t tiles = (k + kTileJ - 1) / kTileJ;
+  float* bias = image != nullptr ? reinterpret_cast<float*>(img + tiles * 3 * (d / 16) * 64) : nullptr;
+  hipLaunchKernelGGL(kmeans_finalize_q_kernel, dim3((unsigned)((k * (int64_t)d + 255) / 256)), dim3(256), 0, s,
+                     reinterpret_cast<const long long*>(sums_q), counts, qscale, k, d, centroids, half_sqnorm, counts_scratch, img,
+                     bias, (int)n_copies);
+  hipLaunchKernelGGL(kmeans_split_kernel, dim3(1), dim3(kSplitThreads), 0, s, counts_scratch, k, d, centroids, half_sqnorm,
+                     n_points, seed, (uint32_t)iter, n_split, img, bias);
   return GCR_LAUNCH_STATUS();
 }

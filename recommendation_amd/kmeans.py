@@ -40,6 +40,15 @@ FAISS_MAX_POINTS_PER_CENTROID = 256
 SORTED_UPDATE_MIN_POINTS = 1 << 20
 MAX_ATOMIC_COPIES = 16
 
+# the wave-independent search (every wave streams the whole centroid image from L2) pays while the problem is small enough
+# to be latency-bound; past this many point-centroid pairs per iteration the tiled kernel's LDS sharing wins
+IMAGE_SEARCH = True
+IMAGE_SEARCH_LOW_REGISTERS = True      # <= 128 registers per lane: co-resident with the InfoNCE loops of the training step
+# cluster sums kept in 64-bit fixed point across the iterations, updated only by the points that changed cluster (exact,
+# order-independent: equals a fresh accumulation bit for bit, and makes the e_step run-to-run reproducible)
+INCREMENTAL_UPDATE = True
+IMAGE_SEARCH_MAX_PAIRS = 1 << 28
+
 _PERM_CACHE = {}
 
 
@@ -111,9 +120,43 @@ def run_kmeans(x, k, niter=FAISS_NITER, seed=FAISS_SEED, init_centroids=None,
     _lib.check(L.gcr_kmeans_update_f32(None, 0, d, None, k, _lib.dptr(cent), _lib.dptr(half_sq), None, None, stream),
                "gcr_kmeans_update_f32")
     fused = not use_sorted and bool(L.gcr_infonce_engine(d))       # search + accumulate in one launch (d <= 128)
+    # small problems (the e_step: 76.8 K sampled points, a few hundred centroids) are latency-bound: wave-independent search
+    # over a pre-split centroid image (gcr_kmeans_search_image_f32), the image rebuilt once per iteration
+    image = None
+    if fused and d in (32, 64) and IMAGE_SEARCH and n_train * k <= IMAGE_SEARCH_MAX_PAIRS:
+        image = torch.empty(int(L.gcr_kmeans_image_bytes(k, d)), dtype=torch.uint8, device=dev)
+    incremental = image is not None and INCREMENTAL_UPDATE
+    if incremental:
+        # fixed-point scale 2^e with max |x| * 2^e in [2^29, 2^30): exact in f32, computed on the device (no read-back)
+        e = 29.0 - torch.floor(torch.log2(xt.abs().max().clamp_min(1e-30)))
+        qscale = torch.stack([torch.exp2(e), torch.exp2(-e)]).to(torch.float32)
+        sums_q = torch.zeros(copies, k, d, dtype=torch.int64, device=dev)
+        counts_i = torch.zeros(copies, k, dtype=torch.int32, device=dev)
+        prev = torch.full((n_train,), -1, dtype=torch.int32, device=dev)
+        counts_f = torch.zeros(k, dtype=torch.float32, device=dev)
+        flags = 1 if IMAGE_SEARCH_LOW_REGISTERS else 0
+        # the operand image is built once; every iteration's update keeps it current (no image launch per iteration)
+        _lib.check(L.gcr_kmeans_centroid_image_f32(_lib.dptr(cent), _lib.dptr(half_sq), k, d, _lib.dptr(image), stream),
+                   "gcr_kmeans_centroid_image_f32")
+        for it in range(int(niter)):
+            _lib.check(L.gcr_kmeans_search_image_incr_f32(_lib.dptr(xt), n_train, _lib.dptr(image), k, d, _lib.dptr(prev),
+                                                          _lib.dptr(qscale), _lib.dptr(sums_q), _lib.dptr(counts_i), copies, flags, stream),
+                       "gcr_kmeans_search_image_incr_f32")
+            _lib.check(L.gcr_kmeans_lloyd_update_q_f32(_lib.dptr(sums_q), _lib.dptr(counts_i), _lib.dptr(qscale), k, d,
+                                                       _lib.dptr(cent), _lib.dptr(half_sq), _lib.dptr(counts_f), n_train,
+                                                       int(seed) & (2 ** 64 - 1), it, _lib.dptr(n_split), _lib.dptr(image), copies,
+                                                       stream),
+                       "gcr_kmeans_lloyd_update_q_f32")
+        niter = 0
     for it in range(int(niter)):
         keys = perm = assign = None
-        if fused:
+        if image is not None:
+            _lib.check(L.gcr_kmeans_centroid_image_f32(_lib.dptr(cent), _lib.dptr(half_sq), k, d, _lib.dptr(image), stream),
+                       "gcr_kmeans_centroid_image_f32")
+            _lib.check(L.gcr_kmeans_search_image_f32(_lib.dptr(xt), n_train, _lib.dptr(image), k, d, None, _lib.dptr(sums),
+                                                     _lib.dptr(counts), copies, 1 if IMAGE_SEARCH_LOW_REGISTERS else 0, stream),
+                       "gcr_kmeans_search_image_f32")
+        elif fused:
             _lib.check(L.gcr_kmeans_assign_accumulate_f32(_lib.dptr(xt), n_train, _lib.dptr(cent), _lib.dptr(half_sq), k, d, None,
                                                           _lib.dptr(sums), _lib.dptr(counts), copies, stream),
                        "gcr_kmeans_assign_accumulate_f32")

@@ -103,7 +103,8 @@ class NCLModel:
                 dev = user_emb.device
                 cur = torch.cuda.current_stream(dev)
                 if self._e_streams is None:
-                    self._e_streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+                    pr = int(getattr(self, "e_stream_priority", 0))
+                    self._e_streams = (torch.cuda.Stream(device=dev, priority=pr), torch.cuda.Stream(device=dev, priority=pr))
                 res = []
                 for s, (x, k) in zip(self._e_streams, ((user_emb, k_users), (item_emb, k_items))):
                     if after is not None:

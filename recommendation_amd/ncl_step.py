@@ -54,6 +54,9 @@ class FusedNCLStep:
         # True: the e_step's streams are joined only in front of the prototype contrast (the structure contrast's forward
         # is issued meanwhile)
         self.early_e_step = True
+        # "late": the e_step's launches are issued behind the backward recurrence (ordered behind `final` by an event);
+        # "early": right after the forward (scripts/exp/ncl_step_quick.py compares them)
+        self.e_step_issue = "late"
 
     def _side_stream(self, dev):
         if self._side is None:
@@ -157,7 +160,10 @@ class FusedNCLStep:
         # in eager mode for the host, and in a replayed graph too (its nodes are dispatched in capture order) ----
         ev_final = None
         if self.e_step_every_batch:
-            if self.early_e_step:
+            if self.e_step_issue == "early":
+                # issued right here, joined in front of the prototype contrast: the chain runs beside everything in between
+                o_.e_step(fu, fi, assign_all=False, join=False)
+            elif self.early_e_step:
                 ev_final = torch.cuda.Event()
                 ev_final.record(main)
             else:
@@ -261,6 +267,8 @@ class FusedNCLStep:
         # backward and the recurrence above; everything that needs the centroids is the 2 B-row prototype contrast below ----
         if ev_final is not None:
             o_.e_step(fu, fi, assign_all=False, join=False, after=ev_final)
+            o_.e_step_join()
+        elif self.e_step_every_batch and self.e_step_issue == "early":
             o_.e_step_join()
 
         # ---- prototype contrast (ncl.py:369-375): InfoNCE(e0[idx], centroid of idx's cluster) * batch_size ----

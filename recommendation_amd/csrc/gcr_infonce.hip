@@ -2792,6 +2792,13 @@ __global__ __launch_bounds__(256, LOWREG ? 4 : 2) void kmeans_search_img_kernel(
   }
 }
 
+// (Tried and removed in round 4: the image shared by a workgroup's four waves through a four-slot LDS ring filled by LDS-DMA
+// three tiles ahead — global_load_lds issued from inline assembly so that hipcc does not drain it with vmcnt(0), counted
+// vmcnt + one raw s_barrier per tile, 64 points per wave: an eighth of the L2 traffic, same assignments, 29.4 us against
+// 27.4 us for the search alone and 8.74 against 8.42 ms for the NCL iteration.  The three designs — LDS staging with a
+// barrier per tile 32 us, per-wave L2 streaming 27 us, LDS-DMA ring 29 us — all sit at ~2 us per centroid tile for 0.75 us
+// of matrix work at 2.4 GHz: what they share is 2400 wave-tiles on 1024 SIMDs (2.3 per SIMD: a makespan of 3) and the
+// clock the chip holds under 1024 SIMDs of back-to-back bf16 MFMAs, not their operand path.)
 }  // namespace
 
 extern "C" int64_t gcr_kmeans_image_bytes(int64_t k, int32_t d) {
@@ -2858,6 +2865,7 @@ extern "C" int32_t gcr_kmeans_search_image_incr_f32(const float* x, int64_t n, c
   const dim3 grid((unsigned)((n + 127) / 128));
   const bool low = (flags & GCR_KMEANS_SEARCH_LOW_REGISTERS) != 0;
   long long* sq = reinterpret_cast<long long*>(sums_q);
+
 #define GCR_KMI(DD, LOW)                                                                                                \
   hipLaunchKernelGGL((kmeans_search_img_kernel<DD, LOW, true>), grid, dim3(256), 0, s, x, n, img, bias, k, (int64_t*)nullptr, \
                      (float*)nullptr, (float*)nullptr, (int)n_copies, prev_assign, qscale, sq, counts)

@@ -40,7 +40,6 @@ t_old = ms(lambda: _lib.check(L.gcr_kmeans_assign_f32(_lib.dptr(x), n, _lib.dptr
 t_new = ms(lambda: _lib.check(L.gcr_kmeans_search_image_f32(_lib.dptr(x), n, _lib.dptr(img), k, d, _lib.dptr(assign2), None, None, 1, 0, st), "b"))
 t_low = ms(lambda: _lib.check(L.gcr_kmeans_search_image_f32(_lib.dptr(x), n, _lib.dptr(img), k, d, _lib.dptr(assign2), None, None, 1, 1, st), "b"))
 print(f"low-register image search only: {t_low:.1f} us, same assignment: {bool(torch.equal(assign, assign2))}")
-print(f"search only: tiled {t_old:.1f} us, image {t_new:.1f} us, same assignment: {bool(torch.equal(assign, assign2))}")
 for copies in (1, 4, 16, 64):
     sums = torch.zeros(copies, k, d, device=dev)
     counts = torch.zeros(copies, k, device=dev)

@@ -164,6 +164,14 @@ int32_t gcr_bpr_bwd_f32(const float* user_tab, const float* item_tab, int32_t d,
  * batch that is the training graph's own edge list those parts are one SpMM with per-edge coefficients on the graph's
  * structure (functional.bpr_edge_sums: gcr_spmm_csr_f32 with val = dL/dx per edge), not two sorted scatters.
  */
+/* keys_u == perm_u == NULL (only together with keys_i == NULL): the users' rows are left to the caller as well — for the
+ * graph's own edge list in user-major order the negatives form a CSR block on the graph's user row pointer:
+ * gcr_bpr_neg_block_f32 writes its columns (int32 [batch * n_neg], dropped samples -> row 0 with value 0), its values
+ * - g dL/dx / n_neg and the dropped samples per user; one gcr_spmm_csr_f32 launch on that block adds
+ * - g dl_e mean_k I[j_ek] to grad_user.  Only the negatives' item rows remain a sorted scatter. */
+int32_t gcr_bpr_neg_block_f32(const float* dloss_dx, const int64_t* j_idx, const int64_t* u_idx, int64_t batch, int32_t n_neg,
+                              int64_t n_items, const float* grad_sums, int32_t* col, float* val, float* dropped_per_user,
+                              void* stream);
 int64_t gcr_sort_index_workspace_bytes(int64_t n);
 int32_t gcr_sort_index(const int64_t* idx, int64_t n, int64_t n_keys, uint32_t* keys_sorted, int32_t* perm,
                        void* workspace, void* stream);

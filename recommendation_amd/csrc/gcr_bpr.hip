@@ -353,6 +353,29 @@ __global__ __launch_bounds__(256) void bpr_edge_values_kernel(const float* __res
   }
 }
 
+// The negatives' USER side of the same full batch as one more SpMM: the training edges are in user-major order, so the
+// negatives drawn for them form a CSR block [U x I] on the graph's own user row pointer (times n_neg) whose columns are
+// this step's negatives and whose values are - g dL/dx / n_neg:  dU[u] -= sum_{e in row u} g dl_e mean_k I[j_ek].  This
+// kernel writes that block's columns (sanitised: a dropped sample's slot points at row 0 with value 0) and values, and
+// tallies the dropped samples per user (the |U[u]|^2 term counts live samples only).
+__global__ __launch_bounds__(256) void bpr_neg_block_kernel(const float* __restrict__ dloss_dx, const int64_t* __restrict__ j_idx,
+                                                            const int64_t* __restrict__ u_idx, int64_t batch, int n_neg,
+                                                            int64_t n_items, const float* __restrict__ grad_sums,
+                                                            int32_t* __restrict__ col, float* __restrict__ val,
+                                                            float* __restrict__ dropped_per_user) {
+  const float g = -grad_sums[0] / (float)n_neg;
+  const int64_t slots = batch * n_neg;
+  for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < slots; s += (int64_t)gridDim.x * 256) {
+    const int64_t e = s / n_neg;
+    const float dl = dloss_dx[e];
+    const int64_t j = j_idx[s];
+    const bool live = dl == dl && j >= 0 && j < n_items;   // (a bad id anywhere in the sample left NaN in dloss_dx)
+    col[s] = live ? (int32_t)j : 0;
+    val[s] = live ? g * dl : 0.f;
+    if (!(dl == dl) && s == e * n_neg) atomicAdd(dropped_per_user + u_idx[e], 1.0f);
+  }
+}
+
 int fwd_blocks(int64_t batch) {
   const int64_t want = (batch + kGroups - 1) / kGroups;
   return (int)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
@@ -442,9 +465,10 @@ extern "C" int32_t gcr_bpr_bwd_sorted_f32(const float* user_tab, const float* it
   GCR_CHECK_ARG(batch * n_neg < (1ll << 31));
   if (batch == 0) return GCR_OK;
   GCR_CHECK_ARG(user_tab && item_tab && u_idx && j_idx && dloss_dx && grad_sums && grad_user && grad_item);
-  GCR_CHECK_ARG(keys_u && perm_u && keys_j && perm_j && (keys_i != nullptr) == (perm_i != nullptr));
+  GCR_CHECK_ARG(keys_j && perm_j && (keys_i != nullptr) == (perm_i != nullptr) && (keys_u != nullptr) == (perm_u != nullptr));
   const bool pos = keys_i != nullptr;                     // false: the caller adds the positive-pair parts (gcr.h)
-  GCR_CHECK_ARG(!pos || i_idx != nullptr);
+  const bool user_side = keys_u != nullptr;               // false (only without the positive parts): the caller adds the
+  GCR_CHECK_ARG(!pos || (i_idx != nullptr && user_side)); // users' rows too (gcr_bpr_neg_block_f32 + one SpMM)
   hipStream_t s = (hipStream_t)stream;
   auto blocks_for = [](int64_t n_entries) {
     const int64_t want = ((n_entries + 63) / 64 + 3) / 4;
@@ -472,7 +496,7 @@ extern "C" int32_t gcr_bpr_bwd_sorted_f32(const float* user_tab, const float* it
   if (pos) {                                                  \
     GCR_SIDE(0, NV, keys_u, perm_u, batch, grad_user);        \
     GCR_SIDE(1, NV, keys_i, perm_i, batch, grad_item);        \
-  } else {                                                    \
+  } else if (user_side) {                                     \
     GCR_NEG0(NV);                                             \
   }                                                           \
   GCR_SIDE(2, NV, keys_j, perm_j, batch * n_neg, grad_item)
@@ -495,5 +519,17 @@ extern "C" int32_t gcr_bpr_edge_values_f32(const float* dloss_dx, const int64_t*
   const int64_t want = (2 * n_pairs + 255) / 256;
   hipLaunchKernelGGL(bpr_edge_values_kernel, dim3((unsigned)(want > 65536 ? 65536 : want)), dim3(256), 0, (hipStream_t)stream,
                      dloss_dx, mirror, col, n_users, n_pairs, grad_sums, val, dropped_per_item);
+  return GCR_LAUNCH_STATUS();
+}
+
+extern "C" int32_t gcr_bpr_neg_block_f32(const float* dloss_dx, const int64_t* j_idx, const int64_t* u_idx, int64_t batch,
+                                         int32_t n_neg, int64_t n_items, const float* grad_sums, int32_t* col, float* val,
+                                         float* dropped_per_user, void* stream) {
+  GCR_CHECK_ARG(batch >= 0 && n_neg >= 1 && n_items >= 1 && batch * n_neg < (1ll << 40));
+  if (batch == 0) return GCR_OK;
+  GCR_CHECK_ARG(dloss_dx && j_idx && u_idx && grad_sums && col && val && dropped_per_user);
+  const int64_t want = (batch * n_neg + 255) / 256;
+  hipLaunchKernelGGL(bpr_neg_block_kernel, dim3((unsigned)(want > 65536 ? 65536 : want)), dim3(256), 0, (hipStream_t)stream,
+                     dloss_dx, j_idx, u_idx, batch, (int)n_neg, n_items, grad_sums, col, val, dropped_per_user);
   return GCR_LAUNCH_STATUS();
 }

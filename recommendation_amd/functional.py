@@ -592,13 +592,27 @@ class _BprEdgeSums(torch.autograd.Function):
         # term rides in the launch below, which walks the samples user by user)
         live = graph.row_degrees()[n_users:] - dropped
         gi.addcmul_(table[n_users:], (2.0 * gs[2] * live).unsqueeze(1))
-        # negatives (fresh every step: one sort) and the users' side of them
-        ku, pu, _ = _sorted_order(u_idx, n_users, cache=True)
+        # the negatives' USER side: the edges are in user-major order, so this step's negatives are a CSR block [U x I] on the
+        # graph's own user row pointer (x n_neg) — one more SpMM on a cached work plan instead of a sorted scatter over E
+        # samples (0.84 -> ~0.4 ms at cfg2); its |U[u]|^2 term counts the live samples of every user
+        L = _lib.lib()
+        n_neg = ctx.n_neg
+        nb = graph.negatives_user_block(n_users, n_items, n_neg)
+        ncol = torch.empty(batch * n_neg, dtype=torch.int32, device=table.device)
+        nval = torch.empty(batch * n_neg, dtype=torch.float32, device=table.device)
+        dropped_u = torch.zeros(n_users, dtype=torch.float32, device=table.device)
+        _lib.check(L.gcr_bpr_neg_block_f32(_lib.dptr(dldx), _lib.dptr(j_idx), _lib.dptr(u_idx), batch, n_neg, n_items,
+                                           _lib.dptr(gs), _lib.dptr(ncol), _lib.dptr(nval), _lib.dptr(dropped_u),
+                                           _lib.cur_stream(table.device)), "gcr_bpr_neg_block_f32")
+        nb.col, nb.val = ncol, nval
+        spmm_into(nb, table[n_users:], acc_in=gu, acc_out=gu)
+        gu.addcmul_(table[:n_users], (2.0 * gs[1] * (graph.row_degrees()[:n_users] - dropped_u)).unsqueeze(1))
+        # the negatives' item rows (fresh every step: one sort, one sorted scatter)
         kj, pj, _ = _sorted_order(j_idx.reshape(-1), n_items)
-        _lib.check(_lib.lib().gcr_bpr_bwd_sorted_f32(
+        _lib.check(L.gcr_bpr_bwd_sorted_f32(
             _lib.dptr(table[:n_users]), _lib.dptr(table[n_users:]), table.shape[1], _lib.dptr(u_idx), None,
-            _lib.dptr(j_idx), batch, ctx.n_neg, n_users, n_items, _lib.dptr(dldx), _lib.dptr(gs), _lib.dptr(ku),
-            _lib.dptr(pu), None, None, _lib.dptr(kj), _lib.dptr(pj), _lib.dptr(gu), _lib.dptr(gi),
+            _lib.dptr(j_idx), batch, n_neg, n_users, n_items, _lib.dptr(dldx), _lib.dptr(gs), None,
+            None, None, None, _lib.dptr(kj), _lib.dptr(pj), _lib.dptr(gu), _lib.dptr(gi),
             _lib.cur_stream(table.device)), "gcr_bpr_bwd_sorted_f32")
         return gfull, None, None, None, None
 

@@ -169,6 +169,22 @@ class CsrGraph:
             self._um_edges = c
         return c[1], c[2]
 
+    def negatives_user_block(self, n_users, n_items, n_neg=1):
+        """The CSR skeleton [U x I] of `n_neg` negatives per training edge in user-major order: the user rows' pointer of this
+        (symmetric bipartite) operator times n_neg, with its work plan — built once, cached; the caller fills `col` / `val`
+        with a step's negatives and coefficients (functional.bpr_edge_sums' backward)."""
+        key = (int(n_users), int(n_items), int(n_neg))
+        cache = self.__dict__.setdefault("_neg_blocks", {})
+        blk = cache.get(key)
+        if blk is None:
+            rp = self.rowptr_host[: n_users + 1] * int(n_neg)
+            nnz = int(rp[-1])
+            blk = CsrGraph(rp, torch.zeros(nnz, dtype=torch.int32, device=self.device),
+                           torch.zeros(nnz, dtype=torch.float32, device=self.device), n_users, n_items, self.device,
+                           symmetric=False, nnz_per_part=self.plan.nnz_per_part, validate=False)
+            cache[key] = blk
+        return blk
+
     def mirror_perm(self):
         """Symmetric operators only: int64 [nnz], mirror[e] = position of the non-zero (c, r) for the non-zero
         e = (r, c) — the nnz -> transpose-nnz map that lets a per-non-zero edge mask be handed to the

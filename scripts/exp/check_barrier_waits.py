@@ -29,7 +29,35 @@ for i, l in enumerate(lines):
                 bad.append((cur[-50:], t.split()[0], i - j))
                 break
             j -= 1
+# Second check: in the 512-thread form (template argument NW = 8) the two wave groups take some barriers
+# inside group-dependent branches (waves 4..7 one more in front of the loop, waves 0..3 one more behind it), which is only
+# sound while the branch is UNIFORM — taken by whole waves — so that a barrier is never executed under a partial EXEC mask.
+# LLVM lowers a branch it has proven uniform to s_cbranch_scc0 / scc1 (scalar compare) or s_cbranch_vccz / vccnz (a uniform
+# value compared in the vector ALU, e.g. a 64-bit tile counter), and a possibly DIVERGENT one to an EXEC-masked region
+# (s_and_saveexec + s_cbranch_execz): no forward branch that skips an s_barrier in those kernels may be of the EXEC kind.
+labels = {}
+for i, l in enumerate(lines):
+    m = re.match(r"^(\.LBB\d+_\d+):", l)
+    if m:
+        labels[m.group(1)] = i
+vector_guarded = []
+cur = None
+for i, l in enumerate(lines):
+    m = re.match(r"^(_Z\w+):", l)
+    if m:
+        cur = m.group(1)
+    if not (cur and "infonce_pipe_kernel" in cur and cur.rstrip("_").find("ELi8EE") >= 0):
+        continue
+    m = re.match(r"\s*(s_cbranch_\w+)\s+(\.LBB\d+_\d+)", l)
+    if m and labels.get(m.group(2), -1) > i:                          # forward branch: does it skip a barrier?
+        skipped = any(re.match(r"\s*s_barrier", x) for x in lines[i + 1:labels[m.group(2)]])
+        if skipped:
+            agg["barriers_in_8wave_branches"] += 1
+            if m.group(1) in ("s_cbranch_execz", "s_cbranch_execnz"):
+                vector_guarded.append((cur[-60:], m.group(1), i + 1))
 print(dict(agg))
 for b in bad[:20]:
     print("UNWAITED", b)
-sys.exit(1 if bad else 0)
+for b in vector_guarded[:20]:
+    print("BARRIER INSIDE AN EXEC-MASKED REGION", b)
+sys.exit(1 if (bad or vector_guarded) else 0)

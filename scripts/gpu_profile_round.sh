@@ -37,6 +37,12 @@ if [ "$WHAT" = "nce" ] || [ "$WHAT" = "all" ]; then
   echo "rank pass done"
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_lg" -- python3 "$R/profiles/lightgcn_step_probe.py" > "$OUT/kt_lg.log" 2>&1
   echo "lightgcn step pass done"
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_bce" -- python3 "$R/profiles/bce_probe.py" > "$OUT/kt_bce.log" 2>&1
+  echo "bce pass done"
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_kme" -- python3 "$R/profiles/kmeans_estep_probe.py" > "$OUT/kt_kme.log" 2>&1
+  echo "k-means e_step pass done"
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_cfg5" -- python3 "$R/bench.py" --workload cfg5 --steps 5 --warmup 2 > "$OUT/bench_cfg5_kt.json" 2> "$OUT/bench_cfg5_kt.err"
+  echo "cfg5 pass done"
 fi
 # keep the merge-back small: only the CSV summaries are read afterwards
 find "$OUT" -name "*.db" -delete 2>/dev/null || true

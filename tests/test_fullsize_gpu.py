@@ -141,26 +141,38 @@ def test_cfg4_graph_three_layer_propagation(cfg4):
     got_h = got.cpu().numpy()
     assert np.abs(got_h - ref).max() <= 1e-5 * np.abs(ref).max()
     del ref, got_h, col_h, val_h, x_h
-    # ~4K sampled rows at PER-ROW 1e-5 (small rows are not hidden behind the global maximum) against a float64 referee:
-    # the same Horner recurrence z <- x0 + A z with every row sum accumulated in float64 (two fp32 summation orders of a
-    # 500K-term hub row differ by more than they each differ from the exact sum)
-    rows = torch.repeat_interleave(torch.arange(g.n_rows, device="cuda"), g.rowptr[1:] - g.rowptr[:-1])
-    col64, val64 = g.col.to(torch.int64), g.val.double()
-    x64 = x0.double()
-    z = x64
-    for _ in range(3):
-        nxt = x64.clone()
-        for lo in range(0, g.nnz, 1 << 24):                  # nnz slabs: the [slab, 64] float64 products stay at 8.6 GB
-            hi = min(g.nnz, lo + (1 << 24))
-            nxt.index_add_(0, rows[lo:hi], z[col64[lo:hi]] * val64[lo:hi].unsqueeze(1))
-        z = nxt
+    # ~4K sampled rows + the 64 longest rows at PER-ROW 1e-5 (small rows are not hidden behind the global maximum) against a
+    # float64 referee, layer by layer: z_k[row] = x0[row] + sum_e val_e z_{k-1}[col_e] with the row's sum accumulated in
+    # float64 from the kernel's own previous layer (two fp32 summation orders of a 500K-term hub row differ by more than each
+    # differs from the exact sum, so the C oracle's fp32 order is no referee for those rows)
     rs = torch.from_numpy(np.random.default_rng(4).integers(0, g.n_rows, 4096)).cuda()
-    hubs = torch.topk(g.rowptr[1:] - g.rowptr[:-1], 64).indices           # ... and the 64 longest rows
-    rs = torch.cat([rs, hubs])
-    denom = z[rs].abs().max(1, keepdim=True).values + 1e-300
-    assert float(((got[rs].double() - z[rs]).abs() / denom).max()) <= 1e-5
-    assert float((got.double() - z).abs().max()) <= 1e-5 * float(z.abs().max())
-    del rows, col64, val64, x64, z, nxt
+    deg = g.rowptr[1:] - g.rowptr[:-1]
+    rs = torch.unique(torch.cat([rs, torch.topk(deg, 64).indices]))
+    starts, lens = g.rowptr[rs], deg[rs]
+    owner = torch.repeat_interleave(torch.arange(rs.numel(), device="cuda"), lens)
+    pos = torch.arange(int(lens.sum()), device="cuda") - torch.repeat_interleave(torch.cumsum(lens, 0) - lens, lens) + starts[owner]
+    col_s, val_s = g.col[pos].to(torch.int64), g.val[pos].double()
+    z_prev = x0
+    for k in range(3):
+        z_k = torch.empty_like(x0)
+        Fn.spmm_into(g, z_prev, acc_in=x0, acc_out=z_k)                    # the Horner layer the timed call launches
+        ref_rows = x0[rs].double()
+        for lo in range(0, pos.numel(), 1 << 22):                         # slabs: [4M, 64] float64 products = 2 GB
+            hi = min(pos.numel(), lo + (1 << 22))
+            # segment sums by prefix sums (the entries of a row are consecutive; half a million float64 atomics onto one
+            # hub row would serialise)
+            cs = torch.cumsum(z_prev[col_s[lo:hi]].double() * val_s[lo:hi].unsqueeze(1), 0)
+            uniq, cnt = torch.unique_consecutive(owner[lo:hi], return_counts=True)
+            ends = torch.cumsum(cnt, 0) - 1
+            seg = cs[ends]
+            seg[1:] -= cs[ends[:-1]]
+            ref_rows[uniq] += seg
+            del cs
+        denom = ref_rows.abs().max(1, keepdim=True).values + 1e-300
+        assert float(((z_k[rs].double() - ref_rows).abs() / denom).max()) <= 1e-5, k
+        z_prev = z_k
+    assert float((z_prev - got).abs().max()) == 0.0                        # the same three launches as lightgcn_propagate
+    del z_prev, z_k, ref_rows, col_s, val_s, pos, owner
     torch.cuda.empty_cache()
     # linearity: P(a x + b z) = a P(x) + b P(z)
     gen = torch.Generator(device="cuda").manual_seed(9)

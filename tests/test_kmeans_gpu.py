@@ -167,3 +167,59 @@ def test_split_falls_back_to_the_largest_cluster():
     np.testing.assert_allclose(cent.cpu().numpy(), ref_c, rtol=2e-6)
     np.testing.assert_allclose(half.cpu().numpy(), 0.5 * (ref_c ** 2).sum(1), rtol=1e-5)
     assert float(counts.abs().sum()) == 0.0 and float(sums.abs().sum()) == 0.0      # scratch left zeroed
+
+
+@pytest.mark.parametrize("d", [64, 32])
+@pytest.mark.parametrize("n,k", [(76800, 300), (1000, 37), (129, 33), (5000, 600)])
+def test_image_search_gives_the_tiled_search_bit_for_bit(n, k, d):
+    """The wave-independent search over the pre-split centroid image (both register budgets) runs the same products in the
+    same order as the tiled kernel: identical assignments, ties and ragged centroid tiles included."""
+    from recommendation_amd import _lib
+    from recommendation_amd.kmeans import kmeans_assign
+    L = _lib.lib()
+    g = torch.Generator(device="cuda").manual_seed(n + k + d)
+    x = torch.randn(n, d, device="cuda", generator=g)
+    c = x[torch.randperm(n, device="cuda", generator=g)[:k]].clone()
+    c[3] = c[1]
+    half = 0.5 * (c * c).sum(1)
+    ref = kmeans_assign(x, c, half)
+    img = torch.empty(int(L.gcr_kmeans_image_bytes(k, d)), dtype=torch.uint8, device="cuda")
+    st = _lib.cur_stream(x.device)
+    _lib.check(L.gcr_kmeans_centroid_image_f32(_lib.dptr(c), _lib.dptr(half), k, d, _lib.dptr(img), st), "image")
+    for flags in (0, 1):
+        got = torch.full((n,), -7, dtype=torch.int64, device="cuda")
+        _lib.check(L.gcr_kmeans_search_image_f32(_lib.dptr(x), n, _lib.dptr(img), k, d, _lib.dptr(got), None, None, 1, flags, st), "search")
+        assert torch.equal(got, ref), flags
+    assert not bool((ref == 3).any())
+
+
+def test_incremental_fixed_point_sums_equal_a_fresh_accumulation():
+    """run_kmeans' default path at the e_step's kind of size: sums kept in 64-bit fixed point, touched only by points that
+    changed cluster.  After every iteration count the centroids must be the exact means of the CURRENT assignment (no drift
+    from 25 rounds of +/- updates), two runs must agree bitwise, and one iteration must agree with the float-atomic path."""
+    from recommendation_amd import kmeans as K
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.nn.functional.normalize(torch.randn(30000, 64, device="cuda", generator=g) + 0.4, dim=1)
+    init = x[torch.randperm(30000, device="cuda", generator=g)[:120]].clone()
+    assert K.IMAGE_SEARCH and K.INCREMENTAL_UPDATE
+    for niter in (1, 7, 25):
+        c1, a1 = K.run_kmeans(x, 120, niter=niter, init_centroids=init, max_points_per_centroid=0)
+        c2, _ = K.run_kmeans(x, 120, niter=niter, init_centroids=init, max_points_per_centroid=0)
+        assert torch.equal(c1, c2)
+        # the centroids are the means of the assignment of iteration `niter` (against the previous centroids): recompute
+        # that assignment by running niter - 1 iterations and assigning once more
+        cp, _ = K.run_kmeans(x, 120, niter=niter - 1, init_centroids=init, max_points_per_centroid=0) if niter > 1 else (init, None)
+        a = K.assign_to_centroids(x, cp)
+        sums = torch.zeros(120, 64, dtype=torch.float64, device="cuda").index_add_(0, a, x.double())
+        cnt = torch.bincount(a, minlength=120).double()
+        expect = torch.where(cnt[:, None] > 0, sums / cnt.clamp_min(1)[:, None], cp.double())
+        assert float((c1.double() - expect).abs().max()) <= 2e-7
+    try:
+        K.INCREMENTAL_UPDATE = False
+        cf, _ = K.run_kmeans(x, 120, niter=1, init_centroids=init, max_points_per_centroid=0)
+        K.IMAGE_SEARCH = False
+        ct, _ = K.run_kmeans(x, 120, niter=1, init_centroids=init, max_points_per_centroid=0)
+    finally:
+        K.IMAGE_SEARCH = K.INCREMENTAL_UPDATE = True
+    c1, _ = K.run_kmeans(x, 120, niter=1, init_centroids=init, max_points_per_centroid=0)
+    assert float((c1 - cf).abs().max()) <= 1e-6 and float((c1 - ct).abs().max()) <= 1e-6

@@ -440,7 +440,7 @@ def infonce_roofline(Fn, x0, n_u, dev):
                                     "bwd": round(12 * flops / t3_b / 1e9 / peak, 4)},
             "note": "EngH2 issues half the MFMA flops for the same f32 result, so its issued fraction of peak is lower "
                     "while its launches are 1.35-1.55x shorter; the limiter moved from the matrix pipe to vector issue "
-                    "and waits (DESIGN 4.2b, profiles/r02_infonce_stall_counters.csv)"}
+                    "and waits (DESIGN 4.2b, profiles/r04_infonce_stall_counters.csv)"}
     pmc = _committed_pmc("infonce", infonce_source_digest())
     if pmc:
         out["mfma_busy_pct"] = pmc.get("fwd_mfma_busy_pct")

@@ -1088,8 +1088,9 @@ def bce_legs(ra, Fn, graph, x0, k_layers, n_u, n_i, dev, timeit):
     out["all_pairs"] = {"shape": f"{m} x {n_i} x {d}", "pairs": pairs, "fwd_ms": round(t_f, 3), "fwd_bwd_ms": round(t_fb, 3),
                         "pairs_per_s_fwd": pairs / t_f * 1e3, "pairs_per_s_fwd_bwd": pairs / t_fb * 1e3,
                         "mfma_issued_frac_fwd_bwd": round(6 * 4 * 2.0 * pairs * d / t_fb / 1e9 / BF16_MFMA_PEAK_TF, 4),
-                        "note": "three bf16 planes (rows are not unit rows): 6 MFMA products per f32 product; fwd = softplus row "
-                                "sums only (1 tile product), fwd_bwd = flash-style forward (2) + item-side backward (2)"}
+                        "note": "three bf16 planes (rows are not unit rows): 6 MFMA products per f32 product; fwd (no gradient) = "
+                                "softplus row sums only (1 tile product), fwd_bwd = forward with the sigmoid-weighted row sum (2) + "
+                                "item-side backward (2)"}
     del a, b, ag, bg
 
     def step_leg(model, g, reps):

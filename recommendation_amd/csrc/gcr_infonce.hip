@@ -1485,6 +1485,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
   constexpr bool FOLD = PRE && SIDES == 2;
   constexpr bool BWD = MODE == 0 || MODE == 3;               // per-row weights (MODE 0: and lse) ride with the tiles
   constexpr bool FWD = MODE == 1 || MODE == 2;               // running row sums + the o accumulators
+  constexpr bool NOO = MODE == 2 && SIDES == 1;              // BCE row sums only (no gradient wanted): no second product
   static_assert(MODE < 2 || (std::is_same<E, EngB3>::value && !EXD && NW == 4), "BCE modes: three planes, four waves");
   static_assert(MODE != 3 || SIDES == 1 || SIDES == 2, "BCE backward: weights on one side");
   __shared__ __align__(16) unsigned char lds_rm[RING][RM];   // ring: tile t (B, transposed reads), t+1 (A), t+2 (staging)
@@ -1677,6 +1678,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
           else acc[r] = wl * __builtin_amdgcn_exp2f(fmaf(sc, E::kSInv, -lse2l)) + wre * __builtin_amdgcn_exp2f(fmaf(sc, E::kSInv, -lre));
         }
       } else {
+        if (NOO) return;                                 // (no second product: nothing to split)
         const int e = m - 16;                            // pair (2e, 2e + 1): k-chunk e / 4, dword e % 4
         unsigned q[NPL];
         E::template split<kSplitForm<MODE>>(acc[2 * e], acc[2 * e + 1], q);
@@ -1791,17 +1793,17 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
         }
       };
       u32x4 ya[2][NPL];
-      load_ya(0, ya[0]);
+      if (!NOO) load_ya(0, ya[0]);
 #pragma unroll
       for (int grp = 0; grp < 2 * B::CT; ++grp) {
         const int kc = grp / B::CT, c = grp % B::CT;
-        if (grp + 1 < 2 * B::CT) load_ya(grp + 1, ya[(grp + 1) & 1]);
+        if (!NOO && grp + 1 < 2 * B::CT) load_ya(grp + 1, ya[(grp + 1) & 1]);
         u32x4 pp[NPL];
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) pp[pl] = (u32x4){pc[kc][pl][0], pc[kc][pl][1], pc[kc][pl][2], pc[kc][pl][3]};
 #pragma unroll
         for (int term = 0; term < NTERM; ++term) {
-          gacc[c] = E::mfma(ya[grp & 1][E::ta(term)], pp[E::tb(term)], gacc[c]);
+          if (!NOO) gacc[c] = E::mfma(ya[grp & 1][E::ta(term)], pp[E::tb(term)], gacc[c]);
           const int slot = grp * NTERM + term;
           if (BWD || real_next) {
 #pragma unroll
@@ -1845,7 +1847,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
           MODE == 2 ? make_float2(0.f, l_run + l_o) : make_float2(m_run, (l_run + l_o) * __builtin_amdgcn_exp2f(-E::kPExp));
   }
   const float o_mul = out_scale * (hw != nullptr ? hw[1] : 1.0f) * sgn_x;
-  if (row_i < mx) {
+  if (!NOO && row_i < mx) {
 #pragma unroll
     for (int c = 0; c < B::CT; ++c)
 #pragma unroll
@@ -2230,8 +2232,12 @@ int32_t launch_bce_fwd(const float* a, int64_t m, const float* b, int64_t n, flo
   bool with_o = false;
   if constexpr (D <= 64) {
     if (bce_pipe(D, force_f32)) {
-      hipLaunchKernelGGL((infonce_pipe_kernel<EngB3, D, 2, false, 0, 4>), grid, dim3(256), 0, s, a, none, m, b, none, n,
-                         kLog2e, 1.0f, none, none, none, none, p.nsplit, p.tiles_per_split, opart, part, none);
+      if (o != nullptr)
+        hipLaunchKernelGGL((infonce_pipe_kernel<EngB3, D, 2, false, 0, 4>), grid, dim3(256), 0, s, a, none, m, b, none, n,
+                           kLog2e, 1.0f, none, none, none, none, p.nsplit, p.tiles_per_split, opart, part, none);
+      else                                                  // row sums only: the same loop without its second product
+        hipLaunchKernelGGL((infonce_pipe_kernel<EngB3, D, 2, false, 1, 4>), grid, dim3(256), 0, s, a, none, m, b, none, n,
+                           kLog2e, 1.0f, none, none, none, none, p.nsplit, p.tiles_per_split, opart, part, none);
       with_o = true;
     }
   }
@@ -2751,12 +2757,12 @@ __global__ __launch_bounds__(256, LOWREG ? 4 : 2) void kmeans_search_img_kernel(
         if (lane + 64 * c < D) {
           const long long v = __float2ll_rn(xp[lane + 64 * c] * qs);
           if (cn >= 0 && cn < k) atomicAdd(reinterpret_cast<unsigned long long*>(sums_q + (int64_t)cn * D + lane + 64 * c), (unsigned long long)v);
-          if (co >= 0) atomicAdd(reinterpret_cast<unsigned long long*>(sums_q + (int64_t)co * D + lane + 64 * c), (unsigned long long)(-v));
+          if (co >= 0 && co < k) atomicAdd(reinterpret_cast<unsigned long long*>(sums_q + (int64_t)co * D + lane + 64 * c), (unsigned long long)(-v));
         }
       }
       if (lane == 0) {
         if (cn >= 0 && cn < k) atomicAdd(counts_i + cn, 1);
-        if (co >= 0) atomicAdd(counts_i + co, -1);
+        if (co >= 0 && co < k) atomicAdd(counts_i + co, -1);
       }
     }
     return;

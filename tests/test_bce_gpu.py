@@ -73,6 +73,9 @@ def test_softplus_rowsum_and_grads(Fn, engine, d, m, n):
     rows = Fn.bce_softplus_rowsum(at, bt, engine=engine)
     ref_rows, sig = O.bce_rows(a, b)
     _close(rows, ref_rows)
+    with torch.no_grad():                                  # without a gradient the forward skips its second product
+        rows_ng = Fn.bce_softplus_rowsum(at, bt, engine=engine)
+    assert torch.equal(rows_ng, rows.detach())
     (rows * _t(w.astype(np.float32))).sum().backward()
     w32 = w.astype(np.float32).astype(np.float64)
     _close(at.grad, (sig * w32[:, None]) @ b.astype(np.float64))

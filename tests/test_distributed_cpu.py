@@ -1,4 +1,4 @@
-"""world_size-2 gloo test of the row-sharded propagation choreography (distributed.py) on CPU
+"""gloo tests (world sizes 2, 4 and 8) of the row-sharded propagation choreography (distributed.py) on CPU
 tensors: the per-rank SpMM is injected from the CPU oracle (tests may use the oracle; the
 product default is the HIP kernel), so what is checked here is the partition, the collectives
 and the autograd wiring:  N-rank result == 1-rank result on the same synthetic graph."""
@@ -66,7 +66,7 @@ def _worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_sharded_propagation_equals_single_process(world):
     from recommendation_amd import _build, _lib
     if not os.path.exists(_lib.LIB_PATH):
@@ -133,9 +133,9 @@ def _nce_worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_sharded_info_nce_loss_equals_single_process():
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_info_nce_loss_equals_single_process(world):
     ctx = mp.get_context("spawn")
-    world = 2
     with ctx.Manager() as mgr:
         out = mgr.dict()
         port = _free_port()
@@ -150,12 +150,13 @@ def test_sharded_info_nce_loss_equals_single_process():
     z1 = torch.randn(64, 16, generator=g)
     z2 = z1 + 0.4 * torch.randn(64, 16, generator=g)
     ref = O.info_nce_loss(z1.numpy(), z2.numpy(), 0.2)
-    assert res[0]["loss"] == pytest.approx(ref, rel=1e-5) and res[1]["loss"] == pytest.approx(ref, rel=1e-5)
+    assert all(res[r]["loss"] == pytest.approx(ref, rel=1e-5) for r in range(world))
     w = np.full(64, 0.5 / 64)
     g1, g2 = O.infonce_grads(z1.numpy(), z2.numpy(), np.arange(64), 5.0, True, w, w)
+    m = 64 // world
     for r in range(world):
-        np.testing.assert_allclose(res[r]["ga"], g1[r * 32:(r + 1) * 32], rtol=1e-4, atol=1e-6)
-        np.testing.assert_allclose(res[r]["gb"], g2[r * 32:(r + 1) * 32], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(res[r]["ga"], g1[r * m:(r + 1) * m], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(res[r]["gb"], g2[r * m:(r + 1) * m], rtol=1e-4, atol=1e-6)
 
 
 # --------------------------------------------------------------------------- BASELINE config 5 (MHCN channels)
@@ -206,14 +207,14 @@ def _mhcn_worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_sharded_mhcn_channels_equal_single_process():
-    """Config 5: users row-sharded over 2 ranks, one all-gather per channel operand, reduce-scatter of the
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_mhcn_channels_equal_single_process(world):
+    """Config 5: users row-sharded over the ranks, one all-gather per channel operand, reduce-scatter of the
     channel gradients, all-reduce of the item-side partial sums: values and gradients == single process."""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import mhcn_sharded_common as C
     ctx = mp.get_context("spawn")
-    world = 2
     with ctx.Manager() as mgr:
         out = mgr.dict()
         port = _free_port()

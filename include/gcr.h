@@ -171,7 +171,20 @@ int32_t gcr_bpr_bwd_f32(const float* user_tab, const float* item_tab, int32_t d,
  * - g dl_e mean_k I[j_ek] to grad_user.  Only the negatives' item rows remain a sorted scatter. */
 int32_t gcr_bpr_neg_block_f32(const float* dloss_dx, const int64_t* j_idx, const int64_t* u_idx, int64_t batch, int32_t n_neg,
                               int64_t n_items, const float* grad_sums, int32_t* col, float* val, float* dropped_per_user,
-                              void* stream);
+                              uint32_t* sort_key, uint64_t* sort_payload, void* stream);
+/* ... and the negatives' ITEM rows from a sort that carries its payload (lightgcn.py:91-93 draws fresh negatives every
+ * step, so this sort cannot be cached): with sort_key / sort_payload non-NULL gcr_bpr_neg_block_f32 also writes, per
+ * negative slot, key = j (n_items for a dropped slot: it sorts last) and payload = (u << 32) | bits(- g dL/dx / n_neg);
+ * gcr_sort_pairs_u64 orders both by key (stable radix sort over the bits n_keys needs; n < 2^31);
+ * gcr_bpr_neg_items_sorted_f32 walks the sorted arrays in 64-entry chunks and adds, per run of equal keys,
+ * sum coef U[u] + 2 g_3 (#entries) I[j] to grad_item[j] with one row atomic — key, user and coefficient arrive by coalesced
+ * loads instead of perm -> sample -> (u_idx, dloss_dx) as in gcr_bpr_bwd_sorted_f32's third launch. */
+int64_t gcr_sort_pairs_u64_workspace_bytes(int64_t n);
+int32_t gcr_sort_pairs_u64(const uint32_t* keys, const uint64_t* payload, int64_t n, int64_t n_keys, uint32_t* keys_sorted,
+                           uint64_t* payload_sorted, void* workspace, void* stream);
+int32_t gcr_bpr_neg_items_sorted_f32(const float* user_tab, const float* item_tab, int32_t d, const uint32_t* keys_sorted,
+                                     const uint64_t* payload_sorted, int64_t n_entries, int64_t n_users, int64_t n_items,
+                                     const float* grad_sums, float* grad_item, void* stream);
 int64_t gcr_sort_index_workspace_bytes(int64_t n);
 int32_t gcr_sort_index(const int64_t* idx, int64_t n, int64_t n_keys, uint32_t* keys_sorted, int32_t* perm,
                        void* workspace, void* stream);

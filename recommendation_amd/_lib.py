@@ -40,7 +40,10 @@ SIGNATURES = {
     "gcr_bpr_edge_values_f32": (c_int32, [_P, _P, _P, c_int64, c_int64, _P, _P, _P, _P]),
     "gcr_bpr_bwd_sorted_f32": (c_int32, [_P, _P, c_int32, _P, _P, _P, c_int64, c_int32, c_int64, c_int64, _P, _P,
                                          _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "gcr_bpr_neg_block_f32": (c_int32, [_P, _P, _P, c_int64, c_int32, c_int64, _P, _P, _P, _P, _P]),
+    "gcr_bpr_neg_block_f32": (c_int32, [_P, _P, _P, c_int64, c_int32, c_int64, _P, _P, _P, _P, _P, _P, _P]),
+    "gcr_sort_pairs_u64_workspace_bytes": (c_int64, [c_int64]),
+    "gcr_sort_pairs_u64": (c_int32, [_P, _P, c_int64, c_int64, _P, _P, _P, _P]),
+    "gcr_bpr_neg_items_sorted_f32": (c_int32, [_P, _P, c_int32, _P, _P, c_int64, c_int64, c_int64, _P, _P, _P]),
     "gcr_neg_sample": (c_int32, [_P, _P, _P, c_int64, c_int32, c_int64, c_int64, c_uint64, c_uint64, c_int32, _P, _P]),
     "gcr_edge_mask_bits": (c_int32, [c_int64, c_float, c_uint64, _P, _P, _P]),
     "gcr_row_inv_norm_f32": (c_int32, [_P, c_int64, c_int32, c_float, _P, _P]),

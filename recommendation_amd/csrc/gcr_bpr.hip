@@ -362,7 +362,8 @@ __global__ __launch_bounds__(256) void bpr_neg_block_kernel(const float* __restr
                                                             const int64_t* __restrict__ u_idx, int64_t batch, int n_neg,
                                                             int64_t n_items, const float* __restrict__ grad_sums,
                                                             int32_t* __restrict__ col, float* __restrict__ val,
-                                                            float* __restrict__ dropped_per_user) {
+                                                            float* __restrict__ dropped_per_user,
+                                                            uint32_t* __restrict__ sort_key, uint64_t* __restrict__ sort_payload) {
   const float g = -grad_sums[0] / (float)n_neg;
   const int64_t slots = batch * n_neg;
   for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < slots; s += (int64_t)gridDim.x * 256) {
@@ -370,10 +371,100 @@ __global__ __launch_bounds__(256) void bpr_neg_block_kernel(const float* __restr
     const float dl = dloss_dx[e];
     const int64_t j = j_idx[s];
     const bool live = dl == dl && j >= 0 && j < n_items;   // (a bad id anywhere in the sample left NaN in dloss_dx)
+    const float v = live ? g * dl : 0.f;
     col[s] = live ? (int32_t)j : 0;
-    val[s] = live ? g * dl : 0.f;
-    if (!(dl == dl) && s == e * n_neg) atomicAdd(dropped_per_user + u_idx[e], 1.0f);
+    val[s] = v;
+    const int64_t u = u_idx[e];
+    if (!(dl == dl) && s == e * n_neg) atomicAdd(dropped_per_user + u, 1.0f);
+    if (sort_key) {                                         // the same slot for the ITEM side: key j, payload (u, value)
+      sort_key[s] = live ? (uint32_t)j : (uint32_t)n_items;
+      sort_payload[s] = live ? ((uint64_t)(uint32_t)u << 32) | (uint64_t)__builtin_bit_cast(uint32_t, v) : 0ull;
+    }
   }
+}
+
+// The negatives' ITEM rows from the slots ordered by negative item WITH their payload (gcr_sort_pairs_u64 of the key /
+// payload arrays bpr_neg_block_kernel writes): a wave walks 64 consecutive sorted entries — key, user and coefficient
+// arrive by three coalesced loads instead of perm -> sample -> (u_idx, dloss_dx) —, keeps 16 user rows in flight and adds
+// a run of equal keys to its item row with one row atomic (+ the run's share of the |I[j]|^2 term).
+template <int NV>
+__global__ __launch_bounds__(256) void bpr_neg_items_sorted_kernel(const float* __restrict__ user_tab,
+                                                                   const float* __restrict__ item_tab, int d,
+                                                                   const uint32_t* __restrict__ keys,
+                                                                   const uint64_t* __restrict__ payload, int64_t n_entries,
+                                                                   int64_t n_items, const float* __restrict__ grad_sums,
+                                                                   float* __restrict__ grad_item) {
+  const int lane = threadIdx.x & 63;
+  const float c_self = 2.f * grad_sums[3];
+  const int64_t n_chunks = (n_entries + 63) / 64;
+  for (int64_t chunk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); chunk < n_chunks; chunk += (int64_t)gridDim.x * 4) {
+    const int64_t c0 = chunk * 64;
+    const int cnt = (int)(n_entries - c0 < 64 ? n_entries - c0 : 64);
+    uint32_t my_key = kBadKey, my_u = 0;
+    float my_coef = 0.f;
+    if (lane < cnt) {
+      my_key = keys[c0 + lane];
+      if (my_key >= (uint32_t)n_items) my_key = kBadKey;          // dropped slots carry the key n_items and sort last
+      const uint64_t p = payload[c0 + lane];
+      my_u = (uint32_t)(p >> 32);
+      my_coef = __builtin_bit_cast(float, (uint32_t)p);
+    }
+    if ((uint32_t)__builtin_amdgcn_readfirstlane((int)my_key) == kBadKey) continue;   // sorted: nothing live from here on
+    uint32_t cur = kBadKey;
+    float acc[NV];
+    float run_n = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = 0.f;
+    auto flush = [&]() {
+      if (cur != kBadKey) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          const int c = lane + 64 * v;
+          if (c < d) atomicAdd(grad_item + (int64_t)cur * d + c, acc[v] + c_self * run_n * item_tab[(int64_t)cur * d + c]);
+        }
+      }
+    };
+    constexpr int kGather = NV == 1 ? 16 : 8;
+    for (int e0 = 0; e0 < cnt; e0 += kGather) {
+      uint32_t key[kGather];
+      float coef[kGather], row[kGather][NV];
+#pragma unroll
+      for (int q = 0; q < kGather; ++q) {
+        const int e = e0 + q < cnt ? e0 + q : cnt - 1;
+        key[q] = e0 + q < cnt ? (uint32_t)__builtin_amdgcn_readlane((int)my_key, e) : kBadKey;
+        coef[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_coef), e));
+        const int64_t src = key[q] != kBadKey ? (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)my_u, e) : 0;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          const int c = lane + 64 * v;
+          row[q][v] = c < d ? user_tab[src * d + c] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < kGather; ++q) {
+        if (key[q] == kBadKey) continue;
+        if (key[q] != cur) {
+          flush();
+          cur = key[q];
+          run_n = 0.f;
+#pragma unroll
+          for (int v = 0; v < NV; ++v) acc[v] = 0.f;
+        }
+        run_n += 1.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[v] += coef[q] * row[q][v];
+      }
+    }
+    flush();
+  }
+}
+
+size_t sort_u32_u64_temp_bytes(int64_t n) {
+  size_t bytes = 0;
+  uint32_t* k = nullptr;
+  uint64_t* v = nullptr;
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, (size_t)n, 0, 32, (hipStream_t)0);
+  return bytes;
 }
 
 int fwd_blocks(int64_t batch) {
@@ -524,12 +615,53 @@ extern "C" int32_t gcr_bpr_edge_values_f32(const float* dloss_dx, const int64_t*
 
 extern "C" int32_t gcr_bpr_neg_block_f32(const float* dloss_dx, const int64_t* j_idx, const int64_t* u_idx, int64_t batch,
                                          int32_t n_neg, int64_t n_items, const float* grad_sums, int32_t* col, float* val,
-                                         float* dropped_per_user, void* stream) {
+                                         float* dropped_per_user, uint32_t* sort_key, uint64_t* sort_payload, void* stream) {
   GCR_CHECK_ARG(batch >= 0 && n_neg >= 1 && n_items >= 1 && batch * n_neg < (1ll << 40));
   if (batch == 0) return GCR_OK;
   GCR_CHECK_ARG(dloss_dx && j_idx && u_idx && grad_sums && col && val && dropped_per_user);
+  GCR_CHECK_ARG((sort_key != nullptr) == (sort_payload != nullptr) && (!sort_key || n_items < 0xFFFFFFFFll));
   const int64_t want = (batch * n_neg + 255) / 256;
   hipLaunchKernelGGL(bpr_neg_block_kernel, dim3((unsigned)(want > 65536 ? 65536 : want)), dim3(256), 0, (hipStream_t)stream,
-                     dloss_dx, j_idx, u_idx, batch, (int)n_neg, n_items, grad_sums, col, val, dropped_per_user);
+                     dloss_dx, j_idx, u_idx, batch, (int)n_neg, n_items, grad_sums, col, val, dropped_per_user, sort_key,
+                     sort_payload);
+  return GCR_LAUNCH_STATUS();
+}
+
+extern "C" int64_t gcr_sort_pairs_u64_workspace_bytes(int64_t n) {
+  return n <= 0 ? 0 : (int64_t)sort_u32_u64_temp_bytes(n);
+}
+
+extern "C" int32_t gcr_sort_pairs_u64(const uint32_t* keys, const uint64_t* payload, int64_t n, int64_t n_keys,
+                                      uint32_t* keys_sorted, uint64_t* payload_sorted, void* workspace, void* stream) {
+  GCR_CHECK_ARG(n >= 0 && n < (1ll << 31) && n_keys >= 0 && n_keys < 0xFFFFFFFFll);
+  if (n == 0) return GCR_OK;
+  GCR_CHECK_ARG(keys && payload && keys_sorted && payload_sorted && workspace);
+  size_t tmp_bytes = sort_u32_u64_temp_bytes(n);
+  int bits = 1;                                            // keys live in [0, n_keys]
+  while (bits < 32 && ((uint64_t)n_keys >> bits) != 0) ++bits;
+  hipError_t err = rocprim::radix_sort_pairs(workspace, tmp_bytes, keys, keys_sorted, payload, payload_sorted, (size_t)n, 0,
+                                             bits, (hipStream_t)stream);
+  if (err != hipSuccess) return gcr_hip_status(err);
+  return GCR_LAUNCH_STATUS();
+}
+
+extern "C" int32_t gcr_bpr_neg_items_sorted_f32(const float* user_tab, const float* item_tab, int32_t d,
+                                                const uint32_t* keys_sorted, const uint64_t* payload_sorted,
+                                                int64_t n_entries, int64_t n_users, int64_t n_items,
+                                                const float* grad_sums, float* grad_item, void* stream) {
+  GCR_CHECK_ARG(n_entries >= 0 && d >= 1 && d <= 256 && n_users >= 0 && n_users < (1ll << 32) && n_items >= 0 &&
+                n_items < 0xFFFFFFFFll);
+  if (n_entries == 0) return GCR_OK;
+  GCR_CHECK_ARG(user_tab && item_tab && keys_sorted && payload_sorted && grad_sums && grad_item);
+  const int64_t want = ((n_entries + 63) / 64 + 3) / 4;
+  const unsigned blocks = (unsigned)(want < 1 ? 1 : (want > 65536 ? 65536 : want));
+#define GCR_NIS(NV)                                                                                                  \
+  hipLaunchKernelGGL((bpr_neg_items_sorted_kernel<NV>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, user_tab,   \
+                     item_tab, d, keys_sorted, payload_sorted, n_entries, n_items, grad_sums, grad_item)
+  if (d <= 64) GCR_NIS(1);
+  else if (d <= 128) GCR_NIS(2);
+  else if (d <= 192) GCR_NIS(3);
+  else GCR_NIS(4);
+#undef GCR_NIS
   return GCR_LAUNCH_STATUS();
 }

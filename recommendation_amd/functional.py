@@ -452,6 +452,9 @@ def _as_index(t, device):
 # batches at least this large take the sorted backward (gcr_bpr_bwd_sorted_f32); below it the three
 # row atomics per sample are cheaper than the sorts
 BPR_SORTED_MIN_BATCH = 1 << 18
+# full-batch edge-list BPR: order the negatives by item together with their (user, coefficient) payload (one 12-byte
+# sort) instead of sorting an index and gathering through it
+BPR_NEG_PAYLOAD_SORT = True
 _ORDER_CACHE = {}
 
 
@@ -601,13 +604,30 @@ class _BprEdgeSums(torch.autograd.Function):
         ncol = torch.empty(batch * n_neg, dtype=torch.int32, device=table.device)
         nval = torch.empty(batch * n_neg, dtype=torch.float32, device=table.device)
         dropped_u = torch.zeros(n_users, dtype=torch.float32, device=table.device)
+        payload_sort = BPR_NEG_PAYLOAD_SORT and batch * n_neg < 2 ** 31
+        skey = spay = None
+        if payload_sort:                     # the same walk also writes the item side's (key j, payload (u, value)) pairs
+            skey = torch.empty(batch * n_neg, dtype=torch.int32, device=table.device)
+            spay = torch.empty(batch * n_neg, dtype=torch.int64, device=table.device)
         _lib.check(L.gcr_bpr_neg_block_f32(_lib.dptr(dldx), _lib.dptr(j_idx), _lib.dptr(u_idx), batch, n_neg, n_items,
                                            _lib.dptr(gs), _lib.dptr(ncol), _lib.dptr(nval), _lib.dptr(dropped_u),
-                                           _lib.cur_stream(table.device)), "gcr_bpr_neg_block_f32")
+                                           _lib.dptr(skey), _lib.dptr(spay), _lib.cur_stream(table.device)),
+                   "gcr_bpr_neg_block_f32")
         nb.col, nb.val = ncol, nval
         spmm_into(nb, table[n_users:], acc_in=gu, acc_out=gu)
         gu.addcmul_(table[:n_users], (2.0 * gs[1] * (graph.row_degrees()[:n_users] - dropped_u)).unsqueeze(1))
-        # the negatives' item rows (fresh every step: one sort, one sorted scatter)
+        # the negatives' item rows (fresh every step: one sort, one sorted scatter).  The sort carries (user, value) with
+        # the key, so the scatter streams its three arrays instead of chasing perm -> sample -> (u_idx, dloss_dx)
+        if payload_sort:
+            ks, ps = torch.empty_like(skey), torch.empty_like(spay)
+            ws = torch.empty(int(L.gcr_sort_pairs_u64_workspace_bytes(batch * n_neg)), dtype=torch.uint8, device=table.device)
+            _lib.check(L.gcr_sort_pairs_u64(_lib.dptr(skey), _lib.dptr(spay), batch * n_neg, n_items, _lib.dptr(ks),
+                                            _lib.dptr(ps), _lib.dptr(ws), _lib.cur_stream(table.device)), "gcr_sort_pairs_u64")
+            _lib.check(L.gcr_bpr_neg_items_sorted_f32(_lib.dptr(table[:n_users]), _lib.dptr(table[n_users:]), table.shape[1],
+                                                      _lib.dptr(ks), _lib.dptr(ps), batch * n_neg, n_users, n_items,
+                                                      _lib.dptr(gs), _lib.dptr(gi), _lib.cur_stream(table.device)),
+                       "gcr_bpr_neg_items_sorted_f32")
+            return gfull, None, None, None, None
         kj, pj, _ = _sorted_order(j_idx.reshape(-1), n_items)
         _lib.check(L.gcr_bpr_bwd_sorted_f32(
             _lib.dptr(table[:n_users]), _lib.dptr(table[n_users:]), table.shape[1], _lib.dptr(u_idx), None,

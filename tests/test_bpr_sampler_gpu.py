@@ -280,13 +280,17 @@ def test_bpr_on_split_table_writes_one_gradient_buffer():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_neg,variant,d", [(1, 2, 64), (3, 2, 64), (1, 0, 32)])
-def test_full_batch_over_the_graphs_edges_equals_the_sampled_form(Fn, n_neg, variant, d):
+@pytest.mark.parametrize("payload", [True, False])
+@pytest.mark.parametrize("n_neg,variant,d", [(1, 2, 64), (3, 2, 64), (1, 0, 32), (2, 2, 128)])
+def test_full_batch_over_the_graphs_edges_equals_the_sampled_form(Fn, monkeypatch, n_neg, variant, d, payload):
     """functional.bpr_edge_sums — the full batch of lightgcn.py:91-118 over the training graph's own edge list, backward's
     positive-pair parts as ONE SpMM with per-edge coefficients — against bpr_sums on the same (u, i, j) triples: same
     sums, gradients of both tables equal to 2e-5 of their largest entry.  Duplicate interactions (kept by the raw
-    multigraph), isolated users / items, n_neg = 1 / 3, a negative id out of range."""
+    multigraph), isolated users / items, n_neg = 1 / 3, a negative id out of range.  payload: the negatives' item rows from
+    the sort that carries (user, coefficient) with the key (gcr_sort_pairs_u64 + gcr_bpr_neg_items_sorted_f32), or from
+    the index sort."""
     import recommendation_amd as ra
+    monkeypatch.setattr(Fn, "BPR_NEG_PAYLOAD_SORT", payload)
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev).manual_seed(17 + n_neg)
     n_u, n_i, e = 20_000, 5_000, 300_000

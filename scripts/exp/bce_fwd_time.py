@@ -17,3 +17,15 @@ for grad in (False, True):
         Fn.bce_softplus_rowsum(aa, b)
     torch.cuda.synchronize()
     print("with gradient (row sums + o)" if grad else "no gradient (row sums only)", f"{(time.perf_counter() - t) / 5 * 1e3:.2f} ms")
+# forward + both gradients (the item side through gcr_bce_bwd_f32)
+aa = a.clone().requires_grad_(True)
+bb = b.clone().requires_grad_(True)
+w = torch.rand(1 << 18, device="cuda", generator=g)
+for i in range(7):
+    if i == 2:
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+    aa.grad = bb.grad = None
+    torch.dot(Fn.bce_softplus_rowsum(aa, bb), w).backward()
+torch.cuda.synchronize()
+print(f"forward + both gradients {(time.perf_counter() - t) / 5 * 1e3:.2f} ms")

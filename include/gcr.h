@@ -378,6 +378,29 @@ int64_t gcr_weighted_colsum_workspace_bytes(int64_t n, int32_t d);
 int32_t gcr_weighted_colsum_f32(const float* x, const float* w, int64_t n, int32_t d, float* out, void* workspace,
                                 void* stream);
 
+/* MHCN's gates around the library GEMM z = em W (univariate/mhcn.py:404-411 `self_gating`, `self_supervised_gating`):
+ *   forward   out = em * sigmoid(z + bias)                                   bias [d] or NULL
+ *   backward  d_em = g * sig,  d_z = g * em * sig * (1 - sig),  d_bias[c] = sum_r d_z[r][c]   (sig recomputed)
+ * one pass each over row-major [n, d] arrays, d <= 256; d_bias from fixed-order partial sums. */
+int32_t gcr_gate_fwd_f32(const float* em, const float* z, const float* bias, int64_t n, int32_t d, float* out, void* stream);
+int64_t gcr_gate_bwd_workspace_bytes(int64_t n, int32_t d);
+int32_t gcr_gate_bwd_f32(const float* g, const float* em, const float* z, const float* bias, int64_t n, int32_t d,
+                         float* d_em, float* d_z, float* d_bias, void* workspace, void* stream);
+
+/* MHCN's channel attention (univariate/mhcn.py:413-420) over three channel tables e_k [n, d] with the logit vector
+ * v = attention_mat attention^T [d]:  score[k][r] = softmax_k <e_k[r], v>,  mixed[r] = sum_k score[k][r] e_k[r]
+ * (+ extra_scale * extra[r], the `+ simple / 2` of mhcn.py:443; extra may be NULL).  score is [3, n].
+ * Backward for g = d mixed:  d_e_k = score_k g + q_k v with q_k = score_k (<g, e_k> - sum_m score_m <g, e_m>),
+ * d_extra = extra_scale g (NULL: not written), d_v[c] = sum_r sum_k q_k[r] e_k[r][c] (fixed-order partial sums).
+ * d in {32, 64, 128, 256} (gcr_channel_mix_supported; GCR_EUNSUPPORTED otherwise). */
+int32_t gcr_channel_mix_supported(int32_t d);
+int32_t gcr_channel_mix_fwd_f32(const float* e1, const float* e2, const float* e3, const float* v, const float* extra,
+                                float extra_scale, int64_t n, int32_t d, float* mixed, float* score, void* stream);
+int64_t gcr_channel_mix_bwd_workspace_bytes(int64_t n, int32_t d);
+int32_t gcr_channel_mix_bwd_f32(const float* g, const float* e1, const float* e2, const float* e3, const float* v,
+                                const float* score, float extra_scale, int64_t n, int32_t d, float* d_e1, float* d_e2,
+                                float* d_e3, float* d_extra, float* d_v, void* workspace, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * BCE-with-logits over the all-pairs score matrix — the `loss_type == "bce"` branch of LightGCN's training step:
  *   scores = torch.matmul(user_vecs, item_emb.t()); labels = one-hot at pos_i;                 lightgcn.py:110-112

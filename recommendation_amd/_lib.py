@@ -66,6 +66,13 @@ SIGNATURES = {
     "gcr_rows_dot_vec_f32": (c_int32, [_P, _P, c_int64, c_int32, _P, _P]),
     "gcr_weighted_colsum_workspace_bytes": (c_int64, [c_int64, c_int32]),
     "gcr_weighted_colsum_f32": (c_int32, [_P, _P, c_int64, c_int32, _P, _P, _P]),
+    "gcr_gate_fwd_f32": (c_int32, [_P, _P, _P, c_int64, c_int32, _P, _P]),
+    "gcr_gate_bwd_workspace_bytes": (c_int64, [c_int64, c_int32]),
+    "gcr_gate_bwd_f32": (c_int32, [_P, _P, _P, _P, c_int64, c_int32, _P, _P, _P, _P, _P]),
+    "gcr_channel_mix_supported": (c_int32, [c_int32]),
+    "gcr_channel_mix_fwd_f32": (c_int32, [_P, _P, _P, _P, _P, c_float, c_int64, c_int32, _P, _P, _P]),
+    "gcr_channel_mix_bwd_workspace_bytes": (c_int64, [c_int64, c_int32]),
+    "gcr_channel_mix_bwd_f32": (c_int32, [_P, _P, _P, _P, _P, _P, c_float, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "gcr_bce_fwd_o_supported": (c_int32, [c_int32, c_uint32]),
     "gcr_bce_fwd_workspace_bytes": (c_int64, [c_int64, c_int64, c_int32]),
     "gcr_bce_fwd_f32": (c_int32, [_P, c_int64, _P, c_int64, c_int32, _P, _P, _P, c_uint32, _P]),

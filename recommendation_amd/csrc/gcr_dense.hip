@@ -12,6 +12,13 @@
 //                     d x d output to one or two workgroups that walk all n rows (0.52 ms at n = 250K, d = 64:
 //                     6.7 of the 18 ms of config 5's fwd + bwd); here the rows are split over the whole chip on the f32
 //                     MFMA (exact f32 products) and the per-workgroup partials are summed in a fixed order.
+//   gate              out = em * sigmoid(z + bias) and its backward (mhcn.py:404-411 self_gating / self_supervised_gating
+//                     around the library GEMM z = em W): d em, d z and the bias gradient's partial column sums in one pass
+//                     each (torch: add, sigmoid, multiply forward; eight element-wise / reduction launches backward);
+//   channel_mix       mhcn.py:413-420 channel_attention on the logits e_k . v: per row the three logits, their softmax,
+//                     mixed = sum_k score_k e_k (+ scale * extra: the `+ simple / 2` of mhcn.py:443) in one pass; the
+//                     backward gives d e_k = score_k g + dlogit_k v, d extra and the partial sums of d v in one pass
+//                     (torch: ~30 launches per call, three calls per step).
 #include "gcr_common.h"
 
 namespace {
@@ -184,6 +191,141 @@ __global__ __launch_bounds__(256) void weighted_colsum_kernel(const float* __res
   }
 }
 
+__device__ __forceinline__ float sigmoid_f32(float t) { return 1.0f / (1.0f + expf(-t)); }
+
+// thread t owns column t % DP of every (256 / DP)-th row (DP = d rounded up to a power of two <= 256): coalesced rows
+__global__ __launch_bounds__(256) void gate_fwd_kernel(const float* __restrict__ em, const float* __restrict__ z,
+                                                       const float* __restrict__ bias, int64_t n, int d, int dp,
+                                                       float* __restrict__ out) {
+  const int c = threadIdx.x % dp, step = 256 / dp;
+  if (c >= d) return;
+  const float b = bias != nullptr ? bias[c] : 0.f;
+  for (int64_t r = (int64_t)blockIdx.x * step + threadIdx.x / dp; r < n; r += (int64_t)gridDim.x * step) {
+    const int64_t k = r * d + c;
+    out[k] = em[k] * sigmoid_f32(z[k] + b);
+  }
+}
+
+// d_em = g sig, d_z = g em sig (1 - sig), part[block][c] = sum over the block's rows of d_z (the bias gradient)
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ g, const float* __restrict__ em,
+                                                       const float* __restrict__ z, const float* __restrict__ bias, int64_t n,
+                                                       int d, int dp, int64_t rows_per_block, float* __restrict__ d_em,
+                                                       float* __restrict__ d_z, float* __restrict__ part) {
+  __shared__ float red[256];
+  const int c = threadIdx.x % dp, lane_row = threadIdx.x / dp, step = 256 / dp;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = min(n, r0 + rows_per_block);
+  float s = 0.f;
+  if (c < d) {
+    const float b = bias != nullptr ? bias[c] : 0.f;
+    for (int64_t r = r0 + lane_row; r < r1; r += step) {
+      const int64_t k = r * d + c;
+      const float sg = sigmoid_f32(z[k] + b), gv = g[k], e = em[k];
+      d_em[k] = gv * sg;
+      const float dz = gv * e * sg * (1.0f - sg);
+      d_z[k] = dz;
+      s += dz;
+    }
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < dp) {
+    float t = 0.f;
+    for (int k = 0; k < step; ++k) t += red[threadIdx.x + k * dp];
+    if (c < d) part[(int64_t)blockIdx.x * d + c] = t;
+  }
+}
+
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int off = LPR / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// LPR lanes per row, float4 per lane (d = 4 LPR in {32, 64, 128, 256}); score [3, n]
+template <int LPR>
+__global__ __launch_bounds__(256) void channel_mix_fwd_kernel(const float* __restrict__ e1, const float* __restrict__ e2,
+                                                              const float* __restrict__ e3, const float* __restrict__ v,
+                                                              const float* __restrict__ extra, float extra_scale, int64_t n,
+                                                              float* __restrict__ mixed, float* __restrict__ score) {
+  constexpr int D = 4 * LPR, GROUPS = 256 / LPR;
+  const int gl = threadIdx.x % LPR;
+  const float4 v4 = *reinterpret_cast<const float4*>(v + 4 * gl);
+  for (int64_t r = (int64_t)blockIdx.x * GROUPS + threadIdx.x / LPR; r < n; r += (int64_t)gridDim.x * GROUPS) {
+    const int64_t k = r * D + 4 * gl;
+    const float4 a = *reinterpret_cast<const float4*>(e1 + k), b = *reinterpret_cast<const float4*>(e2 + k),
+                 c = *reinterpret_cast<const float4*>(e3 + k);
+    const float l1 = group_sum<LPR>(dot4(a, v4)), l2 = group_sum<LPR>(dot4(b, v4)), l3 = group_sum<LPR>(dot4(c, v4));
+    const float m = fmaxf(l1, fmaxf(l2, l3));
+    const float p1 = expf(l1 - m), p2 = expf(l2 - m), p3 = expf(l3 - m);
+    const float inv = 1.0f / (p1 + p2 + p3);
+    const float s1 = p1 * inv, s2 = p2 * inv, s3 = p3 * inv;
+    float4 o = make_float4(s1 * a.x + s2 * b.x + s3 * c.x, s1 * a.y + s2 * b.y + s3 * c.y, s1 * a.z + s2 * b.z + s3 * c.z,
+                           s1 * a.w + s2 * b.w + s3 * c.w);
+    if (extra != nullptr) {
+      const float4 x = *reinterpret_cast<const float4*>(extra + k);
+      o.x += extra_scale * x.x; o.y += extra_scale * x.y; o.z += extra_scale * x.z; o.w += extra_scale * x.w;
+    }
+    *reinterpret_cast<float4*>(mixed + k) = o;
+    if (gl == 0) {
+      score[r] = s1;
+      score[n + r] = s2;
+      score[2 * n + r] = s3;
+    }
+  }
+}
+
+// d e_k = score_k g + dl_k v with dl_k = score_k (<g, e_k> - sum_m score_m <g, e_m>);  d extra = scale g;
+// part[block][c] = sum over the block's rows of sum_k dl_k e_k[c]  (the gradient of v)
+template <int LPR>
+__global__ __launch_bounds__(256) void channel_mix_bwd_kernel(const float* __restrict__ g, const float* __restrict__ e1,
+                                                              const float* __restrict__ e2, const float* __restrict__ e3,
+                                                              const float* __restrict__ v, const float* __restrict__ score,
+                                                              float extra_scale, int64_t n, int64_t rows_per_block,
+                                                              float* __restrict__ d1, float* __restrict__ d2,
+                                                              float* __restrict__ d3, float* __restrict__ d_extra,
+                                                              float* __restrict__ part) {
+  constexpr int D = 4 * LPR, GROUPS = 256 / LPR;
+  __shared__ float4 red[256];
+  const int gl = threadIdx.x % LPR;
+  const float4 v4 = *reinterpret_cast<const float4*>(v + 4 * gl);
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = min(n, r0 + rows_per_block);
+  float4 dv = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t r = r0 + threadIdx.x / LPR; r < r1; r += GROUPS) {
+    const int64_t k = r * D + 4 * gl;
+    const float4 gv = *reinterpret_cast<const float4*>(g + k);
+    const float4 a = *reinterpret_cast<const float4*>(e1 + k), b = *reinterpret_cast<const float4*>(e2 + k),
+                 c = *reinterpret_cast<const float4*>(e3 + k);
+    const float s1 = score[r], s2 = score[n + r], s3 = score[2 * n + r];
+    const float a1 = group_sum<LPR>(dot4(gv, a)), a2 = group_sum<LPR>(dot4(gv, b)), a3 = group_sum<LPR>(dot4(gv, c));
+    const float abar = s1 * a1 + s2 * a2 + s3 * a3;
+    const float q1 = s1 * (a1 - abar), q2 = s2 * (a2 - abar), q3 = s3 * (a3 - abar);
+    *reinterpret_cast<float4*>(d1 + k) = make_float4(s1 * gv.x + q1 * v4.x, s1 * gv.y + q1 * v4.y, s1 * gv.z + q1 * v4.z, s1 * gv.w + q1 * v4.w);
+    *reinterpret_cast<float4*>(d2 + k) = make_float4(s2 * gv.x + q2 * v4.x, s2 * gv.y + q2 * v4.y, s2 * gv.z + q2 * v4.z, s2 * gv.w + q2 * v4.w);
+    *reinterpret_cast<float4*>(d3 + k) = make_float4(s3 * gv.x + q3 * v4.x, s3 * gv.y + q3 * v4.y, s3 * gv.z + q3 * v4.z, s3 * gv.w + q3 * v4.w);
+    if (d_extra != nullptr)
+      *reinterpret_cast<float4*>(d_extra + k) = make_float4(extra_scale * gv.x, extra_scale * gv.y, extra_scale * gv.z, extra_scale * gv.w);
+    dv.x += q1 * a.x + q2 * b.x + q3 * c.x;
+    dv.y += q1 * a.y + q2 * b.y + q3 * c.y;
+    dv.z += q1 * a.z + q2 * b.z + q3 * c.z;
+    dv.w += q1 * a.w + q2 * b.w + q3 * c.w;
+  }
+  red[threadIdx.x] = dv;
+  __syncthreads();
+  if (threadIdx.x < LPR) {
+    float4 t = red[threadIdx.x];
+    for (int k = 1; k < GROUPS; ++k) {
+      const float4 u = red[threadIdx.x + k * LPR];
+      t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+    }
+    *reinterpret_cast<float4*>(part + (int64_t)blockIdx.x * D + 4 * threadIdx.x) = t;
+  }
+}
+
 int gram_blocks(int64_t n) {
   const int64_t want = (n + 255) / 256;                      // >= 256 rows per workgroup
   return (int)(want < 1 ? 1 : (want > 1024 ? 1024 : want));
@@ -277,5 +419,97 @@ extern "C" int32_t gcr_rows_dot_vec_f32(const float* x, const float* v, int64_t 
   const int64_t want = (n + 15) / 16;
   hipLaunchKernelGGL(rows_dot_vec_kernel, dim3((unsigned)(want > 16384 ? 16384 : want)), dim3(256), 0, (hipStream_t)stream,
                      x, v, n, (int)d, out);
+  return GCR_LAUNCH_STATUS();
+}
+
+extern "C" int32_t gcr_gate_fwd_f32(const float* em, const float* z, const float* bias, int64_t n, int32_t d, float* out,
+                                    void* stream) {
+  GCR_CHECK_ARG(n >= 0 && d >= 1 && d <= 256);
+  if (n == 0) return GCR_OK;
+  GCR_CHECK_ARG(em != nullptr && z != nullptr && out != nullptr);
+  int dp = 1;
+  while (dp < d) dp <<= 1;
+  const int64_t want = (n + (256 / dp) * 4 - 1) / ((256 / dp) * 4);
+  hipLaunchKernelGGL(gate_fwd_kernel, dim3((unsigned)(want > 16384 ? 16384 : want)), dim3(256), 0, (hipStream_t)stream, em, z,
+                     bias, n, (int)d, dp, out);
+  return GCR_LAUNCH_STATUS();
+}
+
+extern "C" int64_t gcr_gate_bwd_workspace_bytes(int64_t n, int32_t d) {
+  if (n <= 0 || d < 1 || d > 256) return 0;
+  return (int64_t)gram_blocks(n) * d * (int64_t)sizeof(float);
+}
+
+extern "C" int32_t gcr_gate_bwd_f32(const float* g, const float* em, const float* z, const float* bias, int64_t n, int32_t d,
+                                    float* d_em, float* d_z, float* d_bias, void* workspace, void* stream) {
+  GCR_CHECK_ARG(n >= 0 && d >= 1 && d <= 256 && d_bias != nullptr);
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) return gcr_hip_status(hipMemsetAsync(d_bias, 0, sizeof(float) * (size_t)d, s));
+  GCR_CHECK_ARG(g != nullptr && em != nullptr && z != nullptr && d_em != nullptr && d_z != nullptr && workspace != nullptr);
+  const int nb = gram_blocks(n);
+  const int64_t per = (n + nb - 1) / nb;
+  int dp = 1;
+  while (dp < d) dp <<= 1;
+  float* part = reinterpret_cast<float*>(workspace);
+  hipLaunchKernelGGL(gate_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, s, g, em, z, bias, n, (int)d, dp, per, d_em, d_z, part);
+  int32_t st = GCR_LAUNCH_STATUS();
+  if (st != GCR_OK) return st;
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)((d + 63) / 64)), dim3(256), 0, s, part, nb, (int)d, d_bias);
+  return GCR_LAUNCH_STATUS();
+}
+
+extern "C" int32_t gcr_channel_mix_supported(int32_t d) { return d == 32 || d == 64 || d == 128 || d == 256; }
+
+extern "C" int32_t gcr_channel_mix_fwd_f32(const float* e1, const float* e2, const float* e3, const float* v, const float* extra,
+                                           float extra_scale, int64_t n, int32_t d, float* mixed, float* score, void* stream) {
+  GCR_CHECK_ARG(n >= 0);
+  if (!gcr_channel_mix_supported(d)) return GCR_EUNSUPPORTED;
+  if (n == 0) return GCR_OK;
+  GCR_CHECK_ARG(e1 && e2 && e3 && v && mixed && score);
+  hipStream_t s = (hipStream_t)stream;
+  const int groups = 256 / (d / 4);
+  const int64_t want = (n + groups * 2 - 1) / (groups * 2);
+  const dim3 grid((unsigned)(want > 16384 ? 16384 : want));
+#define GCR_MIXF(LPR) \
+  hipLaunchKernelGGL((channel_mix_fwd_kernel<LPR>), grid, dim3(256), 0, s, e1, e2, e3, v, extra, extra_scale, n, mixed, score)
+  switch (d) {
+    case 32: GCR_MIXF(8); break;
+    case 64: GCR_MIXF(16); break;
+    case 128: GCR_MIXF(32); break;
+    default: GCR_MIXF(64); break;
+  }
+#undef GCR_MIXF
+  return GCR_LAUNCH_STATUS();
+}
+
+extern "C" int64_t gcr_channel_mix_bwd_workspace_bytes(int64_t n, int32_t d) {
+  if (n <= 0 || !gcr_channel_mix_supported(d)) return 0;
+  return (int64_t)gram_blocks(n) * d * (int64_t)sizeof(float);
+}
+
+extern "C" int32_t gcr_channel_mix_bwd_f32(const float* g, const float* e1, const float* e2, const float* e3, const float* v,
+                                           const float* score, float extra_scale, int64_t n, int32_t d, float* d_e1, float* d_e2,
+                                           float* d_e3, float* d_extra, float* d_v, void* workspace, void* stream) {
+  GCR_CHECK_ARG(n >= 0 && d_v != nullptr);
+  if (!gcr_channel_mix_supported(d)) return GCR_EUNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) return gcr_hip_status(hipMemsetAsync(d_v, 0, sizeof(float) * (size_t)d, s));
+  GCR_CHECK_ARG(g && e1 && e2 && e3 && v && score && d_e1 && d_e2 && d_e3 && workspace);
+  const int nb = gram_blocks(n);
+  const int64_t per = (n + nb - 1) / nb;
+  float* part = reinterpret_cast<float*>(workspace);
+#define GCR_MIXB(LPR)                                                                                                       \
+  hipLaunchKernelGGL((channel_mix_bwd_kernel<LPR>), dim3((unsigned)nb), dim3(256), 0, s, g, e1, e2, e3, v, score, extra_scale, \
+                     n, per, d_e1, d_e2, d_e3, d_extra, part)
+  switch (d) {
+    case 32: GCR_MIXB(8); break;
+    case 64: GCR_MIXB(16); break;
+    case 128: GCR_MIXB(32); break;
+    default: GCR_MIXB(64); break;
+  }
+#undef GCR_MIXB
+  int32_t st = GCR_LAUNCH_STATUS();
+  if (st != GCR_OK) return st;
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)((d + 63) / 64)), dim3(256), 0, s, part, nb, (int)d, d_v);
   return GCR_LAUNCH_STATUS();
 }

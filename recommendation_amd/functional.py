@@ -306,6 +306,97 @@ def rows_dot_vec(em, v):
     return _RowsDotVec.apply(em.contiguous(), v)
 
 
+class _Gate(torch.autograd.Function):
+    """em * sigmoid(z + bias) (mhcn.py:404-411 around the GEMM z = em W) as one pass forward (gcr_gate_fwd_f32) and one
+    backward (gcr_gate_bwd_f32: d em, d z and the bias gradient; the sigmoid is recomputed from the saved z)."""
+
+    @staticmethod
+    def forward(ctx, em, z, bias):
+        em, z = em.contiguous(), z.contiguous()
+        b = None if bias is None else bias.reshape(-1).contiguous()
+        out = torch.empty_like(em)
+        n, d = em.shape
+        _lib.check(_lib.lib().gcr_gate_fwd_f32(_lib.dptr(em), _lib.dptr(z), _lib.dptr(b), n, d, _lib.dptr(out),
+                                               _lib.cur_stream(em.device)), "gcr_gate_fwd_f32")
+        ctx.save_for_backward(em, z, b)
+        ctx.bias_shape = None if bias is None else bias.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        em, z, b = ctx.saved_tensors
+        L = _lib.lib()
+        n, d = em.shape
+        g = g.contiguous()
+        d_em, d_z = torch.empty_like(em), torch.empty_like(z)
+        d_b = torch.empty(d, dtype=torch.float32, device=em.device)
+        ws = torch.empty(max(int(L.gcr_gate_bwd_workspace_bytes(n, d)), 4) // 4, dtype=torch.float32, device=em.device)
+        _lib.check(L.gcr_gate_bwd_f32(_lib.dptr(g), _lib.dptr(em), _lib.dptr(z), _lib.dptr(b), n, d, _lib.dptr(d_em),
+                                      _lib.dptr(d_z), _lib.dptr(d_b), _lib.dptr(ws), _lib.cur_stream(em.device)),
+                   "gcr_gate_bwd_f32")
+        return d_em, d_z, (None if ctx.bias_shape is None else d_b.reshape(ctx.bias_shape))
+
+
+def gate(em, z, bias=None):
+    """`em * torch.sigmoid(z + bias)` — mhcn.py:405-406 / 409-410 with z = em @ W; em, z float32 [n, d], bias [1, d] or [d]."""
+    if not em.is_cuda or em.dim() != 2 or z.shape != em.shape or em.dtype != torch.float32 or z.dtype != torch.float32 \
+            or em.shape[1] > 256 or (bias is not None and bias.numel() != em.shape[1]):
+        return em * torch.sigmoid(z if bias is None else z + bias)
+    return _Gate.apply(em, z, bias)
+
+
+class _ChannelMix(torch.autograd.Function):
+    """mhcn.py:413-420 on the logits e_k . v: (mixed, score) in one pass, the backward in one pass + the partial-sum
+    reduction of d v (gcr_channel_mix_fwd_f32 / gcr_channel_mix_bwd_f32)."""
+
+    @staticmethod
+    def forward(ctx, e1, e2, e3, v, extra, extra_scale):
+        L = _lib.lib()
+        e1, e2, e3, v = e1.contiguous(), e2.contiguous(), e3.contiguous(), v.contiguous()
+        ex = None if extra is None else extra.contiguous()
+        n, d = e1.shape
+        mixed = torch.empty_like(e1)
+        score = torch.empty(3, n, dtype=torch.float32, device=e1.device)
+        _lib.check(L.gcr_channel_mix_fwd_f32(_lib.dptr(e1), _lib.dptr(e2), _lib.dptr(e3), _lib.dptr(v), _lib.dptr(ex),
+                                             float(extra_scale), n, d, _lib.dptr(mixed), _lib.dptr(score),
+                                             _lib.cur_stream(e1.device)), "gcr_channel_mix_fwd_f32")
+        ctx.save_for_backward(e1, e2, e3, v, score)
+        ctx.extra_scale, ctx.has_extra = float(extra_scale), extra is not None
+        ctx.mark_non_differentiable(score)
+        return mixed, score
+
+    @staticmethod
+    def backward(ctx, g, _g_score):
+        e1, e2, e3, v, score = ctx.saved_tensors
+        L = _lib.lib()
+        n, d = e1.shape
+        g = g.contiguous()
+        d1, d2, d3 = torch.empty_like(e1), torch.empty_like(e1), torch.empty_like(e1)
+        dx = torch.empty_like(e1) if ctx.has_extra else None
+        dv = torch.empty(d, dtype=torch.float32, device=e1.device)
+        ws = torch.empty(max(int(L.gcr_channel_mix_bwd_workspace_bytes(n, d)), 4) // 4, dtype=torch.float32, device=e1.device)
+        _lib.check(L.gcr_channel_mix_bwd_f32(_lib.dptr(g), _lib.dptr(e1), _lib.dptr(e2), _lib.dptr(e3), _lib.dptr(v),
+                                             _lib.dptr(score), ctx.extra_scale, n, d, _lib.dptr(d1), _lib.dptr(d2),
+                                             _lib.dptr(d3), _lib.dptr(dx), _lib.dptr(dv), _lib.dptr(ws),
+                                             _lib.cur_stream(e1.device)), "gcr_channel_mix_bwd_f32")
+        return d1, d2, d3, dv, dx, None
+
+
+def channel_mix(e1, e2, e3, v, extra=None, extra_scale=0.0):
+    """(mixed, score) of mhcn.py:413-420 for three channel tables [n, d] and the logit vector v [d]:
+    score = softmax over the channels of e_k @ v ([3, n], not differentiable on this path), mixed = sum_k score_k e_k
+    (+ extra_scale * extra).  Widths other than 32 / 64 / 128 / 256 and CPU tensors take the torch expression."""
+    fused = e1.is_cuda and e1.dim() == 2 and e1.dtype == torch.float32 and e2.shape == e1.shape and e3.shape == e1.shape \
+        and v.dim() == 1 and v.numel() == e1.shape[1] and (extra is None or extra.shape == e1.shape) \
+        and bool(_lib.lib().gcr_channel_mix_supported(e1.shape[1]))
+    if not fused:
+        logits = torch.stack([rows_dot_vec(e, v) for e in (e1, e2, e3)])
+        score = torch.softmax(logits, dim=0)
+        mixed = score[0].unsqueeze(1) * e1 + score[1].unsqueeze(1) * e2 + score[2].unsqueeze(1) * e3
+        return (mixed if extra is None else mixed + extra_scale * extra), score
+    return _ChannelMix.apply(e1, e2, e3, v, extra, float(extra_scale))
+
+
 class _NormProp(torch.autograd.Function):
     """One SEPT layer: y = normalize(A x) row-wise (sept.py:223-224); saves y and 1/||Ax||."""
 

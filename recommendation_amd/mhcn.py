@@ -49,19 +49,23 @@ class MHCNEncoder(nn.Module):
 
     # -- dense pieces (mhcn.py:404-420) ---------------------------------------------------------
     def self_gating(self, em, channel):
-        return em * torch.sigmoid(Fn.dense_proj(em, self.gating_weights[str(channel)]) + self.gating_bias[str(channel)])
+        return Fn.gate(em, Fn.dense_proj(em, self.gating_weights[str(channel)]), self.gating_bias[str(channel)])
 
     def self_supervised_gating(self, em, channel):
-        return em * torch.sigmoid(Fn.dense_proj(em, self.sgating_weights[str(channel)]) + self.sgating_bias[str(channel)])
+        return Fn.gate(em, Fn.dense_proj(em, self.sgating_weights[str(channel)]), self.sgating_bias[str(channel)])
 
-    def channel_attention(self, *channel_embeddings):
-        # mhcn.py:414: sum(attention * (e @ attention_mat), 1) = e @ (attention_mat @ attention^T): one [U, d] x [d] product
-        # per channel instead of a [U, d] x [d, d] GEMM, a multiply and a row reduction (and their three backward passes)
+    def channel_attention(self, *channel_embeddings, extra=None, extra_scale=0.0):
+        """mhcn.py:413-420 -> (mixed, score [3, U]).  sum(attention * (e @ attention_mat), 1) = e @ (attention_mat @
+        attention^T): one [U, d] x [d] product per channel instead of a [U, d] x [d, d] GEMM, a multiply and a row
+        reduction; logits, softmax and the weighted sum are one pass (Fn.channel_mix).  extra / extra_scale: a fourth table
+        added to `mixed` in the same pass (the `+ simple_embeddings / 2` of mhcn.py:443,460)."""
         v = (self.attention_mat @ self.attention.t()).squeeze(1)
+        if len(channel_embeddings) == 3:
+            return Fn.channel_mix(*channel_embeddings, v, extra=extra, extra_scale=extra_scale)
         logits = torch.stack([Fn.rows_dot_vec(e, v) for e in channel_embeddings])
         score = torch.softmax(logits, dim=0)
         mixed = sum(score[k].unsqueeze(1) * e for k, e in enumerate(channel_embeddings))
-        return mixed, score
+        return (mixed if extra is None else mixed + extra_scale * extra), score
 
     # -- the layer loop (mhcn.py:422-466) -------------------------------------------------------
     def _five_spmm(self, c1, c2, c3, mixed, items):
@@ -78,13 +82,12 @@ class MHCNEncoder(nn.Module):
         items = self.item_embeddings
         sums = [c1, c2, c3, simple, items]          # running sums of the layer lists (layer 0 = the inputs)
         for _ in range(self.n_layers):
-            mixed, _ = self.channel_attention(c1, c2, c3)
-            mixed = mixed + simple / 2
+            mixed, _ = self.channel_attention(c1, c2, c3, extra=simple, extra_scale=0.5)
             (c1, n1), (c2, n2), (c3, n3), (new_items, n_i), (simple, n_s) = self._five_spmm(c1, c2, c3, mixed, items)
             sums = [sums[0] + n1, sums[1] + n2, sums[2] + n3, sums[3] + n_s, sums[4] + n_i]
             items = new_items
-        final_user, _ = self.channel_attention(sums[0], sums[1], sums[2])
-        return final_user + sums[3] / 2, sums[4]
+        final_user, _ = self.channel_attention(sums[0], sums[1], sums[2], extra=sums[3], extra_scale=0.5)
+        return final_user, sums[4]
 
     def hierarchical_self_supervision(self, em, adj: CsrGraph, perms=None):
         """mhcn.py:480-506.  perms: the three row permutations the reference draws with torch.randperm
@@ -169,16 +172,15 @@ class ShardedMHCNEncoder(MHCNEncoder):
         items = self.item_embeddings
         sums = [c1, c2, c3, simple, items]
         for _ in range(self.n_layers):
-            mixed, _ = self.channel_attention(c1, c2, c3)
-            mixed = mixed + simple / 2
+            mixed, _ = self.channel_attention(c1, c2, c3, extra=simple, extra_scale=0.5)
             (c1, n1), (c2, n2), (c3, n3) = gd.sharded_channel_layer(ch, [c1, c2, c3], ops.channel_dual, ops.channel_spmm_t)
             new_items = gd.all_reduce_sum(ops.spmm(self.R.t, mixed), ch.group)      # R^T mixed: sum over the ranks' users
             n_i = torch.nn.functional.normalize(new_items, p=2, dim=1)
             simple, n_s = ops.dual(self.R, items)
             sums = [sums[0] + n1, sums[1] + n2, sums[2] + n3, sums[3] + n_s, sums[4] + n_i]
             items = new_items
-        final_user, _ = self.channel_attention(sums[0], sums[1], sums[2])
-        return final_user + sums[3] / 2, sums[4]
+        final_user, _ = self.channel_attention(sums[0], sums[1], sums[2], extra=sums[3], extra_scale=0.5)
+        return final_user, sums[4]
 
     def replicated_parameters(self):
         return [p for n, p in self.named_parameters() if n != "user_embeddings"]

@@ -94,6 +94,53 @@ def test_cfg2_full_batch_bpr_and_sampler(cfg2):
     assert float(sums[4]) == 0.0
 
 
+def test_cfg2_full_batch_bce_value_and_gradients(cfg2):
+    """lightgcn.py:109-113 on the full batch of the benchmark graph (E = 10M samples x I = 100K items = 10^12 logits in
+    the reference; 10^11 pairs here, by distinct user): the loss against a float64 evaluation of ALL U x I scores on the
+    GPU (slabs of 4096 users), the gradient rows of 512 sampled users and 256 sampled items against float64."""
+    from recommendation_amd import functional as Fn
+    g, x0, n_u, n_i = cfg2["graph"], cfg2["x0"], cfg2["n_u"], cfg2["n_i"]
+    users, items = cfg2["users"], cfg2["items"]
+    e = users.numel()
+    with torch.no_grad():                                     # scores of a trained-model magnitude (|s| up to a few units)
+        table = Fn.lightgcn_propagate(g, x0 * 40.0, 3, combine="sum")
+    table = table.clone().requires_grad_(True)
+    loss = Fn.bce_edge_loss(g, table, n_u)
+    loss.backward()
+    grad = table.grad
+    a64, b64 = table.detach()[:n_u].double(), table.detach()[n_u:].double()
+    deg = g.row_degrees()[:n_u].double()
+    soft = torch.zeros((), dtype=torch.float64, device=table.device)
+    for u0 in range(0, n_u, 4096):
+        sc = a64[u0:u0 + 4096] @ b64.T
+        soft += (torch.nn.functional.softplus(sc).sum(1) * deg[u0:u0 + 4096]).sum()
+    pos = torch.zeros((), dtype=torch.float64, device=table.device)
+    for k0 in range(0, e, 1 << 21):
+        pos += (a64[users[k0:k0 + (1 << 21)]] * b64[items[k0:k0 + (1 << 21)]]).sum()
+    ref = float((soft - pos) / (float(e) * n_i))
+    assert float(loss.detach()) == pytest.approx(ref, rel=1e-5)
+    gen = torch.Generator(device=table.device).manual_seed(5)
+    norm = float(e) * n_i
+    # users: deg_u sum_i sigmoid(s_ui) b_i - sum_{i in N(u)} b_i
+    su = torch.randint(0, n_u, (512,), device=table.device, generator=gen)
+    want_u = (torch.sigmoid(a64[su] @ b64.T) @ b64) * deg[su].unsqueeze(1)
+    adj_u = torch.zeros(n_u, 64, dtype=torch.float64, device=table.device).index_add_(0, users, b64[items])
+    want_u = (want_u - adj_u[su]) / norm
+    del adj_u
+    got_u = grad[su].double()
+    assert float((got_u - want_u).abs().max()) <= 1e-5 * float(want_u.abs().max())
+    # items: sum_u deg_u sigmoid(s_ui) a_u - sum_{u in N(i)} a_u
+    si = torch.randint(0, n_i, (256,), device=table.device, generator=gen)
+    want_i = torch.zeros(256, 64, dtype=torch.float64, device=table.device)
+    for u0 in range(0, n_u, 1 << 16):
+        sg = torch.sigmoid(a64[u0:u0 + (1 << 16)] @ b64[si].T) * deg[u0:u0 + (1 << 16)].unsqueeze(1)
+        want_i += sg.T @ a64[u0:u0 + (1 << 16)]
+    adj_i = torch.zeros(n_i, 64, dtype=torch.float64, device=table.device).index_add_(0, items, a64[users])
+    want_i = (want_i - adj_i[si]) / norm
+    got_i = grad[n_u:][si].double()
+    assert float((got_i - want_i).abs().max()) <= 1e-5 * float(want_i.abs().max())
+
+
 def test_cfg2_horner_sum_is_the_path_the_bench_times(cfg2):
     """bench.py's timed call: `lightgcn_propagate(graph, x0, 3, combine="sum")` without layer outputs — the
     Horner branch (y = NULL, acc_in = x0) — every element against the C oracle's sum of layers

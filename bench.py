@@ -1075,22 +1075,27 @@ def bce_legs(ra, Fn, graph, x0, k_layers, n_u, n_i, dev, timeit):
     d = x0.shape[1]
     m = min(1 << 18, n_u)
     a, b = (x0[:m] * 8).contiguous(), (x0[n_u:] * 8).contiguous()       # trained-scale rows (scores of a few tenths .. units)
-    with torch.no_grad():
-        t_f = _event_ms(lambda: Fn.bce_softplus_rowsum(a, b), 3)
-    ag, bg = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
-
-    def fb():
-        ag.grad = bg.grad = None
-        Fn.bce_softplus_rowsum(ag, bg).sum().backward()
-
-    t_fb = _event_ms(fb, 3)
     pairs = m * n_i
-    out["all_pairs"] = {"shape": f"{m} x {n_i} x {d}", "pairs": pairs, "fwd_ms": round(t_f, 3), "fwd_bwd_ms": round(t_fb, 3),
-                        "pairs_per_s_fwd": pairs / t_f * 1e3, "pairs_per_s_fwd_bwd": pairs / t_fb * 1e3,
-                        "mfma_issued_frac_fwd_bwd": round(6 * 4 * 2.0 * pairs * d / t_fb / 1e9 / BF16_MFMA_PEAK_TF, 4),
-                        "note": "three bf16 planes (rows are not unit rows): 6 MFMA products per f32 product; fwd (no gradient) = "
-                                "softplus row sums only (1 tile product), fwd_bwd = forward with the sigmoid-weighted row sum (2) + "
-                                "item-side backward (2)"}
+    legs = {}
+    for eng, terms in (("auto", 3), ("b3", 6)):
+        with torch.no_grad():
+            t_f = _event_ms(lambda: Fn.bce_softplus_rowsum(a, b, engine=eng), 3)
+        ag, bg = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+
+        def fb():
+            ag.grad = bg.grad = None
+            Fn.bce_softplus_rowsum(ag, bg, engine=eng).sum().backward()
+
+        t_fb = _event_ms(fb, 3)
+        legs[eng] = {"fwd_ms": round(t_f, 3), "fwd_bwd_ms": round(t_fb, 3), "pairs_per_s_fwd": pairs / t_f * 1e3,
+                     "pairs_per_s_fwd_bwd": pairs / t_fb * 1e3, "mfma_products_per_f32_product": terms,
+                     "mfma_issued_frac_fwd_bwd": round(terms * 4 * 2.0 * pairs * d / t_fb / 1e9 / BF16_MFMA_PEAK_TF, 4)}
+    out["all_pairs"] = {"shape": f"{m} x {n_i} x {d}", "pairs": pairs, **legs["auto"],
+                        "three_bf16_planes": legs["b3"],
+                        "note": "default: two f16 planes on rows scaled to unit norm inside the launch, scores un-scaled by the "
+                                "norms (3 MFMA products per f32 product; DESIGN 4.7 states its range); three_bf16_planes: the raw "
+                                "rows on three bf16 planes (6).  fwd (no gradient) = softplus row sums only (1 tile product), "
+                                "fwd_bwd = forward with the sigmoid-weighted row sum (2) + item-side backward (2)"}
     del a, b, ag, bg
 
     def step_leg(model, g, reps):

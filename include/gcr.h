@@ -411,6 +411,13 @@ int32_t gcr_channel_mix_bwd_f32(const float* g, const float* e1, const float* e2
  * GCR_INFONCE_ENGINE_F32 in the flags).  d in {32, 64, 128, 256}.  The O(M d) positive-logit term is
  * gcr_pos_logit_f32 / gcr_infonce_pos_bwd_f32 (or one SpMM when the batch is the graph's edge list).
  * --------------------------------------------------------------------------------------------- */
+/* GCR_BCE_TWO_PLANES (flags of gcr_bce_fwd_f32 / gcr_bce_bwd_f32, d <= 64, not with GCR_INFONCE_ENGINE_F32): run the loops
+ * on TWO f16 planes and three product terms instead of three bf16 planes and six.  The rows are not unit rows, so a pre-pass
+ * takes every row's norm, the loops see unit rows (operands rounded at 2^-22 of the row's norm) and every score is
+ * un-scaled by its two norms before the softplus / sigmoid; the second product carries norm x weight of the streamed row,
+ * shifted into f16 range by a power of two.  Half the matrix-core work; |score error| a few 2^-24 |a_i| |b_j| — the f32 dot
+ * product's own class.  gcr_bce_bwd_f32 with the weights on the stationary rows (w_x) ignores the flag. */
+#define GCR_BCE_TWO_PLANES 8u
 /* 1 when gcr_bce_fwd_f32 can also return o (d <= 64 on the split-operand engine) */
 int32_t gcr_bce_fwd_o_supported(int32_t d, uint32_t flags);
 int64_t gcr_bce_fwd_workspace_bytes(int64_t m, int64_t n, int32_t d);

@@ -1490,8 +1490,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
   constexpr bool BWD = MODE == 0 || MODE == 3;               // per-row weights (MODE 0: and lse) ride with the tiles
   constexpr bool FWD = MODE == 1 || MODE == 2;               // running row sums + the o accumulators
   constexpr bool NOO = MODE == 2 && SIDES == 1;              // BCE row sums only (no gradient wanted): no second product
-  static_assert(MODE < 2 || (std::is_same<E, EngB3>::value && !EXD && NW == 4), "BCE modes: three planes, four waves");
+  // UNS: BCE on two f16 planes.  Its rows are not unit rows, so the launch scales both sides to unit norm (x_scale /
+  // y_scale = 1 / |row|) and every score is UN-SCALED by the two norms before the softplus / sigmoid: lse_x / lse_y carry
+  // the norms, w_y the streamed rows' factor of the second product (norm x weight, pre-scaled into f16 range by hw[0]).
+  constexpr bool UNS = MODE >= 2 && std::is_same<E, EngH2>::value;
+  constexpr bool STATS = (BWD && SIDES != 1) || UNS;         // per-row values of the streamed rows ride with the tiles
+  static_assert(MODE < 2 || (!EXD && NW == 4), "BCE modes: four waves");
   static_assert(MODE != 3 || SIDES == 1 || SIDES == 2, "BCE backward: weights on one side");
+  static_assert(!(UNS && MODE == 3 && SIDES == 1), "two-plane BCE backward: the weights sit on the streamed rows");
   __shared__ __align__(16) unsigned char lds_rm[RING][RM];   // ring: tile t (B, transposed reads), t+1 (A), t+2 (staging)
   __shared__ __align__(16) float st_lse[RING][kTileJ];
   __shared__ __align__(16) float st_w[RING][kTileJ];
@@ -1506,6 +1512,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
   const bool on_x = BWD && row_i < mx && w_x != nullptr;
   const float wl = on_x ? w_x[row_i] * w_mul : 0.f;
   const float lse2l = (MODE == 0 && on_x) ? lse_x[row_i] * kLog2e : 1.0e30f;
+  const float rs = (UNS && row_i < mx) ? lse_x[row_i] : 1.0f;   // UNS: the stationary row's norm
   // FOLDX (statistics on the stationary rows only): the same move as FOLD inside the kernel — |w_i| into the exponent,
   // sgn w_i into the stationary operand (the scores flip with it, hence c_x) and back out of the gradient row at the end:
   //   P_ij = w_i e^{s_ij - lse_i} = sgn_i 2^(c_x s'_ij + e_x)
@@ -1559,11 +1566,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
         r.s[u] = sp[rr * (unsigned)sstride];
         r.live[u] = row < rem;
       }
-      if (BWD && tid < kTileJ) {
+      if ((BWD || UNS) && tid < kTileJ) {
         const int64_t j = j0 + tid;
         const bool on = j < ny && w_y != nullptr;
         sw = on ? w_y[j] * w_mul : 0.f;
-        sl = (MODE == 0 && on) ? lse_y[j] * kLog2e : 1.0e30f;
+        if (UNS) sl = j < ny ? lse_y[j] : 1.0f;             // the streamed row's norm (a masked row: -inf x 1)
+        else sl = (MODE == 0 && on) ? lse_y[j] * kLog2e : 1.0e30f;
       }
     };
     // one third of the staging of one float4: split (x, y), split (z, w), row-major plane stores
@@ -1587,7 +1595,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
 #pragma unroll
           for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<uint2*>(p + pl * S::PLANE) = make_uint2(sa[u][pl], sb[u][pl]);
         }
-        if (BWD && u == 0 && tid < kTileJ) {
+        if ((BWD || UNS) && u == 0 && tid < kTileJ) {
           st_lse[sbuf][tid] = sl;
           st_w[sbuf][tid] = sw;
         }
@@ -1643,7 +1651,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
     // (timing-only build with constants: 1.82 -> 1.66 ms).
     float4 sl4[2], sw4[2];
     auto stats_begin = [&](int sbuf) {
-      if (BWD && SIDES != 1) {
+      if (STATS) {
         sl4[0] = *reinterpret_cast<const float4*>(&st_lse[sbuf][4 * h]);
         sw4[0] = *reinterpret_cast<const float4*>(&st_w[sbuf][4 * h]);
       }
@@ -1651,29 +1659,30 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
     auto p_unit = [&](int m, f32x16& acc, int sbuf, unsigned (&pq)[2][NPL][4]) {
       if (m < 16) {
         const int r = m;
+        float lre = 0.f, wre = 0.f;
+        if (STATS) {
+          const int g = r >> 2, e = r & 3;
+          if (e == 0 && g < 3) {
+            sl4[(g + 1) & 1] = *reinterpret_cast<const float4*>(&st_lse[sbuf][8 * (g + 1) + 4 * h]);
+            sw4[(g + 1) & 1] = *reinterpret_cast<const float4*>(&st_w[sbuf][8 * (g + 1) + 4 * h]);
+          }
+          const float4 l4 = sl4[g & 1], w4 = sw4[g & 1];
+          lre = e == 0 ? l4.x : (e == 1 ? l4.y : (e == 2 ? l4.z : l4.w));
+          wre = e == 0 ? w4.x : (e == 1 ? w4.y : (e == 2 ? w4.z : w4.w));
+        }
+        const float unscale = UNS ? rs * lre : E::kSInv;   // accumulator -> log2-domain score
         if (MODE == 1) {
           acc[r] = __builtin_amdgcn_exp2f(fmaf(acc[r], E::kSInv, p_off));
           psum += acc[r];
         } else if (MODE == 2) {
           float sp, sg;
-          bce_terms(acc[r] * E::kSInv, sp, sg);
+          bce_terms(acc[r] * unscale, sp, sg);
           psum += sp;
-          acc[r] = sg;
+          acc[r] = UNS ? sg * wre : sg;
         } else {
-          float lre = 0.f, wre = 0.f;
-          if (SIDES != 1) {
-            const int g = r >> 2, e = r & 3;
-            if (e == 0 && g < 3) {
-              sl4[(g + 1) & 1] = *reinterpret_cast<const float4*>(&st_lse[sbuf][8 * (g + 1) + 4 * h]);
-              sw4[(g + 1) & 1] = *reinterpret_cast<const float4*>(&st_w[sbuf][8 * (g + 1) + 4 * h]);
-            }
-            const float4 l4 = sl4[g & 1], w4 = sw4[g & 1];
-            lre = e == 0 ? l4.x : (e == 1 ? l4.y : (e == 2 ? l4.z : l4.w));
-            wre = e == 0 ? w4.x : (e == 1 ? w4.y : (e == 2 ? w4.z : w4.w));
-          }
           const float sc = acc[r];
           if (MODE == 3) {
-            acc[r] = (SIDES == 1 ? wl : wre) * bce_sigmoid(sc * E::kSInv);
+            acc[r] = (SIDES == 1 ? wl : wre) * bce_sigmoid(sc * unscale);
           } else if (SIDES == 1) acc[r] = __builtin_amdgcn_exp2f(fmaf(sc, c_x, e_x));
           else if (FOLD) acc[r] = __builtin_amdgcn_exp2f(fmaf(sc, wre, lre));
           else if (SIDES == 2) acc[r] = wre * __builtin_amdgcn_exp2f(fmaf(sc, E::kSInv, -lre));
@@ -2218,6 +2227,39 @@ __global__ __launch_bounds__(256) void bce_merge_kernel(const float2* __restrict
 
 bool bce_pipe(int d, bool force_f32) { return d <= 64 && use_b3(d, force_f32); }
 
+// Pre-pass of the two-f16-plane BCE loops (EngH2, UNS): per row  inv = 1 / max(|x|, 1e-12)  (the operand scale that makes it a
+// unit row),  nrm = max(|x|, 1e-12)  (what un-scales its scores) and  f = nrm * w  (the row's factor in the second product:
+// sum_j sigmoid(s_ij) w_j y_j = sum_j (sigmoid(s_ij) nrm_j w_j) yhat_j).  D / 4 lanes per row, one float4 per lane.
+template <int D>
+__global__ __launch_bounds__(256) void bce_row_scales_kernel(const float* __restrict__ x, int64_t rows, const float* __restrict__ w,
+                                                             float* __restrict__ inv, float* __restrict__ nrm, float* __restrict__ f) {
+  constexpr int LPR = D / 4, GROUPS = 256 / LPR;
+  const int gl = threadIdx.x % LPR;
+  for (int64_t r = (int64_t)blockIdx.x * GROUPS + threadIdx.x / LPR; r < rows; r += (int64_t)gridDim.x * GROUPS) {
+    const float4 v = *reinterpret_cast<const float4*>(x + r * D + 4 * gl);
+    float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+#pragma unroll
+    for (int off = LPR / 2; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    if (gl == 0) {
+      const float n = fmaxf(sqrtf(ss), 1.0e-12f);
+      inv[r] = 1.0f / n;
+      nrm[r] = n;
+      if (f != nullptr) f[r] = n * (w != nullptr ? w[r] : 1.0f);
+    }
+  }
+}
+
+template <int D>
+void launch_bce_row_scales(const float* x, int64_t rows, const float* w, float* inv, float* nrm, float* f, hipStream_t s) {
+  const int64_t want = (rows + 4 * (1024 / D) - 1) / (4 * (1024 / D));
+  hipLaunchKernelGGL((bce_row_scales_kernel<D>), dim3((unsigned)(want < 1 ? 1 : (want > 8192 ? 8192 : want))), dim3(256), 0, s, x,
+                     rows, w, inv, nrm, f);
+}
+
+inline int64_t align256_i64(int64_t x) { return (x + 255) & ~(int64_t)255; }
+// scratch of the two-plane path behind the partials: inv / nrm of both sides, f of the streamed side, hw[2]
+inline int64_t bce_scales_bytes(int64_t m, int64_t n) { return align256_i64((2 * m + 3 * n + 8) * (int64_t)sizeof(float)); }
+
 FwdPlan plan_bce_fwd(int64_t m, int64_t n, int d, bool force_f32) {
   if (bce_pipe(d, force_f32)) return plan_bwd_rows(m, n, d, 128);
   return plan_fwd(m, n, d <= 128 ? 256 : 128, d <= 64 ? 768 : 512);
@@ -2225,7 +2267,7 @@ FwdPlan plan_bce_fwd(int64_t m, int64_t n, int d, bool force_f32) {
 
 template <int D>
 int32_t launch_bce_fwd(const float* a, int64_t m, const float* b, int64_t n, float* rowsum, float* o, void* workspace,
-                       bool force_f32, hipStream_t s) {
+                       int64_t core_bytes, bool force_f32, bool two_planes, hipStream_t s) {
   const FwdPlan p = plan_bce_fwd(m, n, D, force_f32);
   float2* part = reinterpret_cast<float2*>(workspace);
   float* opart = reinterpret_cast<float*>(part + (int64_t)p.nsplit * m);
@@ -2233,7 +2275,24 @@ int32_t launch_bce_fwd(const float* a, int64_t m, const float* b, int64_t n, flo
   const float* none = nullptr;
   bool with_o = false;
   if constexpr (D <= 64) {
-    if (bce_pipe(D, force_f32)) {
+    if (bce_pipe(D, force_f32) && two_planes) {
+      // two f16 planes: both sides scaled to unit rows, scores un-scaled by the norms, o's streamed factor = the norm
+      float* sc = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + core_bytes);
+      float *inv_a = sc, *nrm_a = sc + m, *inv_b = sc + 2 * m, *nrm_b = inv_b + n, *f_b = nrm_b + n, *hw = f_b + n;
+      launch_bce_row_scales<D>(a, m, nullptr, inv_a, nrm_a, nullptr, s);
+      launch_bce_row_scales<D>(b, n, nullptr, inv_b, nrm_b, o != nullptr ? f_b : nullptr, s);
+      if (o != nullptr) {
+        hipLaunchKernelGGL(h2_wscale_kernel, dim3(1), dim3(1024), 0, s, none, (int64_t)0, (const float*)f_b, n, hw);
+        hipLaunchKernelGGL((infonce_pipe_kernel<EngH2, D, 2, false, 0, 4>), grid, dim3(256), 0, s, a, (const float*)inv_a, m, b,
+                           (const float*)inv_b, n, kLog2e, 1.0f, (const float*)nrm_a, none, (const float*)nrm_b,
+                           (const float*)f_b, p.nsplit, p.tiles_per_split, opart, part, (const float*)hw);
+      } else {
+        hipLaunchKernelGGL((infonce_pipe_kernel<EngH2, D, 2, false, 1, 4>), grid, dim3(256), 0, s, a, (const float*)inv_a, m, b,
+                           (const float*)inv_b, n, kLog2e, 1.0f, (const float*)nrm_a, none, (const float*)nrm_b, none,
+                           p.nsplit, p.tiles_per_split, opart, part, none);
+      }
+      with_o = true;
+    } else if (bce_pipe(D, force_f32)) {
       if (o != nullptr)
         hipLaunchKernelGGL((infonce_pipe_kernel<EngB3, D, 2, false, 0, 4>), grid, dim3(256), 0, s, a, none, m, b, none, n,
                            kLog2e, 1.0f, none, none, none, none, p.nsplit, p.tiles_per_split, opart, part, none);
@@ -2258,13 +2317,26 @@ int32_t launch_bce_fwd(const float* a, int64_t m, const float* b, int64_t n, flo
 
 template <int D>
 int32_t launch_bce_bwd(const float* x, int64_t mx, const float* y, int64_t ny, const float* w_x, const float* w_y, float* g,
-                       void* workspace, bool force_f32, hipStream_t s) {
+                       void* workspace, int64_t core_bytes, bool force_f32, bool two_planes, hipStream_t s) {
   const float* none = nullptr;
   if constexpr (D <= 64) {
     if (bce_pipe(D, force_f32)) {
       const FwdPlan p = plan_bwd_rows(mx, ny, D, BwdB3<D>::ROWS_PER_BLOCK);
       float* gpart = p.nsplit == 1 ? g : reinterpret_cast<float*>(workspace);
       const dim3 grid((unsigned)(p.m_blocks * p.nsplit));
+      if (two_planes && w_y != nullptr) {                  // (weights on the stationary rows stay on three planes)
+        float* sc = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + core_bytes);
+        float *inv_x = sc, *nrm_x = sc + mx, *inv_y = sc + 2 * mx, *nrm_y = inv_y + ny, *f_y = nrm_y + ny, *hw = f_y + ny;
+        launch_bce_row_scales<D>(x, mx, nullptr, inv_x, nrm_x, nullptr, s);
+        launch_bce_row_scales<D>(y, ny, w_y, inv_y, nrm_y, f_y, s);
+        hipLaunchKernelGGL(h2_wscale_kernel, dim3(1), dim3(1024), 0, s, none, (int64_t)0, (const float*)f_y, ny, hw);
+        hipLaunchKernelGGL((infonce_pipe_kernel<EngH2, D, 3, false, 2, 4>), grid, dim3(256), 0, s, x, (const float*)inv_x, mx, y,
+                           (const float*)inv_y, ny, kLog2e, 1.0f, (const float*)nrm_x, none, (const float*)nrm_y,
+                           (const float*)f_y, p.nsplit, p.tiles_per_split, gpart, (float2*)nullptr, (const float*)hw);
+        int32_t st = GCR_LAUNCH_STATUS();
+        if (st != GCR_OK) return st;
+        return reduce_splits(p, gpart, mx, D, g, s);
+      }
       if (w_x != nullptr)
         hipLaunchKernelGGL((infonce_pipe_kernel<EngB3, D, 3, false, 1, 4>), grid, dim3(256), 0, s, x, none, mx, y, none, ny,
                            kLog2e, 1.0f, none, w_x, none, none, p.nsplit, p.tiles_per_split, gpart, (float2*)nullptr, none);
@@ -3112,30 +3184,39 @@ extern "C" int32_t gcr_bce_fwd_o_supported(int32_t d, uint32_t flags) {
   return (d == 32 || d == 64) && bce_pipe(d, (flags & GCR_INFONCE_ENGINE_F32) != 0) ? 1 : 0;
 }
 
-extern "C" int64_t gcr_bce_fwd_workspace_bytes(int64_t m, int64_t n, int32_t d) {
-  if (m <= 0 || n <= 0 || !dim_supported(d)) return 0;
+static int64_t bce_fwd_core_bytes(int64_t m, int64_t n, int32_t d) {
   const FwdPlan p = plan_bce_fwd(m, n, d, false), q = plan_bce_fwd(m, n, d, true);   // either engine (chosen per call)
   const int64_t nsplit = p.nsplit > q.nsplit ? p.nsplit : q.nsplit;
-  return nsplit * m * ((int64_t)sizeof(float2) + (d <= 64 ? (int64_t)d * (int64_t)sizeof(float) : 0));
+  return align256_i64(nsplit * m * ((int64_t)sizeof(float2) + (d <= 64 ? (int64_t)d * (int64_t)sizeof(float) : 0)));
+}
+
+extern "C" int64_t gcr_bce_fwd_workspace_bytes(int64_t m, int64_t n, int32_t d) {
+  if (m <= 0 || n <= 0 || !dim_supported(d)) return 0;
+  return bce_fwd_core_bytes(m, n, d) + (d <= 64 ? bce_scales_bytes(m, n) : 0);
 }
 
 extern "C" int32_t gcr_bce_fwd_f32(const float* a, int64_t m, const float* b, int64_t n, int32_t d, float* row_softplus,
                                    float* o, void* workspace, uint32_t flags, void* stream) {
   GCR_CHECK_ARG(m >= 0 && n >= 1);
-  GCR_CHECK_ARG((flags & ~(uint32_t)GCR_INFONCE_ENGINE_F32) == 0);
+  GCR_CHECK_ARG((flags & ~(uint32_t)(GCR_INFONCE_ENGINE_F32 | GCR_BCE_TWO_PLANES)) == 0);
   if (!dim_supported(d)) return GCR_EUNSUPPORTED;
   if (o != nullptr && !gcr_bce_fwd_o_supported(d, flags)) return GCR_EUNSUPPORTED;
   if (m == 0) return GCR_OK;
   GCR_CHECK_ARG(a != nullptr && b != nullptr && row_softplus != nullptr && workspace != nullptr);
   GCR_CHECK_ARG(m < (1ll << 40) && n < (1ll << 40));
-  const bool f32 = (flags & GCR_INFONCE_ENGINE_F32) != 0;
+  const bool f32 = (flags & GCR_INFONCE_ENGINE_F32) != 0, two = (flags & GCR_BCE_TWO_PLANES) != 0;
   hipStream_t s = (hipStream_t)stream;
+  const int64_t core = bce_fwd_core_bytes(m, n, d);
   switch (d) {
-    case 32: return launch_bce_fwd<32>(a, m, b, n, row_softplus, o, workspace, f32, s);
-    case 64: return launch_bce_fwd<64>(a, m, b, n, row_softplus, o, workspace, f32, s);
-    case 128: return launch_bce_fwd<128>(a, m, b, n, row_softplus, o, workspace, f32, s);
-    default: return launch_bce_fwd<256>(a, m, b, n, row_softplus, o, workspace, f32, s);
+    case 32: return launch_bce_fwd<32>(a, m, b, n, row_softplus, o, workspace, core, f32, two, s);
+    case 64: return launch_bce_fwd<64>(a, m, b, n, row_softplus, o, workspace, core, f32, two, s);
+    case 128: return launch_bce_fwd<128>(a, m, b, n, row_softplus, o, workspace, core, f32, two, s);
+    default: return launch_bce_fwd<256>(a, m, b, n, row_softplus, o, workspace, core, f32, two, s);
   }
+}
+
+static int64_t bce_bwd_core_bytes(int64_t nsplit, int64_t mx, int32_t d) {
+  return nsplit > 1 ? align256_i64(nsplit * mx * d * (int64_t)sizeof(float)) : 0;
 }
 
 extern "C" int64_t gcr_bce_bwd_workspace_bytes(int64_t mx, int64_t ny, int32_t d) {
@@ -3152,24 +3233,26 @@ extern "C" int64_t gcr_bce_bwd_workspace_bytes(int64_t mx, int64_t ny, int32_t d
     const FwdPlan q = plan_bwd_rows(mx, ny, d, 128);
     if (q.nsplit > nsplit) nsplit = q.nsplit;
   }
-  return nsplit > 1 ? nsplit * mx * d * (int64_t)sizeof(float) : 0;
+  return bce_bwd_core_bytes(nsplit, mx, d) + (d <= 64 ? bce_scales_bytes(mx, ny) : 0);
 }
 
 extern "C" int32_t gcr_bce_bwd_f32(const float* x, int64_t mx, const float* y, int64_t ny, int32_t d, const float* w_x,
                                    const float* w_y, float* g, void* workspace, uint32_t flags, void* stream) {
   GCR_CHECK_ARG(mx >= 0 && ny >= 1);
-  GCR_CHECK_ARG((flags & ~(uint32_t)GCR_INFONCE_ENGINE_F32) == 0);
+  GCR_CHECK_ARG((flags & ~(uint32_t)(GCR_INFONCE_ENGINE_F32 | GCR_BCE_TWO_PLANES)) == 0);
   if (!dim_supported(d)) return GCR_EUNSUPPORTED;
   if (mx == 0) return GCR_OK;
   GCR_CHECK_ARG(x != nullptr && y != nullptr && g != nullptr);
   GCR_CHECK_ARG((w_x != nullptr) != (w_y != nullptr));     // the weights sit on exactly one side
   GCR_CHECK_ARG(workspace != nullptr || gcr_bce_bwd_workspace_bytes(mx, ny, d) == 0);
-  const bool f32 = (flags & GCR_INFONCE_ENGINE_F32) != 0;
+  const bool f32 = (flags & GCR_INFONCE_ENGINE_F32) != 0, two = (flags & GCR_BCE_TWO_PLANES) != 0;
   hipStream_t s = (hipStream_t)stream;
+  // (the split partials sit in front of the two-plane scratch; their size follows the plan actually used)
+  int64_t core = gcr_bce_bwd_workspace_bytes(mx, ny, d) - (d <= 64 ? bce_scales_bytes(mx, ny) : 0);
   switch (d) {
-    case 32: return launch_bce_bwd<32>(x, mx, y, ny, w_x, w_y, g, workspace, f32, s);
-    case 64: return launch_bce_bwd<64>(x, mx, y, ny, w_x, w_y, g, workspace, f32, s);
-    case 128: return launch_bce_bwd<128>(x, mx, y, ny, w_x, w_y, g, workspace, f32, s);
-    default: return launch_bce_bwd<256>(x, mx, y, ny, w_x, w_y, g, workspace, f32, s);
+    case 32: return launch_bce_bwd<32>(x, mx, y, ny, w_x, w_y, g, workspace, core, f32, two, s);
+    case 64: return launch_bce_bwd<64>(x, mx, y, ny, w_x, w_y, g, workspace, core, f32, two, s);
+    case 128: return launch_bce_bwd<128>(x, mx, y, ny, w_x, w_y, g, workspace, core, f32, two, s);
+    default: return launch_bce_bwd<256>(x, mx, y, ny, w_x, w_y, g, workspace, core, f32, two, s);
   }
 }

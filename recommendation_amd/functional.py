@@ -1031,8 +1031,16 @@ def infonce_stats(a, b, pos=None, temperature=0.2, normalize=True, want_col=Fals
 # ---------------------------------------------------------------------------------------------
 # BCE-with-logits over all pairs (lightgcn.py:109-113, `loss_type == "bce"`)
 # ---------------------------------------------------------------------------------------------
+BCE_TWO_PLANES = 8          # include/gcr.h GCR_BCE_TWO_PLANES
+
+
 def _bce_flags(engine=None):
-    return _resolve_engine(engine) & INFONCE_ENGINE_F32        # rows are not unit rows: three bf16 planes or the f32 MFMA
+    """'auto': two f16 planes on rows scaled to unit norm inside the launch (scores un-scaled by the norms); 'b3': three bf16
+    planes on the raw rows; 'f32': the f32 MFMA."""
+    e = INFONCE_ENGINE if engine is None else engine
+    if e not in ("auto", "b3", "f32"):
+        raise ValueError("BCE engine must be 'auto', 'b3' or 'f32'")
+    return {"auto": BCE_TWO_PLANES, "b3": 0, "f32": INFONCE_ENGINE_F32}[e]
 
 
 def bce_fwd_raw(a, b, want_o=False, engine_flag=0):

@@ -9,6 +9,7 @@ directory.  Usage: python profiles/summarize.py gpurun_out/prof_r02 r02
                                           <tag>_infonce_pmc_mfma.csv + pmc_traffic.json["infonce"]
   <dir>/kt_ncl/, kt_km/, kt_rank/, kt_lg/ profiles/ncl_step_probe.py, kmeans_probe.py, rank_probe.py, lightgcn_step_probe.py
   <dir>/kt_bce/, kt_kme/, kt_cfg5/        profiles/bce_probe.py, kmeans_estep_probe.py, bench.py --workload cfg5
+  <dir>/kt_gcl/                           profiles/gcl_step_probe.py
 pmc_traffic.json entries carry the digest of the kernel sources the probe ran (written by the probe on the
 GPU box) and the git commit of the tree they were summarised in; bench.py attaches an entry only when the
 digest matches the sources it benchmarks.
@@ -101,6 +102,7 @@ stats("kt_lg/*/*_kernel_stats.csv", f"{tag}_lightgcn_step_kernel_stats.csv", top
 stats("kt_bce/*/*_kernel_stats.csv", f"{tag}_bce_kernel_stats.csv", top=10)             # profiles/bce_probe.py
 stats("kt_kme/*/*_kernel_stats.csv", f"{tag}_kmeans_estep_kernel_stats.csv", top=8)     # profiles/kmeans_estep_probe.py
 stats("kt_cfg5/*/*_kernel_stats.csv", f"{tag}_cfg5_kernel_stats.csv", top=14)           # bench.py --workload cfg5
+stats("kt_gcl/*/*_kernel_stats.csv", f"{tag}_gcl_step_kernel_stats.csv", top=12)        # profiles/gcl_step_probe.py
 
 traffic_path = os.path.join(here, "pmc_traffic.json")
 try:

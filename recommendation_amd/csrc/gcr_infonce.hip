@@ -1415,7 +1415,7 @@ __global__ __launch_bounds__(1024) void h2_wscale_kernel(const float* __restrict
 // statistics, so that the loop stages a tile with two plain loads per lane — no scale loads, multiplies, end-of-array
 // clamps or selects per tile.  The loop's time is its count of vector instructions, and the streamed side of
 // a backward launch is read once per row block: mx / 128 times.
-//   FOLDW = false:  l_j = lse_j log2 e,  w'_j = w_j hw[0],  yhat_j = y_scale_j kSY y_j   (padding: 1e30, 0, zero row)
+//   FOLDW = false:  l_j = lse_j log2 e,  w'_j = w_j hw[0] 2^-l_j,  yhat_j = y_scale_j kSY y_j   (padding: 1e30, 0, zero row)
 //   FOLDW = true (statistics on the streamed rows only, SIDES = 2): the weight of row j moves INTO the exponent and its
 //   sign into the row,
 //     P_ij y_j = w_j e^{s_ij - lse_j} y_j = 2^(c_j s'_ij + e_j) (sgn_j y_j),   s'_ij = x_i . (sgn_j y_j) the score the loop sees,
@@ -1444,8 +1444,11 @@ __global__ __launch_bounds__(256) void h2_prestage_kernel(const float* __restric
         s0 = fmaf(-lse_y[j], kLog2e, __log2f(fabsf(w)));
         s1 = sgn * EngH2::kSInv;
       } else {
+        // statistics on BOTH sides (the only user of this form): the loop factors the common 2^s out of
+        //   w_i 2^(s - l_i) + w_j 2^(s - l_j) = 2^s (w_i 2^-l_i + w_j 2^-l_j),
+        // so the streamed row's weight arrives multiplied by its 2^-l (l >= every score of the row: no overflow)
         s0 = lse_y[j] * kLog2e;
-        s1 = w;
+        s1 = w * __builtin_amdgcn_exp2f(-s0);
       }
     }
     const float sc = sgn * EngH2::kSY * (y_scale != nullptr ? y_scale[j] : 1.0f);
@@ -1513,6 +1516,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
   const float wl = on_x ? w_x[row_i] * w_mul : 0.f;
   const float lse2l = (MODE == 0 && on_x) ? lse_x[row_i] * kLog2e : 1.0e30f;
   const float rs = (UNS && row_i < mx) ? lse_x[row_i] : 1.0f;   // UNS: the stationary row's norm
+  // BOTHF (two planes, statistics on both sides): one exp2 per probability — the unit rows bound the score (|s| <= 28.9
+  // in log2 units), so 2^s is taken once and multiplied by w_i 2^-l_i + w_j 2^-l_j (the streamed half premultiplied by
+  // h2_prestage_kernel): exp2 + add + multiply instead of two fused multiply-adds, two exp2, two multiplies and an add
+  constexpr bool BOTHF = PRE && SIDES == 0;
+  const float ax = BOTHF ? wl * __builtin_amdgcn_exp2f(-lse2l) : 0.f;
   // FOLDX (statistics on the stationary rows only): the same move as FOLD inside the kernel — |w_i| into the exponent,
   // sgn w_i into the stationary operand (the scores flip with it, hence c_x) and back out of the gradient row at the end:
   //   P_ij = w_i e^{s_ij - lse_i} = sgn_i 2^(c_x s'_ij + e_x)
@@ -1686,6 +1694,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
           } else if (SIDES == 1) acc[r] = __builtin_amdgcn_exp2f(fmaf(sc, c_x, e_x));
           else if (FOLD) acc[r] = __builtin_amdgcn_exp2f(fmaf(sc, wre, lre));
           else if (SIDES == 2) acc[r] = wre * __builtin_amdgcn_exp2f(fmaf(sc, E::kSInv, -lre));
+          else if (BOTHF) acc[r] = __builtin_amdgcn_exp2f(sc * E::kSInv) * (ax + wre);
           else acc[r] = wl * __builtin_amdgcn_exp2f(fmaf(sc, E::kSInv, -lse2l)) + wre * __builtin_amdgcn_exp2f(fmaf(sc, E::kSInv, -lre));
         }
       } else {

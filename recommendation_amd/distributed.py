@@ -344,14 +344,78 @@ def allreduce_replicated_grads(params, group=None):
             dist.all_reduce(p.grad, group=group)
 
 
+class _ShardedSymInfoNCE(torch.autograd.Function):
+    """gcl.py:28-35 over row-sharded views on the HIP kernels, the single-process recipe of `functional._InfoNCEStats`
+    (want_col) cut by rows: forward = two row-logsumexp launches (local anchors of one view against the all-gathered other
+    view, one tile product each); backward = one launch per local table with the statistics of BOTH cross-entropies —
+        d/d z1_i = sum_j ( w e^{s_ij - lse12_i} + w e^{s_ij - lse21_j} ) z2hat_j / tau - 2 w z2hat_i / tau,  w = 1 / (2 M)
+    — which needs the other view's rows (gathered already) and its row logsumexps (an all-gather of [M] floats), so NO
+    gradient flows back through the gathered tables: six tile products per step instead of the eight of two flash-forward /
+    table-side-backward pairs, and no reduce-scatter of two [M, d] gradient tables."""
+
+    @staticmethod
+    def forward(ctx, z1, z2, inv_tau, group):
+        multi = dist.is_initialized() and _multi(dist.get_world_size(group))
+        world = dist.get_world_size(group) if multi else 1
+
+        def gather(x):
+            if not multi:
+                return x
+            full = torch.empty((x.shape[0] * world,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+            _all_gather(full, x.contiguous(), group, False)
+            return full
+
+        a, b = Fn._pad_dim(z1).contiguous(), Fn._pad_dim(z2).contiguous()
+        sa, sb = Fn.row_inv_norm(a), Fn.row_inv_norm(b)
+        a_f, b_f, sa_f, sb_f = gather(a), gather(b), gather(sa), gather(sb)
+        eng = Fn._resolve_engine(unit_rows=True)
+        lse12 = Fn.infonce_lse_raw(a, sa, b_f, sb_f, inv_tau, engine_flag=eng)
+        lse21 = Fn.infonce_lse_raw(b, sb, a_f, sa_f, inv_tau, engine_flag=eng)
+        m_local = a.shape[0]
+        idx = torch.arange(m_local, device=a.device, dtype=torch.int64)
+        pos = Fn.pos_logit_raw(a, sa, b, sb, idx, inv_tau)          # row i of both views lives on this rank
+        ctx.save_for_backward(a, b, sa, sb, a_f, b_f, sa_f, sb_f, lse12, lse21, idx)
+        ctx.inv_tau, ctx.eng, ctx.d, ctx.gather, ctx.m_total = inv_tau, eng, z1.shape[1], gather, m_local * world
+        return ((lse12 - pos).sum() + (lse21 - pos).sum()) / (2 * ctx.m_total)
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        a, b, sa, sb, a_f, b_f, sa_f, sb_f, lse12, lse21, idx = ctx.saved_tensors
+        inv_tau, eng = ctx.inv_tau, ctx.eng
+        m_local = a.shape[0]
+        w = (g.float() / (2 * ctx.m_total)).reshape(1)
+        w_local, w_full = w.expand(m_local).contiguous(), w.expand(ctx.m_total).contiguous()
+        lse12_f, lse21_f = ctx.gather(lse12), ctx.gather(lse21)
+        ga = Fn._infonce_bwd_raw(a, sa, b_f, sb_f, inv_tau, lse12, w_local, lse21_f, w_full, False, eng)
+        gb = Fn._infonce_bwd_raw(b, sb, a_f, sa_f, inv_tau, lse21, w_local, lse12_f, w_full, False, eng)
+        L = _lib.lib()
+        stream = _lib.cur_stream(a.device)
+        _lib.check(L.gcr_infonce_pos_bwd_f32(_lib.dptr(a), _lib.dptr(sa), _lib.dptr(b), _lib.dptr(sb), _lib.dptr(idx),
+                                             _lib.dptr((-2.0 * w_local).contiguous()), m_local, m_local, a.shape[1],
+                                             float(inv_tau), _lib.dptr(ga), _lib.dptr(gb), stream), "gcr_infonce_pos_bwd_f32")
+        for x, sc, gx in ((a, sa, ga), (b, sb, gb)):
+            _lib.check(L.gcr_normalize_bwd_f32(_lib.dptr(x), _lib.dptr(sc), _lib.dptr(gx), x.shape[0], x.shape[1],
+                                               _lib.dptr(gx), stream), "gcr_normalize_bwd_f32")
+        if ga.shape[1] != ctx.d:
+            ga, gb = ga[:, :ctx.d].contiguous(), gb[:, :ctx.d].contiguous()
+        return ga, gb, None, None
+
+
 def sharded_info_nce_loss(z1_local, z2_local, temp=0.2, group=None, stats_fn=None):
     """gcl.py:28-35 over row-sharded views (BASELINE config 4): every rank holds the same row block of
     z1 and z2 ([M/world, d] each, equal sizes).  Both cross-entropies are row problems with LOCAL
-    anchors against the ALL-GATHERED other view (CE(sim) from z1's rows, CE(sim.T) from z2's rows),
-    so no column statistics cross ranks; the gathered table's gradient returns by reduce-scatter
-    (`gather_items`).  Returns this rank's share of the loss: summing it over ranks (all-reduce) gives
+    anchors against the ALL-GATHERED other view (CE(sim) from z1's rows, CE(sim.T) from z2's rows).
+    Returns this rank's share of the loss: summing it over ranks (all-reduce) gives
     the single-process value; gradients are already the full-loss gradients of the local rows.
-    `stats_fn` defaults to the HIP `functional.infonce_stats`."""
+    On the HIP path (`_ShardedSymInfoNCE`) the backward uses both cross-entropies' row statistics in one launch per local
+    table and nothing returns through the gathered tables.  `stats_fn` (the gloo choreography tests' CPU stand-in for
+    `functional.infonce_stats`) selects the composition of two row problems instead, whose gathered tables' gradients
+    return by reduce-scatter (`gather_items`)."""
+    if stats_fn is None and z1_local.is_cuda:
+        if z1_local.shape != z2_local.shape:
+            raise ValueError("sharded_info_nce_loss needs the same row block of both views on every rank")
+        return _ShardedSymInfoNCE.apply(z1_local, z2_local, 1.0 / float(temp), group)
     stats = stats_fn or Fn.infonce_stats
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0

@@ -43,6 +43,8 @@ if [ "$WHAT" = "nce" ] || [ "$WHAT" = "all" ]; then
   echo "k-means e_step pass done"
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_cfg5" -- python3 "$R/bench.py" --workload cfg5 --steps 5 --warmup 2 > "$OUT/bench_cfg5_kt.json" 2> "$OUT/bench_cfg5_kt.err"
   echo "cfg5 pass done"
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_gcl" -- python3 "$R/profiles/gcl_step_probe.py" > "$OUT/kt_gcl.log" 2>&1
+  echo "gcl step pass done"
 fi
 # keep the merge-back small: only the CSV summaries are read afterwards
 find "$OUT" -name "*.db" -delete 2>/dev/null || true

@@ -694,8 +694,9 @@ def gcl_step_leg(ra, gdist, dist, dev, rank, world, d, full_graph=None):
     """One sharded SSL4Rec / GCL training step (gcl.py:205-227 with the propagation BASELINE config 4 names):
     two edge-dropped views (ShardedEdgeDrop, independent draws per stored non-zero), K-layer sharded
     propagation of each, all-pairs symmetric InfoNCE over users and over items between the views
-    (row-sharded anchors, all-gathered tables), BPR on a batch, backward incl. the reduce-scatter of the item
-    gradients, on its own named workload (the all-pairs user InfoNCE is O(U^2))."""
+    (row-sharded anchors against the all-gathered other view: two row-logsumexp launches forward, one both-sided
+    backward launch per local table — distributed._ShardedSymInfoNCE), BPR on a batch, backward incl. the reduce-scatter
+    of the item gradients, on its own named workload (the all-pairs user InfoNCE is O(U^2))."""
     from recommendation_amd import functional as Fn
     wl = GCL_LEG
     if full_graph is None:

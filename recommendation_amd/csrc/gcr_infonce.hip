@@ -146,14 +146,17 @@ __device__ __forceinline__ void lse_update(const f32x16 (&acc)[NT], int rem, flo
 
 // log2-domain pieces of the BCE-with-logits element (lightgcn.py:109-113): for the log2-domain score s2 = s log2 e
 //   softplus(s) = ln2 * (max(s2, 0) + log2(1 + u)),  sigmoid(s) = s2 >= 0 ? 1 / (1 + u) : u / (1 + u),  u = 2^-|s2|.
-// log2(1 + u) is compensated for the rounding of v = 1 + u (e = u - (v - 1) exactly; + e log2e / v), so a strongly
-// negative score keeps its ~2^s2 instead of 0.  A masked score (-inf) gives softplus = 0 and sigmoid = 0.
+// log2(1 + u) is compensated for the rounding of v = 1 + u (e = u - (v - 1) exactly; log2(v + e) = log2 v + (e / v) log2 e),
+// so a strongly negative score keeps its ~2^s2 instead of 0.  The correction is taken as e log2 e: leaving the 1 / v out
+// changes it by e u / v log2 e <= 2^-24 u log2 e, i.e. 2^-23 of log2(1 + u) at most — and the row-sum launch, which needs
+// no sigmoid, then needs no reciprocal either (one quarter-rate instruction and a multiply per score less).
+// A masked score (-inf) gives softplus = 0 and sigmoid = 0.
 __device__ __forceinline__ void bce_terms(float s2, float& softplus2, float& sig) {
   const float u = __builtin_amdgcn_exp2f(-fabsf(s2));
   const float v = 1.0f + u;
-  const float rc = __builtin_amdgcn_rcpf(v);
   const float e = u - (v - 1.0f);
-  softplus2 = fmaxf(s2, 0.f) + fmaf(e * rc, kLog2e, __builtin_amdgcn_logf(v));
+  softplus2 = fmaxf(s2, 0.f) + fmaf(e, kLog2e, __builtin_amdgcn_logf(v));
+  const float rc = __builtin_amdgcn_rcpf(v);
   sig = s2 >= 0.f ? rc : u * rc;
 }
 

@@ -111,6 +111,18 @@ int32_t gcr_spmm_csr_dual_f32(const int64_t* desc, int64_t n_parts,
                               const float* x, int32_t d, float* y_raw, float* y_norm, float* inv_norm_out,
                               float* partials, int64_t n_rows, int64_t n_cols, void* stream);
 
+/* The dual launch with the layer-list accumulation folded in (univariate/mhcn.py:440-457 appends the normalised product of
+ * every layer to a list that is summed afterwards):  acc_out = acc_in + normalize(A x)  from the same pass (acc_in may be NULL,
+ * acc_out may alias acc_in).  y_norm may be NULL — inv_norm_out is then required and the backward rebuilds the normalised
+ * rows from y_raw (gcr_normalize_bwd_raw_f32): three [n_rows, d] passes instead of the five of dual launch + add. */
+int32_t gcr_spmm_csr_dual_acc_f32(const int64_t* desc, int64_t n_parts,
+                                  const int32_t* long_row, const int32_t* long_slot0, int64_t n_long_rows,
+                                  const int64_t* rowptr, const int32_t* col, const float* val,
+                                  const uint32_t* keep_bits, float val_scale,
+                                  const float* x, int32_t d, float* y_raw, float* y_norm, const float* acc_in,
+                                  float* acc_out, float* inv_norm_out, float* partials, int64_t n_rows, int64_t n_cols,
+                                  void* stream);
+
 /* Counts structural errors of a CSR on the device (rowptr not monotone / not ending at nnz,
  * col outside [0, n_cols)); *n_errors_dev is a device int64 the caller zeroes and reads back. */
 int32_t gcr_csr_validate(const int64_t* rowptr, const int32_t* col, int64_t n_rows, int64_t n_cols,
@@ -361,6 +373,10 @@ int32_t gcr_normalize_bwd_f32(const float* x, const float* inv_norm, const float
  * one pass; out may alias g_n or g_raw.  d a multiple of 4, <= 256. */
 int32_t gcr_normalize_bwd_n_f32(const float* n_rows_normalised, const float* inv_norm, const float* g_n,
                                 const float* g_raw, int64_t rows, int32_t d, float* out, void* stream);
+/* The same from the RAW rows z = A x (a forward that kept only z and 1 / |z|: gcr_spmm_csr_dual_acc_f32 without y_norm):
+ * n = z * inv_norm on the fly. */
+int32_t gcr_normalize_bwd_raw_f32(const float* z_raw, const float* inv_norm, const float* g_n, const float* g_raw,
+                                  int64_t rows, int32_t d, float* out, void* stream);
 
 /* out[dx, dg] = X^T G for tall row-major X [n, dx], G [n, dg]: the weight gradient of `em @ W` in MHCN's gating /
  * attention (mhcn.py:404-420; W is d x d, n = #users), rows split over the chip on the f32 MFMA, partials summed in a

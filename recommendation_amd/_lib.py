@@ -29,6 +29,8 @@ SIGNATURES = {
     "gcr_bitmap_set": (c_int32, [_P, c_int64, c_int64, _P, _P]),
     "gcr_spmm_csr_dual_f32": (c_int32, [_P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, c_float, _P, c_int32,
                                         _P, _P, _P, _P, c_int64, c_int64, _P]),
+    "gcr_spmm_csr_dual_acc_f32": (c_int32, [_P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, c_float, _P, c_int32,
+                                            _P, _P, _P, _P, _P, _P, c_int64, c_int64, _P]),
     "gcr_csr_validate": (c_int32, [_P, _P, c_int64, c_int64, c_int64, _P, _P]),
     "gcr_bpr_workspace_floats": (c_int64, [c_int64]),
     "gcr_bpr_fwd_f32": (c_int32, [_P, _P, c_int32, _P, _P, _P, c_int64, c_int32, c_int32, c_int64, c_int64,
@@ -61,6 +63,7 @@ SIGNATURES = {
     "gcr_infonce_pos_bwd_f32": (c_int32, [_P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int32, c_float, _P, _P, _P]),
     "gcr_normalize_bwd_f32": (c_int32, [_P, _P, _P, c_int64, c_int32, _P, _P]),
     "gcr_normalize_bwd_n_f32": (c_int32, [_P, _P, _P, _P, c_int64, c_int32, _P, _P]),
+    "gcr_normalize_bwd_raw_f32": (c_int32, [_P, _P, _P, _P, c_int64, c_int32, _P, _P]),
     "gcr_gram_tn_workspace_bytes": (c_int64, [c_int64, c_int32, c_int32]),
     "gcr_gram_tn_f32": (c_int32, [_P, _P, c_int64, c_int32, c_int32, _P, _P, _P]),
     "gcr_rows_dot_vec_f32": (c_int32, [_P, _P, c_int64, c_int32, _P, _P]),

@@ -25,7 +25,9 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// 16 lanes per row, float4 per lane and 64 columns (d % 4 == 0); out may alias g_n or g_raw
+// 16 lanes per row, float4 per lane and 64 columns (d % 4 == 0); out may alias g_n or g_raw.
+// FROM_RAW: `nrm` holds the RAW rows z = A x (the forward did not keep the normalised copy): n = z * inv on the fly.
+template <bool FROM_RAW>
 __global__ __launch_bounds__(256) void normalize_bwd_n_kernel(const float* __restrict__ nrm, const float* __restrict__ inv,
                                                               const float* g_n, const float* g_raw, int64_t rows, int d,
                                                               float* out) {
@@ -39,6 +41,7 @@ __global__ __launch_bounds__(256) void normalize_bwd_n_kernel(const float* __res
       const int c = l16 * 4 + 64 * q;
       if (c < d) {
         nv[q] = *reinterpret_cast<const float4*>(nrm + r * d + c);
+        if (FROM_RAW) { nv[q].x *= s; nv[q].y *= s; nv[q].z *= s; nv[q].w *= s; }
         gv[q] = *reinterpret_cast<const float4*>(g_n + r * d + c);
         dot += nv[q].x * gv[q].x + nv[q].y * gv[q].y + nv[q].z * gv[q].z + nv[q].w * gv[q].w;
       }
@@ -341,8 +344,19 @@ extern "C" int32_t gcr_normalize_bwd_n_f32(const float* n_rows_normalised, const
   if (rows == 0) return GCR_OK;
   GCR_CHECK_ARG(n_rows_normalised != nullptr && inv_norm != nullptr && g_n != nullptr && out != nullptr);
   const int64_t want = (rows + 15) / 16;
-  hipLaunchKernelGGL(normalize_bwd_n_kernel, dim3((unsigned)(want > 16384 ? 16384 : want)), dim3(256), 0,
+  hipLaunchKernelGGL(normalize_bwd_n_kernel<false>, dim3((unsigned)(want > 16384 ? 16384 : want)), dim3(256), 0,
                      (hipStream_t)stream, n_rows_normalised, inv_norm, g_n, g_raw, rows, d, out);
+  return GCR_LAUNCH_STATUS();
+}
+
+extern "C" int32_t gcr_normalize_bwd_raw_f32(const float* z_raw, const float* inv_norm, const float* g_n, const float* g_raw,
+                                             int64_t rows, int32_t d, float* out, void* stream) {
+  GCR_CHECK_ARG(rows >= 0 && d >= 4 && d <= 256 && (d & 3) == 0);
+  if (rows == 0) return GCR_OK;
+  GCR_CHECK_ARG(z_raw != nullptr && inv_norm != nullptr && g_n != nullptr && out != nullptr);
+  const int64_t want = (rows + 15) / 16;
+  hipLaunchKernelGGL(normalize_bwd_n_kernel<true>, dim3((unsigned)(want > 16384 ? 16384 : want)), dim3(256), 0,
+                     (hipStream_t)stream, z_raw, inv_norm, g_n, g_raw, rows, d, out);
   return GCR_LAUNCH_STATUS();
 }
 

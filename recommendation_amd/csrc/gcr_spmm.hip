@@ -365,6 +365,34 @@ extern "C" int32_t gcr_spmm_csr_dual_f32(const int64_t* desc, int64_t n_parts, c
 #undef GCR_GO
 }
 
+// The dual launch with the layer-list accumulation folded in (mhcn.py:440-457 appends the normalised product of every layer
+// to a list that is summed afterwards): acc_out = acc_in + normalize(A x) from the same pass; y_norm may be NULL — the backward
+// rebuilds the normalised rows from y_raw and inv_norm_out (gcr_normalize_bwd_raw_f32).
+extern "C" int32_t gcr_spmm_csr_dual_acc_f32(const int64_t* desc, int64_t n_parts, const int32_t* long_row,
+                                             const int32_t* long_slot0, int64_t n_long_rows, const int64_t* rowptr,
+                                             const int32_t* col, const float* val, const uint32_t* keep_bits,
+                                             float val_scale, const float* x, int32_t d, float* y_raw, float* y_norm,
+                                             const float* acc_in, float* acc_out, float* inv_norm_out, float* partials,
+                                             int64_t n_rows, int64_t n_cols, void* stream) {
+  GCR_CHECK_ARG(n_parts >= 0 && n_long_rows >= 0 && n_rows >= 0 && n_cols >= 0);
+  GCR_CHECK_ARG(n_parts < (1ll << 31) - 4 && n_rows < (1ll << 31) && n_cols < (1ll << 31));
+  GCR_CHECK_ARG(d >= 1 && d <= 256);
+  if (n_rows == 0 || n_parts == 0) return GCR_OK;
+  GCR_CHECK_ARG(desc != nullptr && rowptr != nullptr && x != nullptr && y_raw != nullptr && acc_out != nullptr);
+  GCR_CHECK_ARG(y_raw != y_norm && y_raw != acc_out && (y_norm != nullptr || inv_norm_out != nullptr));
+  GCR_CHECK_ARG(n_long_rows == 0 || (long_row != nullptr && long_slot0 != nullptr && partials != nullptr));
+  Epilogue ep{val_scale, y_norm, acc_in, acc_out, 1.0f, GCR_SPMM_ROW_L2NORM, inv_norm_out, y_raw, nullptr, 0.f, nullptr};
+  hipStream_t s = (hipStream_t)stream;
+#define GCR_GO(NV, D64) \
+  return launch_spmm<NV, D64>(desc, n_parts, long_row, long_slot0, n_long_rows, rowptr, col, val, keep_bits, x, d, ep, partials, s)
+  if (d == 64) GCR_GO(1, true);
+  if (d <= 64) GCR_GO(1, false);
+  if (d <= 128) GCR_GO(2, false);
+  if (d <= 192) GCR_GO(3, false);
+  GCR_GO(4, false);
+#undef GCR_GO
+}
+
 extern "C" int32_t gcr_csr_validate(const int64_t* rowptr, const int32_t* col, int64_t n_rows, int64_t n_cols,
                                     int64_t nnz, int64_t* n_errors_dev, void* stream) {
   GCR_CHECK_ARG(rowptr != nullptr && n_errors_dev != nullptr && n_rows >= 0 && nnz >= 0 && n_cols >= 0);

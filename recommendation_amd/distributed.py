@@ -439,6 +439,15 @@ def _hip_dual(graph, x_full):
     return raw, nrm, inv
 
 
+def _hip_dual_acc(graph, x_full, acc):
+    """(A x, acc + normalize(A x), 1 / |A x|) from one launch: the layer-list accumulation of mhcn.py:440-457 folded in."""
+    raw = torch.empty(graph.n_rows, x_full.shape[1], dtype=torch.float32, device=x_full.device)
+    out = torch.empty_like(raw)
+    inv = torch.empty(graph.n_rows, dtype=torch.float32, device=x_full.device)
+    Fn.spmm_dual_acc_into(graph, x_full, raw, acc.contiguous(), out, inv)
+    return raw, out, inv
+
+
 def _hip_spmm_t(graph, dz, out=None):
     gt = graph.t
     y = out if out is not None else torch.empty(gt.n_rows, dz.shape[1], dtype=torch.float32, device=dz.device)
@@ -469,13 +478,17 @@ class _ShardedChannelLayer(torch.autograd.Function):
         backward  dZ_c = g_raw + normalize-backward(g_norm) -> partial = H_c block^T dZ_c [U, d] -> reduce-scatter
     The three all-gathers are issued back to back (async); channel c's SpMM starts as soon as ITS gather has
     landed, on its own HIP stream, so gather c+1 (and c+2) run beside SpMM c; the backward mirrors it with the
-    reduce-scatter of channel c beside the transposed SpMM of channel c+1."""
+    reduce-scatter of channel c beside the transposed SpMM of channel c+1.
+    With running sums `accs` (HIP path only) the second output of channel c is acc_c + norm_c from the same launch and the
+    normalised copy is not kept (the backward rebuilds it from the raw rows: gcr_normalize_bwd_raw_f32)."""
 
     @staticmethod
-    def forward(ctx, ch, dual_fn, spmm_t_fn, *xs):
-        ctx.ch, ctx.spmm_t_fn = ch, spmm_t_fn
-        world, dev, d = ch.world, xs[0].device, xs[0].shape[1]
+    def forward(ctx, ch, dual_fn, spmm_t_fn, *tensors):
         n_c = len(ch.blocks)
+        xs, accs = tensors[:n_c], tensors[n_c:]
+        ctx.ch, ctx.spmm_t_fn = ch, spmm_t_fn
+        ctx.with_acc = [a is not None for a in accs]
+        world, dev, d = ch.world, xs[0].device, xs[0].shape[1]
         fulls, handles = [], []
         for c in range(n_c):
             if _multi(world):
@@ -494,15 +507,17 @@ class _ShardedChannelLayer(torch.autograd.Function):
                 with torch.cuda.stream(s):
                     if handles[c] is not None:
                         handles[c].wait()                 # stream s waits for gather c only
-                    raw, nrm, inv = dual_fn(ch.blocks[c], fulls[c])
+                    raw, nrm, inv = _hip_dual_acc(ch.blocks[c], fulls[c], accs[c]) if ctx.with_acc[c] \
+                        else dual_fn(ch.blocks[c], fulls[c])
                 for t in (raw, nrm, inv):
                     t.record_stream(cur)
             else:
                 if handles[c] is not None:
                     handles[c].wait()
-                raw, nrm, inv = dual_fn(ch.blocks[c], fulls[c])
-            outs += [raw, nrm]
-            saved += [nrm, inv]
+                raw, nrm, inv = _hip_dual_acc(ch.blocks[c], fulls[c], accs[c]) if ctx.with_acc[c] \
+                    else dual_fn(ch.blocks[c], fulls[c])
+            outs += [raw, nrm]                           # (with an acc: nrm = acc + normalised rows)
+            saved += [raw if ctx.with_acc[c] else nrm, inv]
         if ch.streams is not None:
             for s in ch.streams:
                 cur.wait_stream(s)                       # join: the pooled gather buffers are free again, outputs ready
@@ -517,12 +532,13 @@ class _ShardedChannelLayer(torch.autograd.Function):
         world = ch.world
         n_c = len(ch.blocks)
         dxs, handles, parts = [], [], []
+        daccs = [gs[2 * c + 1] if ctx.with_acc[c] else None for c in range(n_c)]   # acc + n: the sum's gradient passes through
         for c in range(n_c):
             g_raw, g_nrm = gs[2 * c], gs[2 * c + 1]
             nrm, inv = saved[2 * c], saved[2 * c + 1]
             dz = None
             if g_nrm is not None and nrm.is_cuda:
-                dz = Fn.normalize_bwd_n(nrm, inv, g_nrm, g_raw)        # one pass (gcr_normalize_bwd_n_f32)
+                dz = Fn.normalize_bwd_n(nrm, inv, g_nrm, g_raw, from_raw=ctx.with_acc[c])   # one pass
             elif g_nrm is not None:       # CPU stand-ins of the gloo choreography tests only
                 dz = (g_nrm - nrm * (nrm * g_nrm).sum(1, keepdim=True)) * inv.unsqueeze(1)
                 dz = dz if g_raw is None else dz + g_raw
@@ -546,10 +562,14 @@ class _ShardedChannelLayer(torch.autograd.Function):
         for h in handles:
             if h is not None:
                 h.wait()
-        return (None, None, None, *dxs)
+        return (None, None, None, *dxs, *daccs)
 
 
-def sharded_channel_layer(ch: ShardedChannels, xs, dual_fn=_hip_dual, spmm_t_fn=_hip_spmm_t):
-    """[(raw_c, norm_c)] for the rank's user rows of every channel; xs: the rank's [U_g, d] operand rows."""
-    out = _ShardedChannelLayer.apply(ch, dual_fn, spmm_t_fn, *xs)
+def sharded_channel_layer(ch: ShardedChannels, xs, dual_fn=_hip_dual, spmm_t_fn=_hip_spmm_t, accs=None):
+    """[(raw_c, norm_c)] for the rank's user rows of every channel; xs: the rank's [U_g, d] operand rows.
+    accs (HIP path: dual_fn is the default): one running sum per channel — the pairs become (raw_c, acc_c + norm_c)."""
+    if accs is not None and dual_fn is not _hip_dual:
+        raise ValueError("sharded_channel_layer: running sums need the HIP dual launch")
+    accs = [None] * len(xs) if accs is None else list(accs)
+    out = _ShardedChannelLayer.apply(ch, dual_fn, spmm_t_fn, *xs, *accs)
     return [(out[2 * c], out[2 * c + 1]) for c in range(len(xs))]

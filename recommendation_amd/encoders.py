@@ -386,37 +386,47 @@ class _MultiStreamSpMM(torch.autograd.Function):
     join on the caller's stream themselves, so autograd sees a node that lives on the caller's stream (per-operator
     nodes recorded under `torch.cuda.stream(s)` make the engine run each backward on its side stream and the
     parameters' AccumulateGrad then synchronises across streams — the warning GPUTEST r02 showed — and it is the
-    form a hipGraph capture of the step needs)."""
+    form a hipGraph capture of the step needs).
+    Modes per operator: False (A x), True (normalize(A x)), "dual" ((A x, normalize(A x))), "dual_acc" ((A x, acc + normalize(A
+    x)) with the running sum `acc` as a second input: the layer-list accumulation of mhcn.py:440-457 in the same launch; the
+    normalised copy is not kept, the backward rebuilds it from A x and 1 / |A x|)."""
 
     @staticmethod
-    def forward(ctx, graphs, modes, streams, *xs):
+    def forward(ctx, graphs, modes, streams, *tensors):
+        n = len(graphs)
+        xs, accs = list(tensors[:n]), list(tensors[n:])
         dev = xs[0].device
         cur = torch.cuda.current_stream(dev)
         xs = [x.contiguous() for x in xs]
+        accs = [None if a is None else a.contiguous() for a in accs]
         # outputs come from the caller's stream's pool; the join below orders every later reuse behind the side streams
         bufs = []
         for g, x, mode in zip(graphs, xs, modes):
             d = x.shape[1]
             y = torch.empty(g.n_rows, d, dtype=torch.float32, device=dev)
-            raw = torch.empty_like(y) if mode == "dual" else None
+            raw = torch.empty_like(y) if mode in ("dual", "dual_acc") else None
             inv = torch.empty(g.n_rows, dtype=torch.float32, device=dev) if mode else None
             bufs.append((y, raw, inv))
         start = torch.cuda.Event()
         start.record(cur)
-        for g, x, s, mode, (y, raw, inv) in zip(graphs, xs, streams, modes, bufs):
+        for g, x, a, s, mode, (y, raw, inv) in zip(graphs, xs, accs, streams, modes, bufs):
             s.wait_event(start)
             with torch.cuda.stream(s):
-                if mode == "dual":
+                if mode == "dual_acc":
+                    Fn.spmm_dual_acc_into(g, x, raw, a, y, inv)          # y = acc + normalize(A x)
+                elif mode == "dual":
                     Fn.spmm_dual_into(g, x, raw, y, inv)
                 else:
                     Fn.spmm_into(g, x, y=y, l2norm=bool(mode), inv_norm_out=inv)
         for s in streams[: len(graphs)]:
             cur.wait_stream(s)
         ctx.graphs, ctx.modes, ctx.streams = graphs, modes, streams
-        ctx.layout = []
         saved, outs = [], []
         for mode, (y, raw, inv) in zip(modes, bufs):
-            if mode == "dual":
+            if mode == "dual_acc":
+                outs += [raw, y]
+                saved += [raw, inv]
+            elif mode == "dual":
                 outs += [raw, y]
                 saved += [y, inv]
             elif mode:
@@ -437,10 +447,10 @@ class _MultiStreamSpMM(torch.autograd.Function):
         cur = torch.cuda.current_stream(dev)
         start = torch.cuda.Event()
         start.record(cur)
-        dxs, gi, si = [], 0, 0
+        dxs, daccs, gi, si = [], [], 0, 0
         used = []
         for g, s, mode in zip(graphs, streams, modes):
-            if mode == "dual":
+            if mode in ("dual", "dual_acc"):
                 g_raw, g_y = gs[gi], gs[gi + 1]
                 gi += 2
             else:
@@ -448,8 +458,9 @@ class _MultiStreamSpMM(torch.autograd.Function):
                 gi += 1
             y = inv = None
             if mode:
-                y, inv = saved[si], saved[si + 1]
+                y, inv = saved[si], saved[si + 1]                 # (dual_acc: y is the RAW product)
                 si += 2
+            daccs.append(g_y if mode == "dual_acc" else None)    # acc + n: the running sum's gradient passes through
             if g_raw is None and g_y is None:
                 dxs.append(None)
                 continue
@@ -458,17 +469,18 @@ class _MultiStreamSpMM(torch.autograd.Function):
             s.wait_event(start)
             with torch.cuda.stream(s):
                 # through the row normalise, one pass: (g - y <y, g>) / max(||A x||, eps) + g_raw
-                dz = Fn.normalize_bwd_n(y, inv, g_y, g_raw) if g_y is not None else g_raw.contiguous()
+                dz = Fn.normalize_bwd_n(y, inv, g_y, g_raw, from_raw=(mode == "dual_acc")) if g_y is not None \
+                    else g_raw.contiguous()
                 Fn.spmm_into(gt, dz, y=dx)
                 dz.record_stream(s)
             used.append(s)
             dxs.append(dx)
         for s in used:
             cur.wait_stream(s)
-        return (None, None, None, *dxs)
+        return (None, None, None, *dxs, *daccs)
 
 
-def multi_stream_spmm(graphs, xs, streams=None, l2norm=False):
+def multi_stream_spmm(graphs, xs, streams=None, l2norm=False, acc=None):
     """BASELINE config 5 (univariate/mhcn.py:440-456): the per-layer SpMMs over independent operators
     (H_s, H_j, H_p, R^T, R) launched on separate HIP streams so that they fill the chip together and
     can hide each other's tails / a concurrent all-gather.  Returns the outputs in order; the caller's
@@ -478,18 +490,28 @@ def multi_stream_spmm(graphs, xs, streams=None, l2norm=False):
     l2norm: False -> A x (`spmm`); True -> normalize(A x) only (SEPT-style, `spmm_l2norm`);
     "dual" -> the pair (A x, normalize(A x)) per operator (`spmm_l2norm_dual`) — what MHCN's layer loop
     needs: mhcn.py:440-442 feeds the RAW product to the next layer and appends the normalised copy to
-    the layer list.  A per-operator sequence of those values is accepted too."""
+    the layer list.  A per-operator sequence of those values is accepted too.
+    acc (with "dual"): one running sum [n_rows, d] per operator — the pair becomes (A x, acc + normalize(A x)), the
+    layer-list sum of mhcn.py:458-466 folded into the launch."""
     graphs, xs = list(graphs), list(xs)
     if streams is None:
         streams = [torch.cuda.Stream() for _ in graphs]
     modes = list(l2norm) if isinstance(l2norm, (list, tuple)) else [l2norm] * len(graphs)
+    accs = [None] * len(graphs) if acc is None else list(acc)
+    if len(accs) != len(graphs):
+        raise ValueError("acc: one running sum per operator")
+    for k, a in enumerate(accs):
+        if a is not None:
+            if modes[k] != "dual":
+                raise ValueError("acc needs l2norm='dual'")
+            modes[k] = "dual_acc"
     for x in xs:
         if not x.is_cuda:
             raise RuntimeError("multi_stream_spmm operates on HIP device tensors only")
-    flat = _MultiStreamSpMM.apply(graphs, modes, list(streams), *xs)
+    flat = _MultiStreamSpMM.apply(graphs, modes, list(streams), *xs, *accs)
     outs, k = [], 0
     for mode in modes:
-        if mode == "dual":
+        if mode in ("dual", "dual_acc"):
             outs.append((flat[k], flat[k + 1]))
             k += 2
         else:

@@ -208,10 +208,11 @@ def lightgcn_propagate(graph: CsrGraph, x0, n_layers: int, combine: str = "mean"
     return out
 
 
-def normalize_bwd_n(nrm, inv, g_n, g_raw=None, out=None):
+def normalize_bwd_n(nrm, inv, g_n, g_raw=None, out=None, from_raw=False):
     """d(A x) of `F.normalize(A x)` from the saved normalised rows: (g_n - nrm <nrm, g_n>) * inv (+ g_raw) in ONE pass
     (gcr_normalize_bwd_n_f32; sept.py:223-224, mhcn.py:440-457).  Rows clamped by eps have inv = 1e12 and nrm = 0.
-    `out` may be g_n or g_raw themselves (in place)."""
+    `out` may be g_n or g_raw themselves (in place).  from_raw: `nrm` holds the RAW rows A x (n = raw * inv on the fly,
+    gcr_normalize_bwd_raw_f32) — the forward of `spmm_dual_acc_into` keeps no normalised copy."""
     _lib.require_cuda(nrm, inv, g_n, g_raw, out)
     g_n = g_n.contiguous()
     g_raw = None if g_raw is None else g_raw.contiguous()
@@ -220,8 +221,9 @@ def normalize_bwd_n(nrm, inv, g_n, g_raw=None, out=None):
     rows, d = nrm.shape
     if g_n.shape != nrm.shape or out.shape != nrm.shape or (g_raw is not None and g_raw.shape != nrm.shape) or d % 4 or d > 256:
         raise ValueError("normalize_bwd_n: [rows, d] float32 tensors of one shape, d a multiple of 4 and <= 256")
-    _lib.check(_lib.lib().gcr_normalize_bwd_n_f32(_lib.dptr(nrm), _lib.dptr(inv), _lib.dptr(g_n), _lib.dptr(g_raw), rows, d,
-                                                  _lib.dptr(out), _lib.cur_stream(nrm.device)), "gcr_normalize_bwd_n_f32")
+    fn = _lib.lib().gcr_normalize_bwd_raw_f32 if from_raw else _lib.lib().gcr_normalize_bwd_n_f32
+    _lib.check(fn(_lib.dptr(nrm), _lib.dptr(inv), _lib.dptr(g_n), _lib.dptr(g_raw), rows, d, _lib.dptr(out),
+                  _lib.cur_stream(nrm.device)), "gcr_normalize_bwd_raw_f32" if from_raw else "gcr_normalize_bwd_n_f32")
     return out
 
 
@@ -454,6 +456,33 @@ def spmm_dual_into(graph: CsrGraph, x, y_raw, y_norm, inv_norm_out=None, keep_bi
     return y_raw, y_norm
 
 
+def spmm_dual_acc_into(graph: CsrGraph, x, y_raw, acc_in, acc_out, inv_norm_out, y_norm=None, keep_bits=None, val_scale=1.0):
+    """Raw launch of gcr_spmm_csr_dual_acc_f32: y_raw = A x, acc_out = acc_in + normalize(A x), inv_norm_out = 1 / |A x| per row
+    from one pass (mhcn.py:440-457: the normalised product joins a layer list that is summed); y_norm optional."""
+    _lib.require_cuda(x, y_raw, acc_in, acc_out, inv_norm_out, y_norm, keep_bits)
+    x = x.contiguous()
+    _check_dense(x, graph.n_cols, "x")
+    d = x.shape[1]
+    for t, nm in ((y_raw, "y_raw"), (acc_out, "acc_out"), (acc_in, "acc_in"), (y_norm, "y_norm")):
+        if t is None:
+            continue
+        _check_dense(t, graph.n_rows, nm)
+        if t.shape[1] != d or not t.is_contiguous():
+            raise ValueError(f"{nm} must be contiguous [{graph.n_rows}, {d}]")
+    if y_raw.data_ptr() == acc_out.data_ptr() or (y_norm is not None and y_norm.data_ptr() == y_raw.data_ptr()):
+        raise ValueError("y_raw, y_norm and acc_out must be different buffers")
+    if inv_norm_out is None or inv_norm_out.dtype != torch.float32 or inv_norm_out.numel() != graph.n_rows:
+        raise ValueError("inv_norm_out must be float32 [n_rows]")
+    p = graph.plan
+    rc = _lib.lib().gcr_spmm_csr_dual_acc_f32(
+        _lib.dptr(p.desc), p.n_parts, _lib.dptr(p.long_row), _lib.dptr(p.long_slot0), p.n_long,
+        _lib.dptr(graph.rowptr), _lib.dptr(graph.col), _lib.dptr(graph.val), _lib.dptr(keep_bits), float(val_scale),
+        _lib.dptr(x), d, _lib.dptr(y_raw), _lib.dptr(y_norm), _lib.dptr(acc_in), _lib.dptr(acc_out), _lib.dptr(inv_norm_out),
+        _lib.dptr(graph.workspace(d)), graph.n_rows, graph.n_cols, _lib.cur_stream(x.device))
+    _lib.check(rc, "gcr_spmm_csr_dual_acc_f32")
+    return y_raw, acc_out
+
+
 class _NormPropDual(torch.autograd.Function):
     """One MHCN channel layer: (z, n) = (A x, normalize(A x)) from one launch (univariate/mhcn.py:440-442:
     the RAW product feeds the next layer, the normalised copy joins the layer list)."""
@@ -488,6 +517,39 @@ def spmm_l2norm_dual(graph: CsrGraph, x):
     the MHCN layer step (univariate/mhcn.py:440-457), differentiable w.r.t. x through both outputs."""
     _lib.require_cuda(x)
     return _NormPropDual.apply(x, graph)
+
+
+class _NormPropDualAcc(torch.autograd.Function):
+    """(z, acc + normalize(z)), z = A x, from one launch (gcr_spmm_csr_dual_acc_f32): the layer-list accumulation of
+    mhcn.py:440-457 folded into the product; saves z and 1 / |z| (no normalised copy)."""
+
+    @staticmethod
+    def forward(ctx, x, acc, graph):
+        z = torch.empty(graph.n_rows, x.shape[1], dtype=torch.float32, device=x.device)
+        out = torch.empty_like(z)
+        inv = torch.empty(graph.n_rows, dtype=torch.float32, device=x.device)
+        spmm_dual_acc_into(graph, x, z, acc.contiguous(), out, inv)
+        ctx.graph = graph
+        ctx.save_for_backward(z, inv)
+        ctx.set_materialize_grads(False)
+        return z, out
+
+    @staticmethod
+    def backward(ctx, gz, gs):
+        z, inv = ctx.saved_tensors
+        if gz is None and gs is None:
+            return None, None, None
+        dz = normalize_bwd_n(z, inv, gs, gz, from_raw=True) if gs is not None else gz
+        gt = ctx.graph.t
+        dx = torch.empty(gt.n_rows, dz.shape[1], dtype=torch.float32, device=dz.device)
+        spmm_into(gt, dz.contiguous(), y=dx)
+        return dx, gs, None
+
+
+def spmm_l2norm_dual_acc(graph: CsrGraph, x, acc):
+    """(A x, acc + F.normalize(A x, p=2, dim=1)) in one kernel: `spmm_l2norm_dual` with the running layer sum folded in."""
+    _lib.require_cuda(x, acc)
+    return _NormPropDualAcc.apply(x, acc, graph)
 
 
 class _SplitRows(torch.autograd.Function):

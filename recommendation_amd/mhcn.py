@@ -68,12 +68,15 @@ class MHCNEncoder(nn.Module):
         return (mixed if extra is None else mixed + extra_scale * extra), score
 
     # -- the layer loop (mhcn.py:422-466) -------------------------------------------------------
-    def _five_spmm(self, c1, c2, c3, mixed, items):
+    def _five_spmm(self, c1, c2, c3, mixed, items, sums=None):
+        """The five dual products of one layer; sums (per operator: the running sum its normalised product joins): each
+        pair comes back as (raw product, sum + normalised product) from the same launch."""
         graphs = [self.H_s, self.H_j, self.H_p, self.R.t, self.R]
         xs = [c1, c2, c3, mixed, items]
         if self._streams is not None:
-            return multi_stream_spmm(graphs, xs, self._streams, l2norm="dual")
-        return [Fn.spmm_l2norm_dual(g, x) for g, x in zip(graphs, xs)]
+            return multi_stream_spmm(graphs, xs, self._streams, l2norm="dual", acc=sums)
+        pairs = [Fn.spmm_l2norm_dual(g, x) for g, x in zip(graphs, xs)]
+        return pairs if sums is None else [(raw, a + n) for (raw, n), a in zip(pairs, sums)]
 
     def propagate(self):
         """(final_user_embeddings [U, d], final_item_embeddings [I, d])."""
@@ -83,8 +86,10 @@ class MHCNEncoder(nn.Module):
         sums = [c1, c2, c3, simple, items]          # running sums of the layer lists (layer 0 = the inputs)
         for _ in range(self.n_layers):
             mixed, _ = self.channel_attention(c1, c2, c3, extra=simple, extra_scale=0.5)
-            (c1, n1), (c2, n2), (c3, n3), (new_items, n_i), (simple, n_s) = self._five_spmm(c1, c2, c3, mixed, items)
-            sums = [sums[0] + n1, sums[1] + n2, sums[2] + n3, sums[3] + n_s, sums[4] + n_i]
+            # operator order H_s, H_j, H_p, R^T (-> items), R (-> simple): their running sums are sums[0..2], sums[4], sums[3]
+            (c1, s0), (c2, s1), (c3, s2), (new_items, s4), (simple, s3) = \
+                self._five_spmm(c1, c2, c3, mixed, items, [sums[0], sums[1], sums[2], sums[4], sums[3]])
+            sums = [s0, s1, s2, s3, s4]
             items = new_items
         final_user, _ = self.channel_attention(sums[0], sums[1], sums[2], extra=sums[3], extra_scale=0.5)
         return final_user, sums[4]
@@ -173,11 +178,19 @@ class ShardedMHCNEncoder(MHCNEncoder):
         sums = [c1, c2, c3, simple, items]
         for _ in range(self.n_layers):
             mixed, _ = self.channel_attention(c1, c2, c3, extra=simple, extra_scale=0.5)
-            (c1, n1), (c2, n2), (c3, n3) = gd.sharded_channel_layer(ch, [c1, c2, c3], ops.channel_dual, ops.channel_spmm_t)
+            hip = ops is HipOps          # the HIP launches fold the layer-list sums in (CPU stand-ins: separate adds)
+            pairs = gd.sharded_channel_layer(ch, [c1, c2, c3], ops.channel_dual, ops.channel_spmm_t,
+                                             accs=sums[:3] if hip else None)
             new_items = gd.all_reduce_sum(ops.spmm(self.R.t, mixed), ch.group)      # R^T mixed: sum over the ranks' users
             n_i = torch.nn.functional.normalize(new_items, p=2, dim=1)
-            simple, n_s = ops.dual(self.R, items)
-            sums = [sums[0] + n1, sums[1] + n2, sums[2] + n3, sums[3] + n_s, sums[4] + n_i]
+            if hip:
+                (c1, s0), (c2, s1), (c3, s2) = pairs
+                simple, s3 = Fn.spmm_l2norm_dual_acc(self.R, items, sums[3])
+            else:
+                (c1, n1), (c2, n2), (c3, n3) = pairs
+                simple, n_s = ops.dual(self.R, items)
+                s0, s1, s2, s3 = sums[0] + n1, sums[1] + n2, sums[2] + n3, sums[3] + n_s
+            sums = [s0, s1, s2, s3, sums[4] + n_i]
             items = new_items
         final_user, _ = self.channel_attention(sums[0], sums[1], sums[2], extra=sums[3], extra_scale=0.5)
         return final_user, sums[4]

@@ -56,6 +56,34 @@ def test_dual_output_spmm_matches_oracle(d):
     _close(xt.grad, ref_dx, 2e-5)
 
 
+@pytest.mark.parametrize("d", [64, 48, 128])
+def test_dual_output_spmm_with_the_layer_sum_folded_in(d):
+    """gcr_spmm_csr_dual_acc_f32 (`Fn.spmm_l2norm_dual_acc`): (A x, acc + normalize(A x)) = the dual launch followed by the add,
+    bit for bit; its backward (the normalised rows rebuilt from the raw ones, gcr_normalize_bwd_raw_f32) = the composition's,
+    for x and for the running sum; empty and split rows."""
+    import recommendation_amd as ra
+    from recommendation_amd import functional as Fn
+    rng = np.random.default_rng(100 + d)
+    n_r, n_c, nnz = 700, 500, 9000
+    row, col = rng.integers(0, n_r, nnz), rng.integers(0, n_c, nnz)
+    row[row == 3] = 4
+    row[:1500] = 11
+    g = ra.CsrGraph.from_coo(row, col, rng.standard_normal(nnz).astype(np.float32), n_r, n_c, DEV)
+    x1 = torch.from_numpy(rng.standard_normal((n_c, d)).astype(np.float32)).to(DEV).requires_grad_(True)
+    a1 = torch.from_numpy(rng.standard_normal((n_r, d)).astype(np.float32)).to(DEV).requires_grad_(True)
+    x2, a2 = x1.detach().clone().requires_grad_(True), a1.detach().clone().requires_grad_(True)
+    w1 = torch.from_numpy(rng.standard_normal((n_r, d)).astype(np.float32)).to(DEV)
+    w2 = torch.from_numpy(rng.standard_normal((n_r, d)).astype(np.float32)).to(DEV)
+    raw1, sum1 = Fn.spmm_l2norm_dual_acc(g, x1, a1)
+    raw2, nrm2 = Fn.spmm_l2norm_dual(g, x2)
+    sum2 = a2 + nrm2
+    assert torch.equal(raw1, raw2) and torch.equal(sum1, sum2)
+    ((raw1 * w1).sum() + (sum1 * w2).sum()).backward()
+    ((raw2 * w1).sum() + (sum2 * w2).sum()).backward()
+    assert torch.equal(a1.grad, a2.grad)
+    assert float((x1.grad - x2.grad).abs().max()) <= 2e-6 * float(x2.grad.abs().max())
+
+
 def test_mhcn_forward_matches_reference(golden):
     from recommendation_amd.mhcn import MHCNEncoder
     z = golden("mhcn.npz")

@@ -431,8 +431,10 @@ int32_t gcr_channel_mix_bwd_f32(const float* g, const float* e1, const float* e2
  * on TWO f16 planes and three product terms instead of three bf16 planes and six.  The rows are not unit rows, so a pre-pass
  * takes every row's norm, the loops see unit rows (operands rounded at 2^-22 of the row's norm) and every score is
  * un-scaled by its two norms before the softplus / sigmoid; the second product carries norm x weight of the streamed row,
- * shifted into f16 range by a power of two.  Half the matrix-core work; |score error| a few 2^-24 |a_i| |b_j| — the f32 dot
- * product's own class.  gcr_bce_bwd_f32 with the weights on the stationary rows (w_x) ignores the flag. */
+ * shifted into f16 range by a power of two, and sigmoid against a running power-of-two reference per output row (rescaled
+ * like a flash forward), so that a row whose sigmoids are all tiny keeps its digits.  Half the matrix-core work; |score
+ * error| a few 2^-24 |a_i| |b_j| — the f32 dot product's own class; terms below 2^-39 of (largest sigmoid of the row) x
+ * (largest norm x weight) are flushed.  gcr_bce_bwd_f32 with the weights on the stationary rows (w_x) ignores the flag. */
 #define GCR_BCE_TWO_PLANES 8u
 /* 1 when gcr_bce_fwd_f32 can also return o (d <= 64 on the split-operand engine) */
 int32_t gcr_bce_fwd_o_supported(int32_t d, uint32_t flags);

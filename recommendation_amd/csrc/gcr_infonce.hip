@@ -1501,6 +1501,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
   // the norms, w_y the streamed rows' factor of the second product (norm x weight, pre-scaled into f16 range by hw[0]).
   constexpr bool UNS = MODE >= 2 && std::is_same<E, EngH2>::value;
   constexpr bool STATS = (BWD && SIDES != 1) || UNS;         // per-row values of the streamed rows ride with the tiles
+  // UNSREF (UNS with a second product): the probabilities sigmoid x (norm x weight) go into f16 planes, whose floor would
+  // flush a row whose sigmoids are ALL tiny.  Every stationary row therefore carries a running power-of-two reference 2^q,
+  // q ~ log2 of the largest sigmoid seen so far (min(s_max, 0): within one bit of it), the planes hold sigmoid 2^-q x
+  // (norm x weight) <= 2^15, the accumulators are rescaled when a tile raises q by more than one (the flash forward's
+  // deferred rescale, rare after the first tiles) and the result is multiplied by 2^q on the way out.
+  constexpr bool UNSREF = UNS && !NOO;
   static_assert(MODE < 2 || (!EXD && NW == 4), "BCE modes: four waves");
   static_assert(MODE != 3 || SIDES == 1 || SIDES == 2, "BCE backward: weights on one side");
   static_assert(!(UNS && MODE == 3 && SIDES == 1), "two-plane BCE backward: the weights sit on the streamed rows");
@@ -1533,7 +1539,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
   const float e_x = (MODE == 0 && on_x) ? fmaf(-lse_x[row_i], kLog2e, __log2f(fabsf(wl))) : -1.0e30f;
   u32x4 bq[1][NPL][S::KC];
   load_stationary_e<E, D>(x, x_scale, mx, row_i, h, scale2 * E::kSX * sgn_x, bq[0]);
-  float m_run = kNegBig, l_run = 0.f;                   // MODE 1
+  float m_run = UNSREF ? -100.0f : kNegBig, l_run = 0.f;   // MODE 1: reference point of the row; UNSREF: q
   f32x16 gacc[B::CT];
 #pragma unroll
   for (int c = 0; c < B::CT; ++c)
@@ -1622,7 +1628,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
     // each; MODE 1: the same after `prepare` fixed the reference point.
     float m_use = kNegBig, alpha = 1.0f, psum = 0.f, p_off = 0.f;
     bool rescale = false;
-    auto prepare = [&](f32x16& acc, int64_t t) {        // masks (ragged tile / excluded diagonal); MODE 1: reference point
+    auto prepare = [&](f32x16& acc, int64_t t, int sbuf) {   // masks (ragged tile / excluded diagonal); MODE 1: reference point
       const int64_t j0 = t * kTileJ;
       const int lim = (int)min((int64_t)kTileJ, ny - j0);   // rows of this tile that exist (wave-uniform)
       // (statistics on the streamed rows only, MODE 0 / SIDES 2: no end-of-array mask — rows behind the end carry w' = 0
@@ -1655,6 +1661,22 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
         p_off = E::kPExp - m_use;
       }
       if (MODE == 2) psum = 0.f;
+      if (UNSREF) {
+        // scores un-scaled here (so that their maximum is known before the first probability), q from the largest one
+        float smax = -INFINITY;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 l4 = *reinterpret_cast<const float4*>(&st_lse[sbuf][8 * g + 4 * h]);
+          acc[4 * g + 0] *= rs * l4.x; acc[4 * g + 1] *= rs * l4.y; acc[4 * g + 2] *= rs * l4.z; acc[4 * g + 3] *= rs * l4.w;
+          smax = fmaxf(fmaxf(fmaxf(fmaxf(smax, acc[4 * g]), acc[4 * g + 1]), acc[4 * g + 2]), acc[4 * g + 3]);
+        }
+        smax = fmaxf(smax, __shfl_xor(smax, 32, 64));       // both lane halves feed the same output row
+        const float q_tile = fmaxf(fminf(smax, 0.f), -100.0f);
+        rescale = __any(q_tile > m_run + 1.0f);
+        m_use = rescale ? fmaxf(m_run, q_tile) : m_run;
+        alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+        p_off = __builtin_amdgcn_exp2f(-m_use);             // 2^-q: what a probability is multiplied by
+      }
     };
     // streamed rows' statistics (MODE 0, SIDES != 1): accumulator register r = 4 g + e of lane half h is tile row
     // 8 g + 4 h + e, so ONE ds_read_b128 per array serves four consecutive P units; group g + 1 is fetched while group g
@@ -1681,7 +1703,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
           lre = e == 0 ? l4.x : (e == 1 ? l4.y : (e == 2 ? l4.z : l4.w));
           wre = e == 0 ? w4.x : (e == 1 ? w4.y : (e == 2 ? w4.z : w4.w));
         }
-        const float unscale = UNS ? rs * lre : E::kSInv;   // accumulator -> log2-domain score
+        const float unscale = UNSREF ? 1.0f : (UNS ? rs * lre : E::kSInv);   // accumulator -> log2-domain score (UNSREF: done in `prepare`)
         if (MODE == 1) {
           acc[r] = __builtin_amdgcn_exp2f(fmaf(acc[r], E::kSInv, p_off));
           psum += acc[r];
@@ -1689,11 +1711,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
           float sp, sg;
           bce_terms(acc[r] * unscale, sp, sg);
           psum += sp;
-          acc[r] = UNS ? sg * wre : sg;
+          acc[r] = UNSREF ? sg * (wre * p_off) : (UNS ? sg * wre : sg);
         } else {
           const float sc = acc[r];
           if (MODE == 3) {
-            acc[r] = (SIDES == 1 ? wl : wre) * bce_sigmoid(sc * unscale);
+            acc[r] = (SIDES == 1 ? wl : (UNSREF ? wre * p_off : wre)) * bce_sigmoid(sc * unscale);
           } else if (SIDES == 1) acc[r] = __builtin_amdgcn_exp2f(fmaf(sc, c_x, e_x));
           else if (FOLD) acc[r] = __builtin_amdgcn_exp2f(fmaf(sc, wre, lre));
           else if (SIDES == 2) acc[r] = wre * __builtin_amdgcn_exp2f(fmaf(sc, E::kSInv, -lre));
@@ -1722,6 +1744,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
         l_run += psum;
       }
       if (MODE == 2) l_run += psum;
+      if (UNSREF && rescale) {
+#pragma unroll
+        for (int c = 0; c < B::CT; ++c)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) gacc[c][r] *= alpha;
+        m_run = m_use;
+      }
     };
     auto score_plain = [&](const unsigned char* rm, f32x16& acc) {
 #pragma unroll
@@ -1747,7 +1776,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
     load_tile(tile0 + 2, ra, sla, swa);
     __syncthreads();
     score_plain(lds_rm[0], acc);
-    prepare(acc, tile0);
+    prepare(acc, tile0, 0);
     stats_begin(0);
 #pragma unroll
     for (int m = 0; m < 24; ++m) p_unit(m, acc, 0, pqa);
@@ -1795,7 +1824,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
         }
       }
       if (NW == 8) __syncthreads();                      // interval boundary: the partner group moves on to its score phase
-      if (BWD || real_next) prepare(acc, t + 1);
+      if (BWD || real_next) prepare(acc, t + 1, slot1);
       stats_begin(slot1);
       __builtin_amdgcn_sched_barrier(0);
       // phase B: second product of tile t || P(t+1)
@@ -1869,7 +1898,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : E::kMinBlocks) void infonce_
       part[(int64_t)split * mx + row_i] =
           MODE == 2 ? make_float2(0.f, l_run + l_o) : make_float2(m_run, (l_run + l_o) * __builtin_amdgcn_exp2f(-E::kPExp));
   }
-  const float o_mul = out_scale * (hw != nullptr ? hw[1] : 1.0f) * sgn_x;
+  const float o_mul = out_scale * (hw != nullptr ? hw[1] : 1.0f) * sgn_x * (UNSREF ? __builtin_amdgcn_exp2f(m_run) : 1.0f);
   if (!NOO && row_i < mx) {
 #pragma unroll
     for (int c = 0; c < B::CT; ++c)

@@ -191,6 +191,9 @@ int32_t gcr_bpr_neg_block_f32(const float* dloss_dx, const int64_t* j_idx, const
  * gcr_bpr_neg_items_sorted_f32 walks the sorted arrays in 64-entry chunks and adds, per run of equal keys,
  * sum coef U[u] + 2 g_3 (#entries) I[j] to grad_item[j] with one row atomic — key, user and coefficient arrive by coalesced
  * loads instead of perm -> sample -> (u_idx, dloss_dx) as in gcr_bpr_bwd_sorted_f32's third launch. */
+/* (col, val, dropped_per_user may be NULL together when only the sort key / payload are wanted — any batch of triples, not
+ * only a graph's edge list; gcr_bpr_bwd_sorted_f32 with keys_j == perm_j == NULL then leaves the negatives' item rows to
+ * gcr_bpr_neg_items_sorted_f32.) */
 int64_t gcr_sort_pairs_u64_workspace_bytes(int64_t n);
 int32_t gcr_sort_pairs_u64(const uint32_t* keys, const uint64_t* payload, int64_t n, int64_t n_keys, uint32_t* keys_sorted,
                            uint64_t* payload_sorted, void* workspace, void* stream);

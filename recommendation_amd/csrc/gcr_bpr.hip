@@ -372,10 +372,12 @@ __global__ __launch_bounds__(256) void bpr_neg_block_kernel(const float* __restr
     const int64_t j = j_idx[s];
     const bool live = dl == dl && j >= 0 && j < n_items;   // (a bad id anywhere in the sample left NaN in dloss_dx)
     const float v = live ? g * dl : 0.f;
-    col[s] = live ? (int32_t)j : 0;
-    val[s] = v;
+    if (col != nullptr) {
+      col[s] = live ? (int32_t)j : 0;
+      val[s] = v;
+    }
     const int64_t u = u_idx[e];
-    if (!(dl == dl) && s == e * n_neg) atomicAdd(dropped_per_user + u, 1.0f);
+    if (dropped_per_user != nullptr && !(dl == dl) && s == e * n_neg) atomicAdd(dropped_per_user + u, 1.0f);
     if (sort_key) {                                         // the same slot for the ITEM side: key j, payload (u, value)
       sort_key[s] = live ? (uint32_t)j : (uint32_t)n_items;
       sort_payload[s] = live ? ((uint64_t)(uint32_t)u << 32) | (uint64_t)__builtin_bit_cast(uint32_t, v) : 0ull;
@@ -556,7 +558,8 @@ extern "C" int32_t gcr_bpr_bwd_sorted_f32(const float* user_tab, const float* it
   GCR_CHECK_ARG(batch * n_neg < (1ll << 31));
   if (batch == 0) return GCR_OK;
   GCR_CHECK_ARG(user_tab && item_tab && u_idx && j_idx && dloss_dx && grad_sums && grad_user && grad_item);
-  GCR_CHECK_ARG(keys_j && perm_j && (keys_i != nullptr) == (perm_i != nullptr) && (keys_u != nullptr) == (perm_u != nullptr));
+  GCR_CHECK_ARG((keys_j != nullptr) == (perm_j != nullptr) && (keys_i != nullptr) == (perm_i != nullptr) &&
+                (keys_u != nullptr) == (perm_u != nullptr));
   const bool pos = keys_i != nullptr;                     // false: the caller adds the positive-pair parts (gcr.h)
   const bool user_side = keys_u != nullptr;               // false (only without the positive parts): the caller adds the
   GCR_CHECK_ARG(!pos || (i_idx != nullptr && user_side)); // users' rows too (gcr_bpr_neg_block_f32 + one SpMM)
@@ -590,7 +593,7 @@ extern "C" int32_t gcr_bpr_bwd_sorted_f32(const float* user_tab, const float* it
   } else if (user_side) {                                     \
     GCR_NEG0(NV);                                             \
   }                                                           \
-  GCR_SIDE(2, NV, keys_j, perm_j, batch * n_neg, grad_item)
+  if (keys_j != nullptr) { GCR_SIDE(2, NV, keys_j, perm_j, batch * n_neg, grad_item); }
   if (d <= 64) { GCR_ALL(1); }
   else if (d <= 128) { GCR_ALL(2); }
   else if (d <= 192) { GCR_ALL(3); }
@@ -618,8 +621,10 @@ extern "C" int32_t gcr_bpr_neg_block_f32(const float* dloss_dx, const int64_t* j
                                          float* dropped_per_user, uint32_t* sort_key, uint64_t* sort_payload, void* stream) {
   GCR_CHECK_ARG(batch >= 0 && n_neg >= 1 && n_items >= 1 && batch * n_neg < (1ll << 40));
   if (batch == 0) return GCR_OK;
-  GCR_CHECK_ARG(dloss_dx && j_idx && u_idx && grad_sums && col && val && dropped_per_user);
+  GCR_CHECK_ARG(dloss_dx && j_idx && u_idx && grad_sums);
+  GCR_CHECK_ARG((col != nullptr) == (val != nullptr) && (col != nullptr) == (dropped_per_user != nullptr));
   GCR_CHECK_ARG((sort_key != nullptr) == (sort_payload != nullptr) && (!sort_key || n_items < 0xFFFFFFFFll));
+  GCR_CHECK_ARG(col != nullptr || sort_key != nullptr);
   const int64_t want = (batch * n_neg + 255) / 256;
   hipLaunchKernelGGL(bpr_neg_block_kernel, dim3((unsigned)(want > 65536 ? 65536 : want)), dim3(256), 0, (hipStream_t)stream,
                      dloss_dx, j_idx, u_idx, batch, (int)n_neg, n_items, grad_sums, col, val, dropped_per_user, sort_key,

@@ -684,12 +684,32 @@ class _BprSums(torch.autograd.Function):
         if batch >= BPR_SORTED_MIN_BATCH and batch * ctx.n_neg < 2 ** 31:
             ku, pu, _ = _sorted_order(u_idx, user_tab.shape[0], cache=True)
             ki, pi, _ = _sorted_order(i_idx, item_tab.shape[0], cache=True)
-            kj, pj, _ = _sorted_order(j_idx.reshape(-1), item_tab.shape[0])       # fresh negatives every step
-            _lib.check(_lib.lib().gcr_bpr_bwd_sorted_f32(
+            L = _lib.lib()
+            dev, stream = user_tab.device, _lib.cur_stream(user_tab.device)
+            n_users, n_items, slots = user_tab.shape[0], item_tab.shape[0], batch * ctx.n_neg
+            kj = pj = None
+            if not BPR_NEG_PAYLOAD_SORT:
+                kj, pj, _ = _sorted_order(j_idx.reshape(-1), n_items)             # fresh negatives every step
+            _lib.check(L.gcr_bpr_bwd_sorted_f32(
                 _lib.dptr(user_tab), _lib.dptr(item_tab), user_tab.shape[1], _lib.dptr(u_idx), _lib.dptr(i_idx),
-                _lib.dptr(j_idx), batch, ctx.n_neg, user_tab.shape[0], item_tab.shape[0], _lib.dptr(dldx),
+                _lib.dptr(j_idx), batch, ctx.n_neg, n_users, n_items, _lib.dptr(dldx),
                 _lib.dptr(gs), _lib.dptr(ku), _lib.dptr(pu), _lib.dptr(ki), _lib.dptr(pi), _lib.dptr(kj), _lib.dptr(pj),
-                _lib.dptr(gu), _lib.dptr(gi), _lib.cur_stream(user_tab.device)), "gcr_bpr_bwd_sorted_f32")
+                _lib.dptr(gu), _lib.dptr(gi), stream), "gcr_bpr_bwd_sorted_f32")
+            if BPR_NEG_PAYLOAD_SORT:
+                # the negatives' item rows: fresh every step, so their sort carries (user, coefficient) with the key and the
+                # scatter streams sorted arrays (gcr_bpr_neg_items_sorted_f32) instead of gathering through a sorted index
+                skey = torch.empty(slots, dtype=torch.int32, device=dev)
+                spay = torch.empty(slots, dtype=torch.int64, device=dev)
+                _lib.check(L.gcr_bpr_neg_block_f32(_lib.dptr(dldx), _lib.dptr(j_idx), _lib.dptr(u_idx), batch, ctx.n_neg, n_items,
+                                                   _lib.dptr(gs), None, None, None, _lib.dptr(skey), _lib.dptr(spay), stream),
+                           "gcr_bpr_neg_block_f32")
+                ks, ps = torch.empty_like(skey), torch.empty_like(spay)
+                ws = torch.empty(int(L.gcr_sort_pairs_u64_workspace_bytes(slots)), dtype=torch.uint8, device=dev)
+                _lib.check(L.gcr_sort_pairs_u64(_lib.dptr(skey), _lib.dptr(spay), slots, n_items, _lib.dptr(ks), _lib.dptr(ps),
+                                                _lib.dptr(ws), stream), "gcr_sort_pairs_u64")
+                _lib.check(L.gcr_bpr_neg_items_sorted_f32(_lib.dptr(user_tab), _lib.dptr(item_tab), user_tab.shape[1],
+                                                          _lib.dptr(ks), _lib.dptr(ps), slots, n_users, n_items, _lib.dptr(gs),
+                                                          _lib.dptr(gi), stream), "gcr_bpr_neg_items_sorted_f32")
             return gu, gi, None, None, None, None
         _lib.check(_lib.lib().gcr_bpr_bwd_f32(
             _lib.dptr(user_tab), _lib.dptr(item_tab), user_tab.shape[1], _lib.dptr(u_idx), _lib.dptr(i_idx),

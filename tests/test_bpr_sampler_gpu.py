@@ -206,16 +206,21 @@ def test_sorted_backward_equals_atomic_backward(Fn, monkeypatch, d, n_neg):
         j[123] = -7
     w = torch.tensor([1.0 / bsz, 3e-4, 2e-4, 1e-4, 0.0], device="cuda")
     grads = {}
-    for mode, thr in (("atomic", 1 << 40), ("sorted", 1)):
+    # sorted: the negatives' item rows from the sort that carries (user, coefficient) with the key; sorted_index: from the
+    # index sort (gcr_bpr_bwd_sorted_f32's third launch)
+    for mode, thr, payload in (("atomic", 1 << 40, True), ("sorted", 1, True), ("sorted_index", 1, False)):
         monkeypatch.setattr(Fn, "BPR_SORTED_MIN_BATCH", thr)
+        monkeypatch.setattr(Fn, "BPR_NEG_PAYLOAD_SORT", payload)
         ut = torch.from_numpy(ut0).cuda().requires_grad_(True)
         it = torch.from_numpy(it0).cuda().requires_grad_(True)
         sums = Fn.bpr_sums(ut, it, u, i, j, Fn.BPR_LOGSIGMOID)
         assert float(sums[4]) == 3.0
         (sums * w).sum().backward()
         grads[mode] = (ut.grad.cpu().numpy(), it.grad.cpu().numpy())
-    for a, s in zip(grads["atomic"], grads["sorted"]):
-        np.testing.assert_allclose(s, a, rtol=2e-4, atol=2e-6 * np.abs(a).max())
+    for other in ("sorted", "sorted_index"):
+        for a, s in zip(grads["atomic"], grads[other]):
+            np.testing.assert_allclose(s, a, rtol=2e-4, atol=2e-6 * np.abs(a).max())
+    monkeypatch.setattr(Fn, "BPR_NEG_PAYLOAD_SORT", True)
     # and against the float64 oracle on the valid samples
     ok = np.ones(bsz, bool)
     ok[[17, 99, 123]] = False
